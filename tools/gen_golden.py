@@ -1,0 +1,388 @@
+#!/opt/conda/bin/python3.9
+"""
+Generate the golden fixtures under ``tests/golden/`` by running the *reference* TBmodels
+(``/root/reference/src/tbmodels``, imported unmodified) in THIS container.
+
+Run as::
+
+    /opt/conda/bin/python3.9 tools/gen_golden.py
+
+The reference only imports under the conda interpreter (numpy 1.26 / scipy 1.7 / h5py): the system
+python3 has numpy 2 (``np.complex_`` is gone) and no h5py.  Two things the reference imports are
+not installed anywhere in the image, so they are satisfied in memory, without touching
+``/root/reference``:
+
+* ``fsc.hdf5_io`` (third-party serialisation helper, only used for (de)serialisation decorators
+  at ``_tb_model.py:26,47`` / ``kdotp.py:14,19`` / ``io.py:11``) -> a stub module;
+* ``importlib.metadata.version("tbmodels")`` (``__init__.py:7``; the package is not installed).
+
+What is written is DATA only (inputs and the reference's outputs); no reference source travels.
+The fixtures (all ``.npz``, < 2 MB in total) and what produced them:
+
+``silicon.npz``      F1+F2+F3: the silicon model of ``tests/samples/cli_eigenvals/silicon_model.hdf5``
+                     as packed arrays, the reference's stored known answer
+                     (``silicon_eigenvals.hdf5``, checked at 1e-10 by ``tests/test_cli_eigenvals.py:48``),
+                     the reference's H(k) (conventions 1 and 2) and eigenvalues on KPT
+                     (``tests/parameters.py:8``) and on the 10x10x10 grid of BASELINE config 1,
+                     and the stored H(k) golden of ``tests/regression_data/test_wannier/``.
+``toy.npz``          F4: the 2-orbital model of ``tests/conftest.py:155-189`` for all T_VALUES, its
+                     ``hop`` as the reference constructs it, the stored goldens of
+                     ``tests/regression_data/test_hamilton`` / ``test_eigenval`` and the
+                     reference's live output for the same calls.
+``synthetic.npz``    F5: small models from ``tbmodels_amd/synthetic.py`` (the generator bench.py
+                     uses at full size) pushed through the reference: dense, CSR, dim 1/2,
+                     scalar k, empty hop, convention 1 with non-zero positions.
+``kdotp.npz``        ``KdotpModel`` + ``Model.construct_kdotp`` outputs.
+"""
+
+import importlib.util
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+# ---------------------------------------------------------------------------------------------
+# import the reference
+# ---------------------------------------------------------------------------------------------
+def _import_reference():
+    fsc = types.ModuleType("fsc")
+    hdf5_io = types.ModuleType("fsc.hdf5_io")
+
+    def subscribe_hdf5(*_args, **_kwargs):
+        return lambda cls: cls
+
+    class HDF5Enabled:  # pylint: disable=too-few-public-methods
+        pass
+
+    class SimpleHDF5Mapping(HDF5Enabled):  # pylint: disable=too-few-public-methods
+        pass
+
+    def _unavailable(*_a, **_k):
+        raise RuntimeError("fsc.hdf5_io is not installed; the stub has no (de)serialisation")
+
+    hdf5_io.subscribe_hdf5 = subscribe_hdf5
+    hdf5_io.HDF5Enabled = HDF5Enabled
+    hdf5_io.SimpleHDF5Mapping = SimpleHDF5Mapping
+    hdf5_io.save = _unavailable
+    hdf5_io.load = _unavailable
+    hdf5_io.from_hdf5_file = _unavailable
+    hdf5_io.to_hdf5_file = _unavailable
+    fsc.hdf5_io = hdf5_io
+    sys.modules["fsc"] = fsc
+    sys.modules["fsc.hdf5_io"] = hdf5_io
+
+    import importlib.metadata as ilm
+
+    real_version = ilm.version
+
+    def version(name):
+        return "1.4.4" if name == "tbmodels" else real_version(name)
+
+    ilm.version = version
+    sys.path.insert(0, os.path.join(REF, "src"))
+    warnings.filterwarnings("ignore")
+    import tbmodels  # pylint: disable=import-error,import-outside-toplevel
+
+    return tbmodels
+
+
+def _load_synthetic():
+    spec = importlib.util.spec_from_file_location("tbk_synthetic", os.path.join(REPO, "tbmodels_amd", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------
+def _read_fsc_value(group):
+    """Decode the fsc.hdf5_io encoding used by tests/regression_data (lists of numbers, nested)."""
+    if "value" in group:
+        return group["value"][()]
+    keys = sorted((k for k in group.keys() if k != "type_tag"), key=int)
+    return [_read_fsc_value(group[k]) for k in keys]
+
+
+def _regression(module, name):
+    import h5py  # pylint: disable=import-outside-toplevel
+
+    path = os.path.join(REF, "tests", "regression_data", module, name)
+    with h5py.File(path, "r") as handle:
+        return np.array(_read_fsc_value(handle))
+
+
+def _pack_hop(model):
+    """model.hop (dict R -> matrix) as (R int32 (n,dim), hop complex128 (n,N,N)) in dict order."""
+    keys = list(model.hop.keys())
+    r_vec = np.array(keys, dtype=np.int32).reshape(len(keys), model.dim)
+    hop = np.zeros((len(keys), model.size, model.size), dtype=np.complex128)
+    for idx, key in enumerate(keys):
+        hop[idx] = np.array(model.hop[key])
+    return r_vec, hop
+
+
+def _eig(model, k):
+    res = model.eigenval(k)
+    return np.array(res)
+
+
+KPT = [(0.1, 0.2, 0.7), (-0.3, 0.5, 0.2), (0.0, 0.0, 0.0), (0.1, -0.9, -0.7)]
+T_VALUES = [(t1, t2) for t1 in [-0.1, 0.2, 0.3] for t2 in [-0.2, 0.5]]
+
+
+# ---------------------------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------------------------
+def gen_silicon(tbmodels, syn):
+    import h5py  # pylint: disable=import-outside-toplevel
+
+    sample_dir = os.path.join(REF, "tests", "samples", "cli_eigenvals")
+    model = tbmodels.Model.from_hdf5_file(os.path.join(sample_dir, "silicon_model.hdf5"))
+    r_vec, hop = _pack_hop(model)
+    with h5py.File(os.path.join(sample_dir, "silicon_eigenvals.hdf5"), "r") as handle:
+        known_k = handle["kpoints_obj/kpoints"][()]
+        known_e = handle["eigenvals"][()]
+    live_e = _eig(model, known_k)
+    print("silicon: reference vs its stored known answer: max|dE| = %.3e" % np.abs(live_e - known_e).max())
+    assert np.abs(live_e - known_e).max() < 1e-10
+
+    # model rebuilt from the Wannier90 text files (the producer of the HDF5 sample)
+    samples = os.path.join(REF, "tests", "samples")
+    wmodel = tbmodels.Model.from_wannier_files(
+        hr_file=os.path.join(samples, "silicon_hr.dat"),
+        wsvec_file=os.path.join(samples, "silicon_wsvec.dat"),
+    )
+    stored_h = _regression("test_wannier", "test_wannier_hr_wsvec[silicon_hr.dat-silicon_wsvec.dat]")
+    live_h = np.array([wmodel.hamilton(k) for k in KPT])
+    print("silicon: reference H(k) vs stored test_wannier golden: max|dH| = %.3e" % np.abs(live_h - stored_h).max())
+    assert np.abs(live_h - stored_h).max() < 1e-12
+    w_r, w_hop = _pack_hop(wmodel)
+
+    grid = syn.uniform_grid(10)
+    out = dict(
+        R=r_vec,
+        hop=hop,
+        pos=np.array(model.pos),
+        uc=np.array(model.uc),
+        size=np.int64(model.size),
+        known_kpoints=known_k,
+        known_eigenvals=known_e,
+        kpt=np.array(KPT),
+        kpt_h2=np.array(model.hamilton(KPT, convention=2)),
+        kpt_h1=np.array(model.hamilton(KPT, convention=1)),
+        kpt_eig=_eig(model, KPT),
+        grid=grid,
+        grid_eig=_eig(model, grid),
+        grid_h2_first16=np.array(model.hamilton(grid[:16], convention=2)),
+        grid_h1_first16=np.array(model.hamilton(grid[:16], convention=1)),
+        wannier_R=w_r,
+        wannier_hop=w_hop,
+        wannier_pos=np.array(wmodel.pos),
+        wannier_kpt_h2_stored=stored_h,
+    )
+    np.savez_compressed(os.path.join(OUT, "silicon.npz"), **out)
+
+
+def _toy_model(tbmodels, t1, t2, sparse, dim=3):
+    """The model of /root/reference/tests/conftest.py:155-189, built through the reference API."""
+    import itertools  # pylint: disable=import-outside-toplevel
+
+    pos = [[0] * 2, [0.5] * 2]
+    for position in pos:
+        position.extend([0] * (dim - 2))
+    model = tbmodels.Model(pos=pos, occ=1, on_site=(1, -1), size=2, dim=None, sparse=sparse)
+    for phase, r_part in zip([1, -1j, 1j, -1], itertools.product([0, -1], [0, -1])):
+        r_vec = list(r_part)
+        r_vec.extend([0] * (dim - 2))
+        model.add_hop(t1 * phase, 0, 1, r_vec)
+    for r_part in itertools.permutations([0, 1]):
+        r_vec = list(r_part)
+        r_vec.extend([0] * (dim - 2))
+        model.add_hop(t2, 0, 0, r_vec)
+        model.add_hop(-t2, 1, 1, r_vec)
+    return model
+
+
+def gen_toy(tbmodels):
+    out = dict(kpt=np.array(KPT), t_values=np.array(T_VALUES))
+    worst = 0.0
+    for t_idx, (t1, t2) in enumerate(T_VALUES):
+        for sparse in (False, True):
+            model = _toy_model(tbmodels, t1, t2, sparse)
+            tag = "t%d_%s" % (t_idx, "sparse" if sparse else "dense")
+            r_vec, hop = _pack_hop(model)
+            out[tag + "_R"] = r_vec
+            out[tag + "_hop"] = hop
+            out[tag + "_pos"] = np.array(model.pos)
+            for conv in (1, 2):
+                live = np.array([model.hamilton(k, convention=conv) for k in KPT])
+                stored = np.array(
+                    [
+                        _regression(
+                            "test_hamilton",
+                            "test_simple_hamilton[%s-%d-t_values%d-kpt%d]" % (sparse, conv, t_idx, k_idx),
+                        )
+                        for k_idx in range(len(KPT))
+                    ]
+                )
+                worst = max(worst, np.abs(live - stored).max())
+                out[tag + "_h%d" % conv] = live
+                out[tag + "_h%d_stored" % conv] = stored
+                out[tag + "_h%d_batch" % conv] = np.array(model.hamilton(KPT, convention=conv))
+            live_e = np.array([model.eigenval(k) for k in KPT])
+            stored_e = np.array(
+                [
+                    _regression("test_eigenval", "test_simple_eigenval[%s-t_values%d-kpt%d]" % (sparse, t_idx, k_idx))
+                    for k_idx in range(len(KPT))
+                ]
+            )
+            worst = max(worst, np.abs(live_e - stored_e).max())
+            out[tag + "_eig"] = live_e
+            out[tag + "_eig_stored"] = stored_e
+    print("toy: reference vs stored test_hamilton/test_eigenval goldens: max diff = %.3e" % worst)
+    assert worst < 1e-12
+    # dim = 2 and dim = 4 variants of the same model (tests/test_supercell.py uses dims 2/3/4)
+    for dim in (2, 4):
+        model = _toy_model(tbmodels, 0.2, -0.2, False, dim=dim)
+        k = np.random.default_rng(7).random((5, dim)) * 2 - 1
+        r_vec, hop = _pack_hop(model)
+        out["dim%d_R" % dim] = r_vec
+        out["dim%d_hop" % dim] = hop
+        out["dim%d_pos" % dim] = np.array(model.pos)
+        out["dim%d_k" % dim] = k
+        out["dim%d_h1" % dim] = np.array(model.hamilton(k, convention=1))
+        out["dim%d_h2" % dim] = np.array(model.hamilton(k, convention=2))
+        out["dim%d_eig" % dim] = _eig(model, k)
+    np.savez_compressed(os.path.join(OUT, "toy.npz"), **out)
+
+
+def _model_from_packed(tbmodels, r_vec, hop, pos, sparse=False, dim=None):
+    hop_dict = {tuple(int(x) for x in r): np.array(h) for r, h in zip(r_vec, hop)}
+    return tbmodels.Model(
+        hop=hop_dict, pos=pos, size=hop.shape[1] if len(hop) else len(pos), dim=dim, contains_cc=False, sparse=sparse
+    )
+
+
+def gen_synthetic(tbmodels, syn):
+    out = {}
+
+    def case(tag, r_vec, hop, pos, k, sparse=False, store_hop=True, n_h=None):
+        """
+        Push one packed model through the reference.  ``store_hop=False`` keeps the fixture small
+        for the larger cases: the test regenerates ``hop`` with the same generator call and checks
+        it against the stored checksums before using it.  ``n_h`` limits how many H(k) are kept
+        (eigenvalues are always kept for every k).
+        """
+        model = _model_from_packed(tbmodels, r_vec, hop, pos, sparse=sparse, dim=r_vec.shape[1])
+        # what the reference actually stores (insertion order kept, zero blocks dropped)
+        s_r, s_hop = _pack_hop(model)
+        out[tag + "_R"] = s_r
+        if store_hop:
+            out[tag + "_hop"] = s_hop
+        else:
+            out[tag + "_hop_sum"] = np.array([s_hop.sum(), np.abs(s_hop).sum(), (s_hop * np.arange(s_hop.size).reshape(s_hop.shape)).sum()])
+        out[tag + "_pos"] = np.array(model.pos)
+        out[tag + "_k"] = np.array(k)
+        n_h = len(k) if n_h is None else n_h
+        out[tag + "_h2"] = np.array(model.hamilton(k[:n_h], convention=2))
+        out[tag + "_h1"] = np.array(model.hamilton(k[:n_h], convention=1))
+        out[tag + "_eig"] = _eig(model, k)
+        return model
+
+    # dense N=16 / N_R=33 / NK=64
+    r_vec, hop, pos = syn.dense_model_arrays(16, 33, syn.MODEL_SEED + 100)
+    case("dense16", r_vec, hop, pos, syn.random_kpoints(64) * 3 - 1.5)
+    # dense N=64 / N_R=128 / NK=32 (the headline orbital count)
+    r_vec, hop, pos = syn.dense_model_arrays(64, 128, syn.MODEL_SEED + 101)
+    case("dense64", r_vec, hop, pos, syn.random_kpoints(32), store_hop=False, n_h=3)
+    # odd sizes: N not a multiple of any tile, N_R not a multiple of 4, NK prime
+    r_vec, hop, pos = syn.dense_model_arrays(13, 27, syn.MODEL_SEED + 102)
+    case("dense13", r_vec, hop, pos, syn.random_kpoints(37) * 2 - 1)
+    # N = 1 (scalar bands)
+    r_vec, hop, pos = syn.dense_model_arrays(1, 5, syn.MODEL_SEED + 103)
+    case("dense1", r_vec, hop, pos, syn.random_kpoints(9))
+    # CSR N=64 / N_R=40 / 2 % fill / NK=32, stored sparse in the reference
+    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(64, 40, syn.MODEL_SEED + 104)
+    hop = syn.csr_to_dense(64, r_ptr, row, col, val)
+    out["csr64_in_R"] = r_vec
+    out["csr64_in_r_ptr"] = r_ptr
+    out["csr64_in_row"] = row
+    out["csr64_in_col"] = col
+    out["csr64_in_val"] = val
+    model_sparse = case("csr64", r_vec, hop, pos, syn.random_kpoints(32), sparse=True, store_hop=False, n_h=3)
+    model_dense = _model_from_packed(tbmodels, r_vec, hop, pos, sparse=False, dim=3)
+    k = out["csr64_k"]
+    assert np.abs(np.array(model_sparse.hamilton(k)) - np.array(model_dense.hamilton(k))).max() < 1e-14
+    # dim = 1 and dim = 2
+    r_vec, hop, pos = syn.dense_model_arrays(6, 9, syn.MODEL_SEED + 105, dim=1)
+    model = case("dim1", r_vec, hop, pos, syn.random_kpoints(11, dim=1) * 4 - 2)
+    # scalar k for a 1-D model (tests/test_convention.py:32 passes a bare float)
+    out["dim1_scalar_k"] = np.float64(0.37)
+    out["dim1_scalar_h2"] = np.array(model.hamilton(0.37, convention=2))
+    out["dim1_scalar_h1"] = np.array(model.hamilton(0.37, convention=1))
+    out["dim1_scalar_eig"] = np.array(model.eigenval(0.37))
+    r_vec, hop, pos = syn.dense_model_arrays(5, 20, syn.MODEL_SEED + 106, dim=2)
+    case("dim2", r_vec, hop, pos, syn.random_kpoints(10, dim=2))
+    # single k-point call (1-D k array) on a 3-D model: returns (N, N) / (N,)
+    r_vec, hop, pos = syn.dense_model_arrays(8, 12, syn.MODEL_SEED + 107)
+    model = case("single", r_vec, hop, pos, syn.random_kpoints(3))
+    out["single_k0_h2"] = np.array(model.hamilton(out["single_k"][0]))
+    out["single_k0_eig"] = np.array(model.eigenval(out["single_k"][0]))
+    # empty hop: H == 0
+    model = tbmodels.Model(size=3, dim=3)
+    out["empty_h2"] = np.array(model.hamilton([[0.1, 0.2, 0.3], [0.5, 0.5, 0.5]]))
+    out["empty_eig"] = _eig(model, [[0.1, 0.2, 0.3], [0.5, 0.5, 0.5]])
+    # large |k| and large |R|: phase accuracy (k is NOT reduced mod 1 by the reference)
+    r_vec, hop, pos = syn.dense_model_arrays(4, 200, syn.MODEL_SEED + 108)
+    case("bigk", r_vec[-40:], hop[-40:], pos, (syn.random_kpoints(16) - 0.5) * 40.0)
+    np.savez_compressed(os.path.join(OUT, "synthetic.npz"), **out)
+
+
+def gen_kdotp(tbmodels, syn):
+    """KdotpModel.hamilton/eigenval and Model.construct_kdotp."""
+    out = {}
+    r_vec, hop, pos = syn.dense_model_arrays(6, 15, syn.MODEL_SEED + 200)
+    model = _model_from_packed(tbmodels, r_vec, hop, pos, dim=3)
+    k0 = np.array([0.12, -0.31, 0.44])
+    out["R"] = r_vec
+    out["hop"] = hop
+    out["pos"] = pos
+    out["k0"] = k0
+    for order in (0, 1, 2, 3):
+        kp = model.construct_kdotp(k0, order=order)
+        powers = sorted(kp.taylor_coefficients.keys())
+        out["order%d_powers" % order] = np.array(powers, dtype=np.int64).reshape(len(powers), 3)
+        out["order%d_coeffs" % order] = np.array([kp.taylor_coefficients[p] for p in powers])
+        dk = (syn.random_kpoints(7) - 0.5) * 0.2
+        out["order%d_dk" % order] = dk
+        out["order%d_h" % order] = np.array(kp.hamilton(dk))
+        out["order%d_eig" % order] = np.array(kp.eigenval(dk))
+        out["order%d_h_single" % order] = np.array(kp.hamilton(dk[0]))
+        out["order%d_eig_single" % order] = np.array(kp.eigenval(dk[0]))
+    np.savez_compressed(os.path.join(OUT, "kdotp.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tbmodels = _import_reference()
+    syn = _load_synthetic()
+    print("reference tbmodels", tbmodels.__version__, "numpy", np.__version__)
+    gen_silicon(tbmodels, syn)
+    gen_toy(tbmodels)
+    gen_synthetic(tbmodels, syn)
+    gen_kdotp(tbmodels, syn)
+    for name in sorted(os.listdir(OUT)):
+        print("%-16s %8d bytes" % (name, os.path.getsize(os.path.join(OUT, name))))
+
+
+if __name__ == "__main__":
+    main()
