@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""
+bench.py -- k-points/s of the TBmodels hot path (H(k) + eigenvalues) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2]
+
+Metric (BASELINE.json): k-points/sec (H(k)+eig) at N_orb=64, N_R=4096.  A "step" is one pass of
+``Model.eigenval`` over one batch of k-points per GPU: at N=1 the batch is BASELINE config 2 (dense
+N_orb=64, N_R=4096, 100k random k-points, SURVEY.md section 8d generator).  With N>1 every rank
+holds the same staged model and evaluates its own contiguous slab of an N x 100k k list (weak
+scaling, per-GPU work fixed), followed by the RCCL all-gather of eigenvalue slabs inside the timed
+region.  k-points and eigenvalues are resident in HBM when the clock starts.
+
+Host side: Python + ctypes -> libtbk.so (include/tbk.h).  torch is imported only for N>1, and only
+as the rendezvous the driver's launcher expects (torch.distributed, gloo): barrier, max-over-ranks
+and handing the RCCL unique id to the ranks.  The data path never touches torch.
+
+Rank 0 prints ONE JSON line with the contract fields plus ``roofline`` (the H(k) MFMA kernel, timed
+with HIP events on the library's stream) and ``cpu_baseline`` (the oracle = port of the reference's
+NumPy/SciPy algorithm, timed on this box's host cores on a bounded sample).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# load libtbk (system ROCm runtime) before anything else can pull in another copy of the runtime
+from tbmodels_amd import _lib, synthetic  # noqa: E402  pylint: disable=wrong-import-position
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD public spec for MI355X (vector = matrix FP64); see DESIGN.md
+
+CONFIGS = {
+    # name: (kind, n_orb, n_r, n_k per GPU, config index for the seed)
+    "cfg1": ("silicon", 8, 95, 1000, 1),
+    "cfg2": ("dense", 64, 4096, 100_000, 2),
+    "cfg3": ("csr", 256, 512, 50_000, 3),
+    "cfg5": ("dense", 512, 2048, 10_000, 5),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--nk", type=int, default=0, help="override k-points per GPU")
+    ap.add_argument("--nr", type=int, default=0, help="override N_R (exploration only)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="k-points for the CPU baseline (0 = skip)")
+    ap.add_argument("--eigensolver", default="auto", choices=["auto", "jacobi", "rocsolver"])
+    ap.add_argument("--k-chunk", type=int, default=0)
+    ap.add_argument("--construct-only", action="store_true", help="time H(k) construction alone (not the metric)")
+    return ap.parse_args()
+
+
+def build_model_arrays(cfg_name, n_r_override=0):
+    kind, n_orb, n_r, _, idx = CONFIGS[cfg_name]
+    if n_r_override:
+        n_r = n_r_override
+    seed = synthetic.MODEL_SEED + idx
+    if kind == "silicon":
+        data = np.load(os.path.join(ROOT, "tests", "golden", "silicon.npz"))
+        return dict(kind="dense", n_orb=8, R=data["R"].astype(np.int32), hop=data["hop"], pos=data["pos"])
+    if kind == "dense":
+        r_vec, hop, pos = synthetic.dense_model_arrays(n_orb, n_r, seed)
+        return dict(kind="dense", n_orb=n_orb, R=r_vec, hop=hop, pos=pos)
+    r_vec, r_ptr, row, col, val, pos = synthetic.csr_model_arrays(n_orb, n_r, seed)
+    return dict(kind="csr", n_orb=n_orb, R=r_vec, r_ptr=r_ptr, row=row, col=col, val=val, pos=pos)
+
+
+def stage(lib, device, arrays):
+    handle = ctypes.c_void_p()
+    r_vec = np.ascontiguousarray(arrays["R"], dtype=np.int32)
+    if arrays["kind"] == "dense":
+        hop = np.ascontiguousarray(arrays["hop"], dtype=np.complex128)
+        _lib.check(lib.tbk_model_create_dense(device, r_vec.shape[1], arrays["n_orb"], len(r_vec), _lib.ptr(r_vec),
+                                              _lib.ptr(hop), ctypes.byref(handle)))
+    else:
+        _lib.check(lib.tbk_model_create_csr(device, r_vec.shape[1], arrays["n_orb"], len(r_vec), _lib.ptr(r_vec),
+                                            _lib.ptr(arrays["r_ptr"]), _lib.ptr(arrays["row"]), _lib.ptr(arrays["col"]),
+                                            _lib.ptr(np.ascontiguousarray(arrays["val"])), ctypes.byref(handle)))
+    return handle
+
+
+def cpu_baseline(arrays, kpts, sample):
+    """The oracle (NumPy/SciPy port of the reference loop), single process, on `sample` k-points."""
+    from oracle import tbk_oracle as oracle  # checker / baseline only
+
+    if arrays["kind"] == "dense":
+        hop = arrays["hop"]
+    else:
+        hop = synthetic.csr_to_dense(arrays["n_orb"], arrays["r_ptr"], arrays["row"], arrays["col"], arrays["val"])
+    k = kpts[:sample]
+    t0 = time.perf_counter()
+    eig = oracle.eigenval(arrays["R"], hop, k)
+    dt = time.perf_counter() - t0
+    return len(k) / dt, dt, np.array(eig)
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    lib = _lib.lib()
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libtbk has no CPU path")
+    device = local_rank % _lib.device_count()
+
+    dist = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    kind, n_orb, n_r, nk_gpu, cfg_idx = CONFIGS[args.config]
+    if args.nk:
+        nk_gpu = args.nk
+    if args.nr:
+        n_r = args.nr
+    arrays = build_model_arrays(args.config, args.nr)
+    n_r = len(arrays["R"])
+    dim = arrays["R"].shape[1]
+
+    # the global k list (N x nk_gpu rows); every rank materialises only its slab
+    if args.config == "cfg1":
+        k_all = synthetic.uniform_grid(10)
+        k_slab = k_all[:nk_gpu]
+    else:
+        rng = np.random.default_rng(synthetic.K_SEED)
+        k_slab = None
+        for r in range(rank + 1):  # same stream as random_kpoints(world * nk_gpu), slab by slab
+            k_slab = rng.random((nk_gpu, dim))
+    k_slab = np.ascontiguousarray(k_slab)
+
+    model = stage(lib, device, arrays)
+    solver = {"auto": _lib.TBK_EIG_AUTO, "jacobi": _lib.TBK_EIG_JACOBI, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[args.eigensolver]
+    _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, solver))
+    if args.k_chunk:
+        _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_K_CHUNK, args.k_chunk))
+
+    def dmalloc(nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(lib.tbk_device_malloc(device, nbytes, ctypes.byref(p)))
+        return p
+
+    d_k = dmalloc(k_slab.nbytes)
+    _lib.check(lib.tbk_memcpy_h2d(device, d_k, _lib.ptr(k_slab), k_slab.nbytes))
+    e_count = nk_gpu * n_orb
+    d_e = dmalloc(e_count * 8)
+    d_h = None
+    if args.construct_only:
+        d_h = dmalloc(nk_gpu * n_orb * n_orb * 16)
+    d_gather = None
+    comm = None
+    if world > 1:
+        d_gather = dmalloc(world * e_count * 8)
+        uid = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            _lib.check(lib.tbk_comm_unique_id(_lib.ptr(uid)))
+        import torch  # pylint: disable=import-outside-toplevel
+
+        t_uid = torch.from_numpy(uid)
+        dist.broadcast(t_uid, src=0)
+        comm = ctypes.c_void_p()
+        _lib.check(lib.tbk_comm_create(device, world, rank, _lib.ptr(uid), ctypes.byref(comm)))
+
+    def step():
+        if args.construct_only:
+            _lib.check(lib.tbk_hamilton_device(model, d_k, nk_gpu, 2, None, d_h))
+            return
+        _lib.check(lib.tbk_eigenval_device(model, d_k, nk_gpu, d_e))
+        if comm is not None:
+            _lib.check(lib.tbk_comm_allgather_f64(comm, model, d_e, d_gather, e_count))
+
+    def barrier():
+        _lib.check(lib.tbk_synchronize(model))
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.construct_only:
+        _lib.check(lib.tbk_eigenval_check(model))
+    _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 1))
+    ms = (ctypes.c_double * _lib.TBK_T_COUNT)()
+    launches = (ctypes.c_int64 * _lib.TBK_T_COUNT)()
+    _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch  # pylint: disable=import-outside-toplevel
+
+        t_el = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+    if not args.construct_only:
+        _lib.check(lib.tbk_eigenval_check(model))
+    _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
+    stage_ms = {name: ms[i] for i, name in enumerate(_lib.STAGE_NAMES)}
+    stage_n = {name: launches[i] for i, name in enumerate(_lib.STAGE_NAMES)}
+
+    # --- correctness spot check on rank 0: first k-points of the slab against the oracle ------------
+    eig_head = np.empty((min(nk_gpu, 64), n_orb))
+    if not args.construct_only:
+        _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_head), d_e, eig_head.nbytes))
+
+    result = None
+    if rank == 0:
+        total_k = world * nk_gpu * args.steps
+        value = total_k / elapsed
+        # algorithmic work per k-point, SURVEY.md section 8(d): dense 8 N^2 N_R + 2 N^2 flops
+        if arrays["kind"] == "dense":
+            f_k = 8.0 * n_orb * n_orb * n_r + 2.0 * n_orb * n_orb
+            f_exec = 8.0 * (n_orb * (n_orb + 1) / 2) * n_r  # what the symmetrised contraction executes
+        else:
+            nnz = int(arrays["r_ptr"][-1])
+            f_k = 8.0 * nnz + 2.0 * n_orb * n_orb
+            f_exec = f_k
+        hk_launches = max(1, stage_n["hk"])
+        hk_ms_avg = stage_ms["hk"] / hk_launches
+        k_per_launch = nk_gpu * args.steps / hk_launches
+        if arrays["kind"] == "dense":
+            achieved = f_k * k_per_launch / (hk_ms_avg * 1e-3) / 1e12 if hk_ms_avg > 0 else 0.0
+            roofline = {
+                "kernel": "hk_dense_kernel", "bound": "mfma", "achieved": round(achieved, 3),
+                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "executed_tflops": round(f_exec * k_per_launch / (hk_ms_avg * 1e-3) / 1e12, 3) if hk_ms_avg > 0 else 0.0,
+                "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
+                "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
+            }
+        else:
+            out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not args.construct_only else n_orb * n_orb)
+            b_k = out_bytes + 8 * dim
+            achieved = b_k * k_per_launch / (hk_ms_avg * 1e-3) / 1e9 if hk_ms_avg > 0 else 0.0
+            roofline = {
+                "kernel": "hk_csr_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
+            }
+
+        sample = args.cpu_sample
+        if sample < 0:
+            sample = {"cfg1": 1000, "cfg2": 256, "cfg3": 48, "cfg5": 4}[args.config]
+        cpu = None
+        parity = None
+        if sample > 0 and not args.construct_only:
+            cpu_rate, cpu_dt, cpu_eig = cpu_baseline(arrays, k_slab, sample)
+            n_cmp = min(len(cpu_eig), len(eig_head))
+            parity = float(np.abs(cpu_eig[:n_cmp] - eig_head[:n_cmp]).max())
+            cpu = {
+                "value": round(cpu_rate, 2), "unit": "k-points/s", "cores": 1, "kind": "port",
+                "sample": "%d of the %d k-points of this workload, oracle/tbk_oracle.py (NumPy loop over R + "
+                          "scipy eigvalsh), one process, %.1f s" % (sample, nk_gpu, cpu_dt),
+                "host_cpus": os.cpu_count(),
+            }
+        result = {
+            "metric": "k-points/sec (H(k)+eig) at N_orb=%d, N_R=%d" % (n_orb, n_r) if not args.construct_only
+                      else "k-points/sec (H(k) construction only) at N_orb=%d, N_R=%d" % (n_orb, n_r),
+            "value": round(value, 1),
+            "unit": "k-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s N_orb=%d N_R=%d, %d %s k-points per GPU, eigenval (H(k)+eig)"
+                            % (args.config, arrays["kind"], n_orb, n_r, nk_gpu,
+                               "grid" if args.config == "cfg1" else "random"),
+                "kpoints_per_gpu": nk_gpu,
+                "sharding": "contiguous k slabs, hoppings replicated, RCCL all-gather of eigenvalues" if world > 1
+                            else "single GPU",
+                "eigensolver": args.eigensolver,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            "max_abs_err_vs_oracle": parity,
+        }
+        print(json.dumps(result), flush=True)
+
+    if comm is not None:
+        lib.tbk_comm_destroy(comm)
+    lib.tbk_model_destroy(model)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and result and result.get("max_abs_err_vs_oracle") is not None:
+        if result["max_abs_err_vs_oracle"] > 1e-10:
+            raise SystemExit("parity failure: max|dE| = %g" % result["max_abs_err_vs_oracle"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * tbk.h -- C ABI of libtbk.so: the MI355X (gfx950) k-space evaluation path of a tight-binding model.
+ *
+ *     H(k) = sum_R exp(2 pi i k.R) hop[R]  +  h.c.        and        eigenvalues of H(k)
+ *
+ * The reference (Z2PackDev/TBmodels 1.4.4) is pure Python and has NO FFI / plugin interface for
+ * this path: the path is two bound methods of tbmodels.Model.  This header is therefore the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to replace the bodies of
+ *
+ *     Model.hamilton(k, convention=2)   /root/reference/src/tbmodels/_tb_model.py:1076-1132
+ *     Model.eigenval(k)                 /root/reference/src/tbmodels/_tb_model.py:1134-1150
+ *     KdotpModel.hamilton / eigenval    /root/reference/src/tbmodels/kdotp.py:51-100
+ *
+ * Conventions
+ *   - plain pointers and sizes only; complex128 is passed as interleaved (re, im) doubles;
+ *   - every array is C-contiguous, row-major, in the reference's own layouts:
+ *       R    int32   [n_r][dim]          lattice vectors = keys of model.hop (_tb_model.py:206-210)
+ *       hop  double  [n_r][n_orb][n_orb][2]   = values of model.hop: half-space blocks, the R = 0
+ *                                             block stored HALVED (_tb_model.py:268, :218)
+ *       k    double  [nk][dim]           reduced coordinates, NOT reduced mod 1 (_tb_model.py:1103-1108)
+ *       pos  double  [n_orb][dim]        orbital positions, only read for convention 1 (:1124-1128)
+ *       H    double  [nk][n_orb][n_orb][2]    H[k][i][j] (_tb_model.py:1109)
+ *       E    double  [nk][n_orb]         ascending eigenvalues per k (scipy.linalg.eigvalsh, :1149)
+ *   - every function returns 0 on success, a tbk_status otherwise; tbk_last_error() gives the
+ *     message of the calling thread's last failure;
+ *   - "host" entry points take caller-owned host memory and return when the result is in it;
+ *     "device" entry points take device pointers on the model's device, enqueue on the model's
+ *     stream and return without synchronising (tbk_synchronize waits);
+ *   - a handle is immutable after creation (re-create it when model.hop changes); calls on one
+ *     handle must not overlap in time; different handles are independent.
+ *
+ * There is no CPU implementation behind this interface: without a gfx950 device every compute
+ * entry point fails with TBK_ERR_DEVICE.
+ */
+#ifndef TBK_H
+#define TBK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tbk_model tbk_model; /* staged hoppings + workspaces on one device */
+typedef struct tbk_kdotp tbk_kdotp; /* staged Taylor coefficients of a k.p model   */
+typedef struct tbk_comm tbk_comm;   /* RCCL communicator of one rank               */
+
+typedef enum tbk_status {
+    TBK_OK = 0,
+    TBK_ERR_ARGUMENT = 1, /* bad size / null pointer / convention not in {1, 2}  -> ValueError   */
+    TBK_ERR_DEVICE = 2,   /* no device, HIP / rocBLAS / RCCL failure              -> RuntimeError */
+    TBK_ERR_MEMORY = 3,   /* device allocation failed                             -> MemoryError  */
+    TBK_ERR_NOT_FINITE = 4, /* NaN / Inf in H(k): scipy check_finite=True         -> ValueError   */
+    TBK_ERR_NO_CONVERGENCE = 5 /* eigensolver did not converge                    -> LinAlgError  */
+} tbk_status;
+
+/* eigensolver selection for tbk_model_set_option(TBK_OPT_EIGENSOLVER, ...) */
+enum { TBK_EIG_AUTO = 0, TBK_EIG_JACOBI = 1, TBK_EIG_ROCSOLVER = 2 };
+enum {
+    TBK_OPT_EIGENSOLVER = 1, /* one of TBK_EIG_*                                           */
+    TBK_OPT_K_CHUNK = 2,     /* max k-points per internal chunk (0 = choose from free HBM) */
+    TBK_OPT_TIMING = 3       /* 1: bracket every kernel with HIP events (tbk_get_timing)   */
+};
+
+/* ---- library / device ------------------------------------------------------------------ */
+const char* tbk_version(void);
+const char* tbk_last_error(void);
+int tbk_device_count(int* count);
+
+/* ---- model staging (replaces the per-call walk over model.hop, _tb_model.py:1111) ------- */
+
+/* Dense hoppings.  `hop` = the n_r stored (n_orb x n_orb) complex blocks, in the order of `R`. */
+int tbk_model_create_dense(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
+                           const double* hop, tbk_model** out);
+
+/* Sparse hoppings (model._sparse, _sparse_matrix.py:35-37): the per-R scipy CSR matrices
+ * concatenated as COO triplets; entries of lattice vector r are [r_ptr[r], r_ptr[r+1]).
+ * Duplicate (row, col) entries inside one R are summed, like scipy's toarray(). */
+int tbk_model_create_csr(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
+                         const int64_t* r_ptr, const int32_t* row, const int32_t* col,
+                         const double* val, tbk_model** out);
+
+void tbk_model_destroy(tbk_model* m);
+int tbk_model_set_option(tbk_model* m, int option, int64_t value);
+int tbk_model_info(const tbk_model* m, int* device, int* dim, int* n_orb, int64_t* n_r,
+                   int* is_sparse, int64_t* staged_bytes);
+
+/* ---- the hot path, host buffers (what Model.hamilton / Model.eigenval call) -------------- */
+
+/* H(k) for nk k-points.  convention in {1, 2}; pos may be NULL for convention 2. */
+int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int convention, const double* pos,
+                 double* H_out);
+
+/* Ascending eigenvalues of H(k) (convention 2) for nk k-points. */
+int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E_out);
+
+/* ---- the hot path, device buffers (bench, sharded runs, device-side consumers) ----------- */
+int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, int convention,
+                        const double* d_pos, double* d_H);
+int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E);
+/* Check the info flags of the eigenvalue calls since the last check (synchronises). */
+int tbk_eigenval_check(tbk_model* m);
+int tbk_synchronize(tbk_model* m);
+
+/* ---- k.p models (kdotp.py:51-100): H(k) = sum_p prod_d k_d^powers[p][d] * coeffs[p] ------- */
+int tbk_kdotp_create(int device, int dim, int n_orb, int64_t n_p, const int32_t* powers,
+                     const double* coeffs, tbk_kdotp** out);
+void tbk_kdotp_destroy(tbk_kdotp* m);
+int tbk_kdotp_hamilton(tbk_kdotp* m, const double* k, int64_t nk, double* H_out);
+int tbk_kdotp_eigenval(tbk_kdotp* m, const double* k, int64_t nk, double* E_out);
+
+/* ---- device memory helpers (so a Python host needs no other GPU runtime) ----------------- */
+int tbk_device_malloc(int device, int64_t bytes, void** d_ptr);
+int tbk_device_free(int device, void* d_ptr);
+int tbk_memcpy_h2d(int device, void* d_dst, const void* h_src, int64_t bytes);
+int tbk_memcpy_d2h(int device, void* h_dst, const void* d_src, int64_t bytes);
+int tbk_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
+
+/* ---- timing: HIP events on the model's stream around every kernel of the path ------------ */
+enum { TBK_T_PHASE = 0, TBK_T_HK = 1, TBK_T_EIG = 2, TBK_T_EXPAND = 3, TBK_T_COUNT = 4 };
+/* ms[i] = summed duration of stage i, launches[i] = number of timed launches; reset = 1 clears. */
+int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int reset);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------- */
+/* 128-byte RCCL unique id, created on rank 0 and handed to the other ranks by the launcher. */
+int tbk_comm_unique_id(void* id128);
+int tbk_comm_create(int device, int world_size, int rank, const void* id128, tbk_comm** out);
+void tbk_comm_destroy(tbk_comm* c);
+/* All-gather of per-rank eigenvalue slabs: every rank contributes `count` doubles from d_send and
+ * receives world_size * count doubles in rank order in d_recv.  Enqueued on `m`'s stream. */
+int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
+                           int64_t count);
+
+/* ---- microbenchmark: sustained v_mfma_f64_16x16x4_f64 rate of the device (TFLOP/s) -------- */
+int tbk_mfma_f64_peak(int device, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBK_H */

@@ -1,0 +1,481 @@
+"""
+``Model`` -- the host-side mirror of ``tbmodels.Model`` for the k-space evaluation path.
+
+The reference has no plugin boundary: the hot path is two bound methods,
+``Model.hamilton(k, convention=2)`` (``/root/reference/src/tbmodels/_tb_model.py:1076-1132``) and
+``Model.eigenval(k)`` (``:1134-1150``), reading ``self.hop``, ``self.size``, ``self.dim``,
+``self.pos`` and ``self._sparse``.  This class keeps that surface -- same constructor keywords, same
+``hop`` storage convention (half-space lattice vectors, ``R = 0`` block halved; ``:175-218``,
+``:247-298``), same ``add_hop`` / ``add_on_site`` / ``set_sparse`` mutators, same argument and return
+conventions, same exceptions -- and evaluates both methods on the GPU through ``libtbk.so``
+(``include/tbk.h``).  Nothing here computes H(k) on the CPU; without the library and a device the
+two methods raise.
+
+Device state is a cache of ``self.hop``: it is re-validated against a content fingerprint on every
+call (``add_hop``, ``model.hop[R] += ...`` and ``set_sparse`` all mutate in place), dropped on pickling
+and rebuilt lazily.
+"""
+
+import collections as co
+import ctypes
+import os
+import zlib
+
+import numpy as np
+
+from . import _lib
+from ._sparse_matrix import csr as _csr
+
+try:  # fast content hash for the staging fingerprint; zlib is the fallback
+    import xxhash as _xxhash
+except ImportError:  # pragma: no cover
+    _xxhash = None
+
+__all__ = ("Model",)
+
+
+def _first_nonzero(vec):
+    for x in vec:
+        if x != 0:
+            return x
+    return 0
+
+
+def _hash_bytes(running, array):
+    data = np.ascontiguousarray(array)
+    if _xxhash is not None:
+        running.update(data.view(np.uint8).reshape(-1).data)
+        return running
+    return zlib.adler32(data.view(np.uint8).reshape(-1).data, running)
+
+
+class Model:
+    """
+    Tight-binding model with GPU evaluation of ``hamilton`` / ``eigenval``.
+
+    Keyword arguments are those of ``tbmodels.Model`` (``_tb_model.py:89-102``): ``on_site``,
+    ``hop`` (dict ``R -> (size, size)`` matrix), ``size``, ``dim``, ``occ``, ``pos``, ``uc``,
+    ``contains_cc``, ``cc_check_tolerance``, ``sparse``.
+    """
+
+    def __init__(
+        self,
+        *,
+        on_site=None,
+        hop=None,
+        size=None,
+        dim=None,
+        occ=None,
+        pos=None,
+        uc=None,
+        contains_cc=True,
+        cc_check_tolerance=1e-12,
+        sparse=False,
+    ):
+        hop = {} if hop is None else hop
+        self._handle = None
+        self._staged_fingerprint = None
+        self._pinned = False
+        self.device = int(os.environ.get("TBK_DEVICE", "0"))
+
+        self.set_sparse(sparse)
+
+        # size and dimension are inferred in the reference's order of precedence (:135-172)
+        if size is not None:
+            self.size = size
+        elif on_site is not None:
+            self.size = len(on_site)
+        elif pos is not None:
+            self.size = len(pos)
+        elif hop:
+            self.size = next(iter(hop.values())).shape[0]
+        else:
+            raise ValueError(
+                "Empty hoppings dictionary supplied and no size, on-site energies or positions given. "
+                "Cannot determine the size of the system."
+            )
+        if dim is not None:
+            self.dim = dim
+        elif pos is not None:
+            self.dim = len(pos[0])
+        elif hop:
+            self.dim = len(next(iter(hop.keys())))
+        elif uc is not None:
+            self.dim = len(uc[0])
+        else:
+            raise ValueError(
+                "No dimension specified and no positions, hoppings, or unit cell are given. "
+                "The dimensionality of the system cannot be determined."
+            )
+        self._zero_vec = tuple([0] * self.dim)
+        self.uc = None if uc is None else np.array(uc)
+
+        blocks = {tuple(int(x) for x in key): self._as_dense(value) for key, value in hop.items()}
+
+        if pos is None:
+            self.pos = np.zeros((self.size, self.dim))
+        else:
+            if len(pos) != self.size:
+                raise ValueError(
+                    "Invalid argument for 'pos': The number of positions must be the same as the size "
+                    "(number of orbitals) of the system."
+                )
+            if any(len(p) != self.dim for p in pos):
+                raise ValueError(
+                    "Invalid argument for 'pos': The length of each position must be the same as the "
+                    "dimensionality of the system."
+                )
+            pos_arr, blocks = self._fold_into_home_cell(np.array(pos, dtype=float), blocks)
+            self.pos = pos_arr
+
+        if contains_cc:
+            blocks = self._halve_conjugate_pairs(blocks, cc_check_tolerance)
+        else:
+            blocks = self._fold_to_half_space(blocks)
+
+        self.hop = co.defaultdict(self._empty_matrix)
+        for key, mat in blocks.items():
+            if np.any(mat):
+                self.hop[key] = self._matrix_type(mat)
+        if on_site is not None:
+            if len(on_site) != self.size:
+                raise ValueError(
+                    "The number of on-site energies {} does not match the size of the system {}".format(
+                        len(on_site), self.size
+                    )
+                )
+            self.hop[self._zero_vec] += 0.5 * self._matrix_type(np.diag(np.array(on_site, dtype=complex)))
+
+        for mat in self.hop.values():
+            if mat.shape != (self.size, self.size):
+                raise ValueError(
+                    "Hopping matrix of shape {0} found, should be ({1},{1}).".format(mat.shape, self.size)
+                )
+        for key in self.hop.keys():
+            if len(key) != self.dim:
+                raise ValueError(
+                    "The length of R = {} does not match the dimensionality of the system ({})".format(key, self.dim)
+                )
+        if self.uc is not None and self.uc.shape != (self.dim, self.dim):
+            raise ValueError(
+                "Inconsistend dimension of the unit cell: {}, does not match the dimensionality of the "
+                "system ({})".format(self.uc.shape, self.dim)
+            )
+        self.occ = None if occ is None else int(occ)
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def _as_dense(value):
+        if hasattr(value, "toarray"):
+            return np.asarray(value.toarray(), dtype=complex)
+        return np.array(value, dtype=complex)
+
+    def _fold_into_home_cell(self, pos, blocks):
+        """
+        Orbitals outside ``[0, 1)^dim`` are moved into the home cell and every hopping that touches
+        them is re-labelled ``R -> R + shift[col] - shift[row]`` (``_tb_model.py:221-245``).
+        """
+        shift = np.floor(pos).astype(int)
+        if not shift.any():
+            return pos, blocks
+        moved = co.defaultdict(lambda: np.zeros((self.size, self.size), dtype=complex))
+        for key, mat in blocks.items():
+            rows, cols = np.nonzero(mat)
+            for i, j in zip(rows, cols):
+                new_key = tuple(int(x) for x in (np.array(key, dtype=int) + shift[j] - shift[i]))
+                moved[new_key][i, j] += mat[i, j]
+        return pos % 1, dict(moved)
+
+    @staticmethod
+    def _halve_conjugate_pairs(blocks, tolerance):
+        """
+        ``contains_cc=True`` input lists both ``R`` and ``-R``: check ``hop[-R] == hop[R]^H``, keep the
+        average on the half-space and HALF of it at ``R = 0`` (``_tb_model.py:247-279``).
+        """
+        kept = {}
+        bad = []
+        for key, mat in blocks.items():
+            minus = tuple(-x for x in key)
+            partner = blocks[minus].conj().T if minus in blocks else np.zeros_like(mat)
+            delta = np.linalg.norm(mat - partner)
+            if delta > tolerance:
+                bad.append((key, delta))
+            mean = (mat + partner) / 2
+            lead = _first_nonzero(key)
+            if lead > 0:
+                kept[key] = mean
+            elif lead == 0:
+                kept[key] = mean / 2
+        if bad:
+            bad.sort(key=lambda item: -item[1])
+            raise ValueError(
+                "The provided hoppings do not correspond to a hermitian Hamiltonian. "
+                "hoppings[-R] = hoppings[R].H is not fulfilled for the following values:\n"
+                + "\n".join("R={}, delta_norm={}".format(key, delta) for key, delta in bad)
+            )
+        return kept
+
+    def _fold_to_half_space(self, blocks):
+        """``contains_cc=False``: a block at ``-R`` is stored as its conjugate transpose at ``+R`` (:281-298)."""
+        folded = {}
+
+        def accumulate(key, mat):
+            folded[key] = folded[key] + mat if key in folded else mat.copy()
+
+        for key, mat in blocks.items():
+            lead = _first_nonzero(key)
+            if lead > 0:
+                accumulate(key, mat)
+            elif lead < 0:
+                accumulate(tuple(-x for x in key), mat.conj().T)
+            else:
+                accumulate(key, 0.5 * mat + 0.5 * mat.conj().T)
+        return folded
+
+    @classmethod
+    def from_hop_list(cls, *, hop_list=(), size=None, **kwargs):
+        """
+        Build a model from ``(t, orbital_1, orbital_2, R)`` terms (``_tb_model.py:332-397``); repeated
+        ``(orbital_1, orbital_2, R)`` entries add up.
+        """
+        if size is None:
+            if "on_site" not in kwargs:
+                raise ValueError(
+                    "No on-site energies and no size given. The size of the system cannot be determined."
+                )
+            size = len(kwargs["on_site"])
+        blocks = {}
+        for amplitude, i, j, r_vec in hop_list:
+            key = tuple(int(x) for x in r_vec)
+            if key not in blocks:
+                blocks[key] = np.zeros((size, size), dtype=complex)
+            blocks[key][i, j] += amplitude
+        return cls(size=size, hop=blocks, **kwargs)
+
+    @classmethod
+    def from_packed(cls, r_vec, hop, pos=None, **kwargs):
+        """
+        Build a model from packed half-space arrays ``R (n_r, dim)`` / ``hop (n_r, N, N)`` (the layout of
+        the golden fixtures and of ``tbmodels_amd.synthetic``); equivalent to
+        ``Model(hop={R: mat}, contains_cc=False, ...)``.
+        """
+        r_vec = np.asarray(r_vec)
+        hop = np.asarray(hop)
+        kwargs.setdefault("dim", r_vec.shape[1] if r_vec.ndim == 2 else None)
+        if hop.ndim == 3 and hop.shape[0]:
+            kwargs.setdefault("size", hop.shape[1])
+        blocks = {tuple(int(x) for x in r): h for r, h in zip(r_vec, hop)}
+        return cls(hop=blocks, pos=pos, contains_cc=False, **kwargs)
+
+    # ------------------------------------------------------------------ mutators (reference API)
+    def add_hop(self, overlap, orbital_1, orbital_2, R):
+        """
+        Add ``<orbital_1, 0| H |orbital_2, R> = overlap``; the conjugate term is implied
+        (``_tb_model.py:1153-1215``): a negative-half-space ``R`` is stored conjugated at ``-R`` and an
+        ``R = 0`` term is split symmetrically.
+        """
+        R = tuple(R)
+        if len(R) != self.dim:
+            raise ValueError(
+                "Dimension of R ({}) does not match the model dimension ({})".format(len(R), self.dim)
+            )
+        overlap = complex(overlap)
+        mat = np.zeros((self.size, self.size), dtype=complex)
+        lead = _first_nonzero(R)
+        if lead == 0:
+            mat[orbital_1, orbital_2] += overlap / 2.0
+            mat[orbital_2, orbital_1] += overlap.conjugate() / 2.0
+        elif lead > 0:
+            mat[orbital_1, orbital_2] += overlap
+        else:
+            R = tuple(-x for x in R)
+            mat[orbital_2, orbital_1] += overlap.conjugate()
+        self.hop[R] += self._matrix_type(mat)
+
+    def add_on_site(self, on_site):
+        """Add to the on-site energies (``_tb_model.py:1217-1234``)."""
+        if self.size != len(on_site):
+            raise ValueError(
+                "The number of on-site energy terms should be {}, but is {}.".format(self.size, len(on_site))
+            )
+        for orbital, energy in enumerate(on_site):
+            self.add_hop(energy / 2.0, orbital, orbital, self._zero_vec)
+
+    def _empty_matrix(self):
+        return self._matrix_type(np.zeros((self.size, self.size), dtype=complex))
+
+    def set_sparse(self, sparse=True):
+        """Switch the storage of ``hop`` between dense arrays and CSR (``_tb_model.py:1294-1321``)."""
+        if getattr(self, "_sparse", None) == sparse:
+            return
+        self._sparse = sparse
+        self._matrix_type = _csr if sparse else np.array
+        if hasattr(self, "hop"):
+            for key, mat in self.hop.items():
+                self.hop[key] = self._matrix_type(self._as_dense(mat) if sparse else np.array(mat))
+
+    def _array_cast(self, mat):
+        return np.array(mat) if self._sparse else mat
+
+    # ------------------------------------------------------------------ pickling
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_handle"] = None
+        state["_staged_fingerprint"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def __del__(self):
+        self._drop_staging()
+
+    # ------------------------------------------------------------------ staging
+    def _drop_staging(self):
+        handle = getattr(self, "_handle", None)
+        if handle is not None:
+            try:
+                _lib.lib().tbk_model_destroy(handle)
+            except Exception:  # pylint: disable=broad-except  # interpreter shutdown
+                pass
+        self._handle = None
+        self._staged_fingerprint = None
+
+    def pin_staging(self, pinned=True):
+        """
+        Skip the per-call content check of ``self.hop`` (it costs one pass over the hopping bytes).
+        The caller promises not to mutate the model while pinned.
+        """
+        self._pinned = bool(pinned)
+
+    def _fingerprint(self):
+        running = _xxhash.xxh3_64() if _xxhash is not None else 1
+        meta = [self.device, self.size, self.dim, int(self._sparse), len(self.hop)]
+        for key, mat in self.hop.items():
+            meta.extend(key)
+            if self._sparse:
+                running = _hash_bytes(running, mat.indptr)
+                running = _hash_bytes(running, mat.indices)
+                running = _hash_bytes(running, mat.data)
+            else:
+                running = _hash_bytes(running, mat)
+        digest = running.intdigest() if _xxhash is not None else running
+        return (tuple(meta), digest)
+
+    def packed_hop(self):
+        """
+        ``self.hop`` as the arrays the C ABI takes: ``R int32 (n_r, dim)`` plus either
+        ``hop complex128 (n_r, N, N)`` (dense) or ``(r_ptr int64, row int32, col int32, val complex128)``.
+        """
+        keys = list(self.hop.keys())
+        r_vec = np.array(keys, dtype=np.int32).reshape(len(keys), self.dim)
+        if not self._sparse:
+            hop = np.empty((len(keys), self.size, self.size), dtype=np.complex128)
+            for idx, key in enumerate(keys):
+                hop[idx] = self.hop[key]
+            return r_vec, hop
+        r_ptr = [0]
+        rows, cols, vals = [], [], []
+        for key in keys:
+            coo = self.hop[key].tocoo()
+            rows.append(coo.row.astype(np.int32))
+            cols.append(coo.col.astype(np.int32))
+            vals.append(coo.data.astype(np.complex128))
+            r_ptr.append(r_ptr[-1] + coo.nnz)
+        cat = lambda parts, dtype: np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(0, dtype), dtype)
+        return r_vec, (np.array(r_ptr, dtype=np.int64), cat(rows, np.int32), cat(cols, np.int32), cat(vals, np.complex128))
+
+    def _staged(self):
+        """The ``tbk_model*`` for the current contents of ``self.hop`` (re-staged when they changed)."""
+        if self._handle is not None and self._pinned:
+            return self._handle
+        fingerprint = self._fingerprint()
+        if self._handle is not None and fingerprint == self._staged_fingerprint:
+            return self._handle
+        self._drop_staging()
+        lib = _lib.lib()
+        r_vec, payload = self.packed_hop()
+        handle = ctypes.c_void_p()
+        if self._sparse:
+            r_ptr, row, col, val = payload
+            status = lib.tbk_model_create_csr(
+                self.device, self.dim, self.size, len(r_vec), _lib.ptr(r_vec), _lib.ptr(r_ptr), _lib.ptr(row),
+                _lib.ptr(col), _lib.ptr(val), ctypes.byref(handle),
+            )
+        else:
+            status = lib.tbk_model_create_dense(
+                self.device, self.dim, self.size, len(r_vec), _lib.ptr(r_vec), _lib.ptr(payload), ctypes.byref(handle)
+            )
+        _lib.check(status)
+        self._handle = handle
+        self._staged_fingerprint = fingerprint
+        return handle
+
+    def set_option(self, option, value):
+        """Forward a ``TBK_OPT_*`` option to the staged model (see ``include/tbk.h``)."""
+        _lib.check(_lib.lib().tbk_model_set_option(self._staged(), option, int(value)))
+
+    # ------------------------------------------------------------------ the hot path
+    def _k_array(self, k):
+        """``np.array(k, ndmin=1)``; 1-D (or scalar) means one k-point (``_tb_model.py:1103-1108``)."""
+        k_array = np.array(k, ndmin=1)
+        single = k_array.ndim == 1
+        if single:
+            k_array = k_array.reshape((1, -1))
+        k_array = np.ascontiguousarray(k_array, dtype=np.float64)
+        if k_array.ndim != 2 or k_array.shape[1] != self.dim:
+            # the reference fails inside np.dot(k_array, R) with a shape ValueError
+            raise ValueError(
+                "shapes {} and ({},) not aligned: k-point dimension does not match the model".format(
+                    k_array.shape, self.dim
+                )
+            )
+        return k_array, single
+
+    def hamilton(self, k, convention=2):
+        """
+        The Hamilton matrix at one k-point (returns ``(size, size)``) or a list of k-points
+        (``(NK, size, size)``), complex128; ``convention`` 1 or 2 as in PythTB
+        (``_tb_model.py:1076-1132``).
+        """
+        if convention not in [1, 2]:
+            raise ValueError(
+                "Invalid value '{}' for 'convention': must be either '1' or '2'".format(convention)
+            )
+        k_array, single = self._k_array(k)
+        n_k = k_array.shape[0]
+        out = np.empty((n_k, self.size, self.size), dtype=np.complex128)
+        pos = np.ascontiguousarray(self.pos, dtype=np.float64) if convention == 1 else None
+        _lib.check(
+            _lib.lib().tbk_hamilton(self._staged(), _lib.ptr(k_array), n_k, int(convention), _lib.ptr(pos), _lib.ptr(out))
+        )
+        return out[0] if single else out
+
+    def eigenval(self, k):
+        """
+        Ascending eigenvalues at one k-point (1-D array) or a list of k-points (a list of 1-D arrays,
+        like the reference: ``_tb_model.py:1134-1150``).
+        """
+        k_array, single = self._k_array(k)
+        if not np.isfinite(k_array).all():
+            # scipy.linalg.eigvalsh(check_finite=True) on the NaN Hamiltonian
+            raise ValueError("array must not contain infs or NaNs")
+        n_k = k_array.shape[0]
+        out = np.empty((n_k, self.size), dtype=np.float64)
+        _lib.check(_lib.lib().tbk_eigenval(self._staged(), _lib.ptr(k_array), n_k, _lib.ptr(out)))
+        if not np.isfinite(out).all():
+            raise ValueError("array must not contain infs or NaNs")
+        return out[0] if single else list(out)
+
+    # ------------------------------------------------------------------ introspection
+    def timing(self, reset=True):
+        """Per-stage HIP-event times of the staged model: ``{stage: (ms, launches)}`` (needs TBK_OPT_TIMING)."""
+        ms = (ctypes.c_double * _lib.TBK_T_COUNT)()
+        launches = (ctypes.c_int64 * _lib.TBK_T_COUNT)()
+        _lib.check(_lib.lib().tbk_get_timing(self._staged(), ms, launches, int(bool(reset))))
+        return {name: (ms[i], launches[i]) for i, name in enumerate(_lib.STAGE_NAMES)}
+
+    def __repr__(self):
+        return "tbmodels_amd.Model(hop=<{} matrices>, size={}, dim={}, sparse={})".format(
+            len(self.hop), self.size, self.dim, self._sparse
+        )

@@ -1,0 +1,586 @@
+// tbk_api.hip -- the C ABI of include/tbk.h: staging, the chunked k pipeline, host/device entry
+// points.  Kernels live in tbk_phase.hip / tbk_stage.hip / tbk_hk_dense.hip / tbk_hk_csr.hip /
+// tbk_eig.hip; this file only owns memory, streams and ordering.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+
+#include "tbk_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void tbk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* tbk_last_error(void) { return g_err; }
+extern "C" const char* tbk_version(void) { return "tbk 0.1 (gfx950)"; }
+
+extern "C" int tbk_device_count(int* count) {
+    TBK_ARG(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+int DevBuf::reserve(size_t want) {
+    if (want <= bytes) return TBK_OK;
+    release();
+    const size_t rounded = (want + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    TBK_HIP(hipMalloc(&ptr, rounded));
+    bytes = rounded;
+    return TBK_OK;
+}
+
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+StageTimer::StageTimer(tbk_model* m_, int stage) : m(m_), on(m_->timing) {
+    ev.stage = stage;
+    if (on) {
+        if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(ev.start, m->stream);
+    }
+}
+
+StageTimer::~StageTimer() {
+    if (on) {
+        (void)hipEventRecord(ev.stop, m->stream);
+        m->events.push_back(ev);
+    }
+}
+
+static inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+static int require_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        tbk_set_error("no HIP device visible: libtbk has no CPU path");
+        return TBK_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        tbk_set_error("device %d out of range (have %d)", device, n);
+        return TBK_ERR_ARGUMENT;
+    }
+    TBK_HIP(hipSetDevice(device));
+    return TBK_OK;
+}
+
+// everything both model kinds share: stream, rocBLAS handle, lattice vectors, packed-element map
+static int create_common(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
+                         int64_t k_rows_per_r, tbk_model** out) {
+    TBK_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    TBK_ARG(dim >= 1 && dim <= TBK_MAX_DIM, "dim must be in [1, 8]");
+    TBK_ARG(n_orb >= 1 && n_orb <= 32768, "n_orb must be in [1, 32768]");
+    TBK_ARG(n_r >= 0 && n_r < (int64_t(1) << 28), "n_r out of range");
+    TBK_ARG(n_r == 0 || R != nullptr, "R is NULL");
+    TBK_CHECK(require_device(device));
+
+    tbk_model* m = new (std::nothrow) tbk_model();
+    if (!m) {
+        tbk_set_error("out of host memory");
+        return TBK_ERR_MEMORY;
+    }
+    m->device = device;
+    m->dim = dim;
+    m->n_orb = n_orb;
+    m->n_r = n_r;
+    // K rows are padded to whole LDS stages (TBK_BK); padding rows carry zero hoppings
+    m->k2 = round_up(n_r * k_rows_per_r, TBK_BK);
+    m->n_r_pad = m->k2 / k_rows_per_r;
+    m->ncol = (int)((int64_t)n_orb * (n_orb + 1) / 2);
+    m->ncol_pad = (int)round_up(m->ncol, TBK_BNP);
+
+    int rc = TBK_OK;
+    auto fail = [&](int code) {
+        tbk_model_destroy(m);
+        return code;
+    };
+#define TBK_TRY(expr)                           \
+    do {                                        \
+        rc = [&]() -> int {                     \
+            expr;                               \
+            return TBK_OK;                      \
+        }();                                    \
+        if (rc != TBK_OK) return fail(rc);      \
+    } while (0)
+
+    TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)));
+    TBK_TRY(TBK_ROCBLAS(rocblas_create_handle(&m->blas)));
+    TBK_TRY(TBK_ROCBLAS(rocblas_set_stream(m->blas, m->stream)));
+    TBK_TRY(TBK_CHECK(m->ws_flag.reserve(2 * sizeof(int))));
+    TBK_TRY(TBK_HIP(hipMemsetAsync(m->ws_flag.ptr, 0, 2 * sizeof(int), m->stream)));
+
+    // packed upper-triangle map, row-major over (i <= j): consecutive e -> consecutive j
+    {
+        std::vector<int32_t> colmap((size_t)m->ncol_pad, -1);
+        size_t e = 0;
+        for (int i = 0; i < n_orb; ++i)
+            for (int j = i; j < n_orb; ++j) colmap[e++] = (int32_t)((i << 16) | j);
+        TBK_TRY(TBK_HIP(hipMalloc((void**)&m->d_colmap, colmap.size() * sizeof(int32_t))));
+        TBK_TRY(TBK_HIP(hipMemcpy(m->d_colmap, colmap.data(), colmap.size() * sizeof(int32_t),
+                                  hipMemcpyHostToDevice)));
+        m->staged_bytes += (int64_t)(colmap.size() * sizeof(int32_t));
+    }
+    if (m->n_r_pad > 0 && R != nullptr) {
+        std::vector<int32_t> r_pad((size_t)m->n_r_pad * dim, 0);
+        std::memcpy(r_pad.data(), R, (size_t)n_r * dim * sizeof(int32_t));
+        TBK_TRY(TBK_HIP(hipMalloc((void**)&m->d_R, r_pad.size() * sizeof(int32_t))));
+        TBK_TRY(TBK_HIP(hipMemcpy(m->d_R, r_pad.data(), r_pad.size() * sizeof(int32_t),
+                                  hipMemcpyHostToDevice)));
+        m->staged_bytes += (int64_t)(r_pad.size() * sizeof(int32_t));
+    }
+#undef TBK_TRY
+    *out = m;
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model creation / destruction
+// ------------------------------------------------------------------------------------------------
+extern "C" int tbk_model_create_dense(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
+                                      const double* hop, tbk_model** out) {
+    TBK_ARG(n_r == 0 || hop != nullptr, "hop is NULL");
+    tbk_model* m = nullptr;
+    TBK_CHECK(create_common(device, dim, n_orb, n_r, R, 2, &m));
+    m->sparse = false;
+    int rc = TBK_OK;
+    double* d_raw = nullptr;
+    const size_t raw_bytes = (size_t)n_r * n_orb * n_orb * 2 * sizeof(double);
+    rc = [&]() -> int {
+        if (raw_bytes) {
+            TBK_HIP(hipMalloc((void**)&d_raw, raw_bytes));
+            TBK_HIP(hipMemcpyAsync(d_raw, hop, raw_bytes, hipMemcpyHostToDevice, m->stream));
+        }
+        TBK_CHECK(tbk_stage_dense(m, d_raw));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+        return TBK_OK;
+    }();
+    if (d_raw) (void)hipFree(d_raw);
+    if (rc != TBK_OK) {
+        tbk_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return TBK_OK;
+}
+
+extern "C" int tbk_model_create_csr(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
+                                    const int64_t* r_ptr, const int32_t* row, const int32_t* col,
+                                    const double* val, tbk_model** out) {
+    TBK_ARG(n_r == 0 || r_ptr != nullptr, "r_ptr is NULL");
+    const int64_t nnz = n_r > 0 ? r_ptr[n_r] : 0;
+    TBK_ARG(nnz >= 0, "negative nnz");
+    TBK_ARG(nnz == 0 || (row && col && val), "row/col/val is NULL");
+    for (int64_t r = 0; r < n_r; ++r) TBK_ARG(r_ptr[r] <= r_ptr[r + 1], "r_ptr not monotone");
+    for (int64_t t = 0; t < nnz; ++t)
+        TBK_ARG(row[t] >= 0 && row[t] < n_orb && col[t] >= 0 && col[t] < n_orb,
+                "row/col index out of range");
+
+    tbk_model* m = nullptr;
+    TBK_CHECK(create_common(device, dim, n_orb, n_r, R, 2, &m));
+    m->sparse = true;
+
+    // transpose "per lattice vector, which elements" into "per packed element, which lattice
+    // vectors" with a counting sort; record order inside an element follows r (deterministic sums)
+    auto packed_index = [n_orb](int i, int j) -> int64_t {  // i <= j
+        return (int64_t)i * n_orb - (int64_t)i * (i - 1) / 2 + (j - i);
+    };
+    std::vector<int64_t> cptr((size_t)m->ncol + 1, 0);
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int i = std::min(row[t], col[t]), j = std::max(row[t], col[t]);
+        cptr[(size_t)packed_index(i, j) + 1]++;
+    }
+    for (int e = 0; e < m->ncol; ++e) cptr[(size_t)e + 1] += cptr[(size_t)e];
+    std::vector<int32_t> rec_r((size_t)nnz);
+    std::vector<double> rec_v((size_t)nnz * 2);
+    {
+        std::vector<int64_t> cursor(cptr.begin(), cptr.end() - 1);
+        for (int64_t r = 0; r < n_r; ++r)
+            for (int64_t t = r_ptr[r]; t < r_ptr[r + 1]; ++t) {
+                const int i = row[t], j = col[t];
+                const int kind = (i == j) ? 2 : (i < j ? 0 : 1);
+                const int64_t e = packed_index(std::min(i, j), std::max(i, j));
+                const int64_t slot = cursor[(size_t)e]++;
+                rec_r[(size_t)slot] = (int32_t)((kind << 28) | (int32_t)r);
+                rec_v[(size_t)slot * 2] = val[2 * t];
+                rec_v[(size_t)slot * 2 + 1] = val[2 * t + 1];
+            }
+    }
+    m->nnz_rec = nnz;
+    int rc = [&]() -> int {
+        TBK_HIP(hipMalloc((void**)&m->d_cptr, cptr.size() * sizeof(int64_t)));
+        TBK_HIP(hipMemcpy(m->d_cptr, cptr.data(), cptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        m->staged_bytes += (int64_t)(cptr.size() * sizeof(int64_t));
+        if (nnz > 0) {
+            TBK_HIP(hipMalloc((void**)&m->d_rec_r, (size_t)nnz * sizeof(int32_t)));
+            TBK_HIP(hipMalloc((void**)&m->d_rec_v, (size_t)nnz * 2 * sizeof(double)));
+            TBK_HIP(hipMemcpy(m->d_rec_r, rec_r.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+            TBK_HIP(hipMemcpy(m->d_rec_v, rec_v.data(), (size_t)nnz * 2 * sizeof(double), hipMemcpyHostToDevice));
+            m->staged_bytes += nnz * (int64_t)(sizeof(int32_t) + 2 * sizeof(double));
+        }
+        return TBK_OK;
+    }();
+    if (rc != TBK_OK) {
+        tbk_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return TBK_OK;
+}
+
+extern "C" void tbk_model_destroy(tbk_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (auto& ev : m->events) {
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
+    }
+    if (m->blas) (void)rocblas_destroy_handle(m->blas);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    void* ptrs[] = {m->d_R, m->d_colmap, m->d_B, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_powers};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E, &m->ws_info, &m->ws_k,
+                      &m->ws_pos,   &m->ws_out, &m->ws_flag};
+    for (DevBuf* b : bufs) b->release();
+    delete m;
+}
+
+extern "C" int tbk_model_set_option(tbk_model* m, int option, int64_t value) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    switch (option) {
+        case TBK_OPT_EIGENSOLVER:
+            TBK_ARG(value >= TBK_EIG_AUTO && value <= TBK_EIG_ROCSOLVER, "unknown eigensolver");
+            m->eigensolver = (int)value;
+            return TBK_OK;
+        case TBK_OPT_K_CHUNK:
+            TBK_ARG(value >= 0, "k chunk must be >= 0");
+            m->k_chunk = value;
+            return TBK_OK;
+        case TBK_OPT_TIMING:
+            m->timing = value != 0;
+            return TBK_OK;
+        default:
+            tbk_set_error("unknown option %d", option);
+            return TBK_ERR_ARGUMENT;
+    }
+}
+
+extern "C" int tbk_model_info(const tbk_model* m, int* device, int* dim, int* n_orb, int64_t* n_r,
+                              int* is_sparse, int64_t* staged_bytes) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    if (device) *device = m->device;
+    if (dim) *dim = m->dim;
+    if (n_orb) *n_orb = m->n_orb;
+    if (n_r) *n_r = m->n_r;
+    if (is_sparse) *is_sparse = m->sparse ? 1 : 0;
+    if (staged_bytes) *staged_bytes = m->staged_bytes;
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the chunked pipeline
+// ------------------------------------------------------------------------------------------------
+static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
+    const int64_t n = m->n_orb;
+    int64_t per_k = m->k2 * 8 + (with_eig ? n * n * 16 + (int64_t)tbk_eig_scratch_per_k(m) : 0);
+    if (per_k < 64) per_k = 64;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
+    int64_t budget = std::min<int64_t>((int64_t)(free_b / 4), int64_t(6) << 30);
+    int64_t chunk = budget / per_k / TBK_BM * TBK_BM;
+    chunk = std::max<int64_t>(TBK_BM, std::min<int64_t>(chunk, 32768));
+    if (m->k_chunk > 0) chunk = round_up(m->k_chunk, TBK_BM);
+    return std::min(chunk, round_up(nk, TBK_BM));
+}
+
+static int fill_rows(tbk_model* m, const double* d_k, int64_t nk, int64_t nk_pad, double* d_A) {
+    if (m->kdotp)
+        return tbk_launch_monomials(m->stream, m->d_powers, m->dim, m->n_r, m->k2, d_k, nk, nk_pad, d_A);
+    return tbk_launch_phase(m, d_k, nk, nk_pad, d_A);
+}
+
+static int build_h(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
+                   int convention, const double* d_k, const double* d_pos, double* d_H) {
+    if (m->sparse)
+        return tbk_launch_hk_csr(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H);
+    return tbk_launch_hk_dense(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H);
+}
+
+extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, int convention,
+                                   const double* d_pos, double* d_H) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_ARG(convention == 1 || convention == 2, "convention must be 1 or 2");
+    TBK_ARG(nk >= 0, "nk < 0");
+    if (nk == 0) return TBK_OK;
+    TBK_ARG(d_k && d_H, "k / H is NULL");
+    TBK_ARG(convention == 2 || d_pos != nullptr, "convention 1 needs pos");
+    TBK_HIP(hipSetDevice(m->device));
+    const int64_t chunk = choose_chunk(m, nk, false);
+    const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
+    for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
+        const int64_t nkc = std::min(chunk, nk - c0);
+        const int64_t nk_pad = round_up(nkc, TBK_BM);
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        double* d_A = m->ws_phase.as<double>();
+        const double* kc = d_k + c0 * m->dim;
+        TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
+        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_FULL, convention, kc, d_pos, d_H + (size_t)c0 * nn2));
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_ARG(nk >= 0, "nk < 0");
+    if (nk == 0) return TBK_OK;
+    TBK_ARG(d_k && d_E, "k / E is NULL");
+    TBK_HIP(hipSetDevice(m->device));
+    const int64_t chunk = choose_chunk(m, nk, true);
+    const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
+    for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
+        const int64_t nkc = std::min(chunk, nk - c0);
+        const int64_t nk_pad = round_up(nkc, TBK_BM);
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        TBK_CHECK(m->ws_H.reserve((size_t)nkc * nn2 * sizeof(double)));
+        double* d_A = m->ws_phase.as<double>();
+        double* d_H = m->ws_H.as<double>();
+        const double* kc = d_k + c0 * m->dim;
+        TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
+        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H));
+        TBK_CHECK(tbk_eig_batched(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_synchronize(tbk_model* m) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_HIP(hipSetDevice(m->device));
+    TBK_HIP(hipStreamSynchronize(m->stream));
+    return TBK_OK;
+}
+
+extern "C" int tbk_eigenval_check(tbk_model* m) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_HIP(hipSetDevice(m->device));
+    int flag[2] = {0, 0};
+    TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost, m->stream));
+    TBK_HIP(hipMemsetAsync(m->ws_flag.ptr, 0, sizeof(flag), m->stream));
+    TBK_HIP(hipStreamSynchronize(m->stream));
+    if (flag[0] != 0) {
+        tbk_set_error("eigensolver did not converge for %d matrices", flag[0]);
+        return TBK_ERR_NO_CONVERGENCE;
+    }
+    return TBK_OK;
+}
+
+// ---- host-buffer entry points -------------------------------------------------------------------
+extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int convention,
+                            const double* pos, double* H_out) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_ARG(convention == 1 || convention == 2, "convention must be 1 or 2");
+    TBK_ARG(nk >= 0, "nk < 0");
+    if (nk == 0) return TBK_OK;
+    TBK_ARG(k && H_out, "k / H is NULL");
+    TBK_ARG(convention == 2 || pos != nullptr, "convention 1 needs pos");
+    TBK_HIP(hipSetDevice(m->device));
+    const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
+    // bound the device copy of H: at most ~2 GiB per round trip
+    int64_t out_chunk = std::max<int64_t>(1, (int64_t)((size_t(2) << 30) / (nn2 * sizeof(double))));
+    out_chunk = std::min(out_chunk, nk);
+    TBK_CHECK(m->ws_k.reserve((size_t)nk * m->dim * sizeof(double)));
+    TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, k, (size_t)nk * m->dim * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    const double* d_pos = nullptr;
+    if (convention == 1) {
+        TBK_CHECK(m->ws_pos.reserve((size_t)m->n_orb * m->dim * sizeof(double)));
+        TBK_HIP(hipMemcpyAsync(m->ws_pos.ptr, pos, (size_t)m->n_orb * m->dim * sizeof(double),
+                               hipMemcpyHostToDevice, m->stream));
+        d_pos = m->ws_pos.as<double>();
+    }
+    TBK_CHECK(m->ws_out.reserve((size_t)out_chunk * nn2 * sizeof(double)));
+    for (int64_t c0 = 0; c0 < nk; c0 += out_chunk) {
+        const int64_t nkc = std::min(out_chunk, nk - c0);
+        TBK_CHECK(tbk_hamilton_device(m, m->ws_k.as<double>() + c0 * m->dim, nkc, convention, d_pos,
+                                      m->ws_out.as<double>()));
+        TBK_HIP(hipMemcpyAsync(H_out + (size_t)c0 * nn2, m->ws_out.ptr, (size_t)nkc * nn2 * sizeof(double),
+                               hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E_out) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_ARG(nk >= 0, "nk < 0");
+    if (nk == 0) return TBK_OK;
+    TBK_ARG(k && E_out, "k / E is NULL");
+    TBK_HIP(hipSetDevice(m->device));
+    TBK_CHECK(m->ws_k.reserve((size_t)nk * m->dim * sizeof(double)));
+    TBK_CHECK(m->ws_out.reserve((size_t)nk * m->n_orb * sizeof(double)));
+    TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, k, (size_t)nk * m->dim * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    TBK_CHECK(tbk_eigenval_device(m, m->ws_k.as<double>(), nk, m->ws_out.as<double>()));
+    TBK_HIP(hipMemcpyAsync(E_out, m->ws_out.ptr, (size_t)nk * m->n_orb * sizeof(double),
+                           hipMemcpyDeviceToHost, m->stream));
+    return tbk_eigenval_check(m);  // synchronises
+}
+
+// ------------------------------------------------------------------------------------------------
+// k.p models
+// ------------------------------------------------------------------------------------------------
+extern "C" int tbk_kdotp_create(int device, int dim, int n_orb, int64_t n_p, const int32_t* powers,
+                                const double* coeffs, tbk_kdotp** out) {
+    TBK_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    TBK_ARG(n_p == 0 || (powers && coeffs), "powers / coeffs is NULL");
+    for (int64_t t = 0; t < n_p * dim; ++t) TBK_ARG(powers[t] >= 0, "negative power");
+    tbk_model* m = nullptr;
+    TBK_CHECK(create_common(device, dim, n_orb, n_p, nullptr, 1, &m));
+    m->kdotp = true;
+    double* d_raw = nullptr;
+    const size_t raw_bytes = (size_t)n_p * n_orb * n_orb * 2 * sizeof(double);
+    int rc = [&]() -> int {
+        if (n_p > 0) {
+            TBK_HIP(hipMalloc((void**)&m->d_powers, (size_t)n_p * dim * sizeof(int32_t)));
+            TBK_HIP(hipMemcpy(m->d_powers, powers, (size_t)n_p * dim * sizeof(int32_t), hipMemcpyHostToDevice));
+            TBK_HIP(hipMalloc((void**)&d_raw, raw_bytes));
+            TBK_HIP(hipMemcpyAsync(d_raw, coeffs, raw_bytes, hipMemcpyHostToDevice, m->stream));
+        }
+        TBK_CHECK(tbk_stage_kdotp(m, d_raw));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+        return TBK_OK;
+    }();
+    if (d_raw) (void)hipFree(d_raw);
+    if (rc != TBK_OK) {
+        tbk_model_destroy(m);
+        return rc;
+    }
+    tbk_kdotp* kp = new (std::nothrow) tbk_kdotp();
+    if (!kp) {
+        tbk_model_destroy(m);
+        tbk_set_error("out of host memory");
+        return TBK_ERR_MEMORY;
+    }
+    kp->core = m;
+    *out = kp;
+    return TBK_OK;
+}
+
+extern "C" void tbk_kdotp_destroy(tbk_kdotp* kp) {
+    if (!kp) return;
+    tbk_model_destroy(kp->core);
+    delete kp;
+}
+
+extern "C" int tbk_kdotp_hamilton(tbk_kdotp* kp, const double* k, int64_t nk, double* H_out) {
+    TBK_ARG(kp != nullptr, "model is NULL");
+    return tbk_hamilton(kp->core, k, nk, 2, nullptr, H_out);
+}
+
+extern "C" int tbk_kdotp_eigenval(tbk_kdotp* kp, const double* k, int64_t nk, double* E_out) {
+    TBK_ARG(kp != nullptr, "model is NULL");
+    return tbk_eigenval(kp->core, k, nk, E_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int tbk_device_malloc(int device, int64_t bytes, void** d_ptr) {
+    TBK_ARG(d_ptr != nullptr && bytes >= 0, "bad malloc arguments");
+    TBK_CHECK(require_device(device));
+    *d_ptr = nullptr;
+    if (bytes == 0) return TBK_OK;
+    TBK_HIP(hipMalloc(d_ptr, (size_t)bytes));
+    return TBK_OK;
+}
+
+extern "C" int tbk_device_free(int device, void* d_ptr) {
+    if (!d_ptr) return TBK_OK;
+    TBK_CHECK(require_device(device));
+    TBK_HIP(hipFree(d_ptr));
+    return TBK_OK;
+}
+
+extern "C" int tbk_memcpy_h2d(int device, void* d_dst, const void* h_src, int64_t bytes) {
+    TBK_CHECK(require_device(device));
+    if (bytes > 0) {
+        TBK_HIP(hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));
+        TBK_HIP(hipDeviceSynchronize());  // pageable H2D may return before the DMA has landed
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_memcpy_d2h(int device, void* h_dst, const void* d_src, int64_t bytes) {
+    TBK_CHECK(require_device(device));
+    if (bytes > 0) TBK_HIP(hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return TBK_OK;
+}
+
+extern "C" int tbk_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes) {
+    TBK_CHECK(require_device(device));
+    size_t f = 0, t = 0;
+    TBK_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timing
+// ------------------------------------------------------------------------------------------------
+extern "C" int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int reset) {
+    TBK_ARG(m != nullptr, "model is NULL");
+    TBK_HIP(hipSetDevice(m->device));
+    TBK_HIP(hipStreamSynchronize(m->stream));
+    for (auto& ev : m->events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ev.start, ev.stop) == hipSuccess) {
+            m->t_ms[ev.stage] += (double)t;
+            m->t_n[ev.stage] += 1;
+        }
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
+    }
+    m->events.clear();
+    for (int i = 0; i < TBK_T_COUNT; ++i) {
+        if (ms) ms[i] = m->t_ms[i];
+        if (launches) launches[i] = m->t_n[i];
+        if (reset) {
+            m->t_ms[i] = 0.0;
+            m->t_n[i] = 0;
+        }
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_mfma_f64_peak(int device, double* tflops) {
+    TBK_ARG(tflops != nullptr, "tflops is NULL");
+    TBK_CHECK(require_device(device));
+    return tbk_run_mfma_f64_peak(tflops);
+}

@@ -1,0 +1,84 @@
+// tbk_comm.hip -- the one exchange of the sharded path: an RCCL all-gather of per-rank eigenvalue
+// slabs over xGMI.  One process per GPU; the launcher (bench.py / tbmodels_amd.sharding) hands the
+// 128-byte unique id from rank 0 to the other ranks over its own rendezvous.
+//
+// The reference has no distributed code at all; k-points are independent
+// (/root/reference/src/tbmodels/_tb_model.py:1111-1123 has no cross-k term), so the hoppings are
+// replicated, the k list is split into contiguous slabs, and this gather is the only collective.
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+
+#include "tbk_internal.h"
+
+struct tbk_comm {
+    int device = 0;
+    int world = 1;
+    int rank = 0;
+    ncclComm_t comm = nullptr;
+};
+
+#define TBK_NCCL(expr)                                                                           \
+    do {                                                                                         \
+        ncclResult_t r_ = (expr);                                                                \
+        if (r_ != ncclSuccess) {                                                                 \
+            tbk_set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__,      \
+                          __LINE__);                                                             \
+            return TBK_ERR_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == 128, "tbk_comm_unique_id hands out 128 bytes");
+
+extern "C" int tbk_comm_unique_id(void* id128) {
+    TBK_ARG(id128 != nullptr, "id buffer is NULL");
+    ncclUniqueId id;
+    TBK_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return TBK_OK;
+}
+
+extern "C" int tbk_comm_create(int device, int world_size, int rank, const void* id128, tbk_comm** out) {
+    TBK_ARG(out != nullptr && id128 != nullptr, "out / id is NULL");
+    TBK_ARG(world_size >= 1 && rank >= 0 && rank < world_size, "bad rank / world size");
+    *out = nullptr;
+    TBK_HIP(hipSetDevice(device));
+    tbk_comm* c = new (std::nothrow) tbk_comm();
+    if (!c) {
+        tbk_set_error("out of host memory");
+        return TBK_ERR_MEMORY;
+    }
+    c->device = device;
+    c->world = world_size;
+    c->rank = rank;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
+    if (r != ncclSuccess) {
+        tbk_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
+        delete c;
+        return TBK_ERR_DEVICE;
+    }
+    *out = c;
+    return TBK_OK;
+}
+
+extern "C" void tbk_comm_destroy(tbk_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
+                                      int64_t count) {
+    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
+    TBK_ARG(count >= 0, "count < 0");
+    if (count == 0) return TBK_OK;
+    TBK_ARG(d_send && d_recv, "send / recv is NULL");
+    TBK_HIP(hipSetDevice(c->device));
+    TBK_NCCL(ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, m->stream));
+    return TBK_OK;
+}

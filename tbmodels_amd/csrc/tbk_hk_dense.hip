@@ -1,0 +1,259 @@
+// tbk_hk_dense.hip -- H(k) for a chunk of k-points and dense hoppings: the Fourier sum of
+// /root/reference/src/tbmodels/_tb_model.py:1109-1128 as ONE real f64 MFMA contraction.
+//
+//     H[k][e].{re,im} = sum_kk  A[kk][k] * Bt[kk][e].{re,im}
+//
+//     A   [k2][nk_pad]                 cos/sin rows from tbk_phase.hip (k contiguous)
+//     Bt  [k2][ncol_pad/16][2][16]     symmetrised hoppings from tbk_stage.hip
+//     e = packed upper-triangle element (i <= j);  output scattered to H[k][i][j] (and, in FULL
+//     mode, the conjugate to H[k][j][i]) -- the `H += H^H` of :1123 is already inside Bt.
+//
+// Machine mapping (gfx950):
+//   * v_mfma_f64_16x16x4_f64: 16 k-points x 16 columns x 4 K rows per instruction, one f64 of A and
+//     of B per lane (A[i = lane & 15][kk = lane >> 4], B[kk = lane >> 4][j = lane & 15]), result
+//     D[row = (lane >> 4) + 4 reg][col = lane & 15].
+//   * workgroup = 4 waves = 128 k-points x 64 packed elements (128 real columns); wave (wm, wn)
+//     owns 64 k-points x 32 elements = 4 x 2 x {re, im} = 16 accumulators (128 VGPRs).
+//   * K is walked in stages of 16 rows through double-buffered LDS: global -> registers (issued
+//     before the MFMAs of the current stage) -> LDS (after them), one barrier per stage.
+//     LDS rows are padded by 16 doubles so that the two K rows a 32-lane group reads with
+//     ds_read_b64 fall in different halves of the 64-bank row: conflict-free.
+//   * both operands are K-major with the fast index contiguous, so every staging load is a
+//     full 1 KiB wave row (16 B per lane) and every fragment read is 128 contiguous bytes per
+//     16 lanes.
+//   * the tile grid is walked so that the 32 workgroups resident on one XCD (block b runs on XCD
+//     b % 8) share A row-panels and Bt column-panels in that XCD's private L2.
+//
+// Roofline: 8 * ncol * n_r flops per k-point against (16 + 16) B of operand traffic per
+// (k-tile row + column) K step -- FP64-MFMA bound (78.6 TFLOP/s), not HBM bound; see DESIGN.md.
+
+#include "tbk_internal.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int LDA = TBK_BM + 16;       // doubles per K row of the A stage
+constexpr int LDB = 2 * TBK_BNP + 16;  // doubles per K row of the B stage
+constexpr int STAGE_DOUBLES = TBK_BK * (LDA + LDB);
+
+static_assert(TBK_BM == 128 && TBK_BNP == 64 && TBK_BK == 16, "wave decomposition is written for 128x64x16");
+
+struct HkArgs {
+    const double* A;
+    const double* Bt;
+    const int32_t* colmap;
+    const double* kpts;  // [nk][dim], convention 1 only
+    const double* pos;   // [n_orb][dim], convention 1 only
+    double* H;
+    int64_t k2;
+    int64_t nk;
+    int64_t nk_pad;
+    int ncol_pad;
+    int n_orb;
+    int dim;
+    int mt_count;  // k tiles
+    int nt_count;  // element tiles
+    int xcd_rows;  // 0: plain order; > 0: k tiles per XCD super-row
+};
+
+__device__ __forceinline__ bool tile_of_block(const HkArgs& a, int b, int& mt, int& nt) {
+    if (a.xcd_rows == 0) {
+        nt = b % a.nt_count;
+        mt = b / a.nt_count;
+        return mt < a.mt_count;
+    }
+    // XCD-aware walk: XCD x owns the k tiles {mt : mt % 8 == x}; inside an XCD consecutive blocks
+    // sweep `xcd_rows` k tiles for one element tile, then the next element tile, so the ~32
+    // co-resident workgroups of an XCD form an (xcd_rows x 32/xcd_rows) patch of the tile grid.
+    const int x = b & 7;
+    const int t = b >> 3;
+    const int per_group = a.xcd_rows * a.nt_count;
+    const int g = t / per_group;
+    const int r = t % per_group;
+    nt = r / a.xcd_rows;
+    mt = (g * a.xcd_rows + r % a.xcd_rows) * 8 + x;
+    return mt < a.mt_count;
+}
+
+template <int MODE, int CONV>
+__global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+
+    int mt_idx, nt_idx;
+    if (!tile_of_block(a, blockIdx.x, mt_idx, nt_idx)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1;  // which 64 k-points
+    const int wn = wave & 1;   // which 32 packed elements
+    const int l15 = lane & 15;
+    const int l4 = lane >> 4;
+
+    const int64_t m0 = (int64_t)mt_idx * TBK_BM;
+    const int64_t n0 = (int64_t)nt_idx * TBK_BNP;
+
+    // staging: wave w copies K rows w, w+4, w+8, w+12 of both operands, 16 B per lane
+    const double* gA = a.A + m0 + lane * 2;
+    const double* gB = a.Bt + n0 * 2 + lane * 2;
+    const int64_t ldgA = a.nk_pad;
+    const int64_t ldgB = (int64_t)a.ncol_pad * 2;
+
+    d4 acc[4][2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) acc[i][j][p] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    d2 ra[4], rb[4];
+    const int n_stage = (int)(a.k2 / TBK_BK);
+
+    auto load_stage = [&](int s) {
+        const int64_t kk0 = (int64_t)s * TBK_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t kk = kk0 + wave + 4 * i;
+            ra[i] = *reinterpret_cast<const d2*>(gA + kk * ldgA);
+            rb[i] = *reinterpret_cast<const d2*>(gB + kk * ldgB);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        double* sA = smem + buf * STAGE_DOUBLES;
+        double* sB = sA + TBK_BK * LDA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave + 4 * i;
+            *reinterpret_cast<d2*>(sA + row * LDA + lane * 2) = ra[i];
+            *reinterpret_cast<d2*>(sB + row * LDB + lane * 2) = rb[i];
+        }
+    };
+
+    if (n_stage > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < n_stage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_stage) load_stage(s + 1);
+
+        const double* sA = smem + buf * STAGE_DOUBLES + wm * 64 + l15;
+        const double* sB = smem + buf * STAGE_DOUBLES + TBK_BK * LDA + wn * 64 + l15;
+#pragma unroll
+        for (int ks = 0; ks < TBK_BK / 4; ++ks) {
+            const int krow = ks * 4 + l4;
+            double fa[4], fb[2][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = sA[krow * LDA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[j][0] = sB[krow * LDB + j * 32];
+                fb[j][1] = sB[krow * LDB + j * 32 + 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j][0], acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j][1], acc[i][j][1], 0, 0, 0);
+                }
+        }
+
+        if (s + 1 < n_stage) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scatter the packed tile into H[k][i][j] (and H[k][j][i]) ----
+    const size_t nn = (size_t)a.n_orb * a.n_orb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = (int)n0 + (wn * 2 + j) * 16 + l15;
+        const int32_t ij = a.colmap[e];
+        if (ij < 0) continue;
+        const int oi = ij >> 16, oj = ij & 0xffff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t kq = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+                if (kq >= a.nk) continue;
+                double re = acc[i][j][0][r];
+                double im = acc[i][j][1][r];
+                if (CONV == 1) {
+                    // H[i][j] *= conj(e_i) e_j,  e_p = exp(2 pi i k.pos_p)   (_tb_model.py:1124-1128)
+                    double dot = 0.0;
+                    for (int d = 0; d < a.dim; ++d)
+                        dot = fma(a.kpts[kq * a.dim + d], a.pos[oj * a.dim + d] - a.pos[oi * a.dim + d], dot);
+                    double sn, cs;
+                    sincospi(2.0 * dot, &sn, &cs);
+                    const double t = re * cs - im * sn;
+                    im = re * sn + im * cs;
+                    re = t;
+                }
+                double* hk = a.H + (size_t)kq * nn * 2;
+                *reinterpret_cast<d2*>(hk + ((size_t)oi * a.n_orb + oj) * 2) = (d2){re, im};
+                if (MODE == HK_FULL && oi != oj)
+                    *reinterpret_cast<d2*>(hk + ((size_t)oj * a.n_orb + oi) * 2) = (d2){re, -im};
+            }
+        }
+    }
+}
+
+template <int MODE, int CONV>
+hipError_t launch(const HkArgs& a, int grid, hipStream_t s) {
+    const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
+                        int convention, const double* d_k, const double* d_pos, double* d_H) {
+    if (nk == 0) return TBK_OK;
+    HkArgs a;
+    a.A = d_A;
+    a.Bt = m->d_B;
+    a.colmap = m->d_colmap;
+    a.kpts = d_k;
+    a.pos = d_pos;
+    a.H = d_H;
+    a.k2 = m->k2;
+    a.nk = nk;
+    a.nk_pad = nk_pad;
+    a.ncol_pad = m->ncol_pad;
+    a.n_orb = m->n_orb;
+    a.dim = m->dim;
+    a.mt_count = (int)(nk_pad / TBK_BM);
+    a.nt_count = m->ncol_pad / TBK_BNP;
+    int grid;
+    if (a.mt_count >= 32) {
+        a.xcd_rows = 4;
+        const int groups = (a.mt_count + 8 * a.xcd_rows - 1) / (8 * a.xcd_rows);
+        grid = groups * a.xcd_rows * a.nt_count * 8;
+    } else {
+        a.xcd_rows = 0;
+        grid = a.mt_count * a.nt_count;
+    }
+    StageTimer t(m, TBK_T_HK);
+    if (mode == HK_TRI) {
+        TBK_HIP((launch<HK_TRI, 2>(a, grid, m->stream)));
+    } else if (convention == 1) {
+        TBK_HIP((launch<HK_FULL, 1>(a, grid, m->stream)));
+    } else {
+        TBK_HIP((launch<HK_FULL, 2>(a, grid, m->stream)));
+    }
+    return TBK_OK;
+}

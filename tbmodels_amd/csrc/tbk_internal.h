@@ -1,0 +1,174 @@
+// tbk_internal.h -- shared declarations of libtbk.so (not part of the C ABI; see include/tbk.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "tbk.h"
+
+// ------------------------------------------------------------------------------------------------
+// Tile geometry of the dense H(k) kernel (tbk_hk_dense.hip).  The staging code pads to these.
+// ------------------------------------------------------------------------------------------------
+constexpr int TBK_BM = 128;      // k-points per workgroup tile
+constexpr int TBK_BNP = 64;      // packed (i <= j) matrix elements per workgroup tile (x2 real columns)
+constexpr int TBK_BK = 16;       // depth of one LDS stage in real K rows (= 8 lattice vectors)
+constexpr int TBK_CT = 16;       // packed elements per MFMA column tile
+constexpr int TBK_MAX_DIM = 8;   // lattice dimension limit of the phase kernel
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+void tbk_set_error(const char* fmt, ...);
+
+#define TBK_HIP(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            tbk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,        \
+                          __LINE__);                                                              \
+            return (e_ == hipErrorOutOfMemory) ? TBK_ERR_MEMORY : TBK_ERR_DEVICE;                 \
+        }                                                                                         \
+    } while (0)
+
+#define TBK_ROCBLAS(expr)                                                                         \
+    do {                                                                                          \
+        rocblas_status s_ = (expr);                                                               \
+        if (s_ != rocblas_status_success) {                                                       \
+            tbk_set_error("%s failed: rocblas_status %d (%s:%d)", #expr, (int)s_, __FILE__,       \
+                          __LINE__);                                                              \
+            return (s_ == rocblas_status_memory_error) ? TBK_ERR_MEMORY : TBK_ERR_DEVICE;         \
+        }                                                                                         \
+    } while (0)
+
+#define TBK_CHECK(expr)                                                                           \
+    do {                                                                                          \
+        int r_ = (expr);                                                                          \
+        if (r_ != TBK_OK) return r_;                                                              \
+    } while (0)
+
+#define TBK_ARG(cond, msg)                                                                        \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            tbk_set_error("invalid argument: %s", msg);                                           \
+            return TBK_ERR_ARGUMENT;                                                              \
+        }                                                                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// a grow-only device buffer
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want);  // keeps contents only if no reallocation happens
+    void release();
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(ptr);
+    }
+};
+
+struct EventPair {
+    hipEvent_t start, stop;
+    int stage;
+};
+
+// ------------------------------------------------------------------------------------------------
+// staged model
+// ------------------------------------------------------------------------------------------------
+struct tbk_model {
+    int device = 0;
+    int dim = 0;
+    int n_orb = 0;
+    int64_t n_r = 0;
+    bool sparse = false;
+    bool kdotp = false;  // K rows are k.p monomials (one per Taylor coefficient) instead of phases
+
+    // --- common staging ---
+    int64_t n_r_pad = 0;   // n_r rounded up so that 2 * n_r_pad is a multiple of TBK_BK
+    int64_t k2 = 0;        // real K rows of the contraction: 2 * n_r_pad (cos, sin per lattice vector)
+    int ncol = 0;          // n_orb (n_orb + 1) / 2 packed upper-triangle elements
+    int ncol_pad = 0;      // rounded up to TBK_BNP
+    int32_t* d_R = nullptr;       // [n_r_pad][dim] lattice vectors (padding rows are zero)
+    int32_t* d_colmap = nullptr;  // [ncol_pad]  (i << 16) | j, or -1 for padding
+    int32_t* d_powers = nullptr;  // k.p only: [n_r][dim] monomial exponents
+
+    // --- dense: symmetrised hop planes, tile-interleaved  Bt[K2][ncol_pad / 16][2][16] ---
+    double* d_B = nullptr;
+
+    // --- sparse: per packed element, the list of lattice vectors that touch it ---
+    int64_t nnz_rec = 0;
+    int64_t* d_cptr = nullptr;   // [ncol + 1]
+    int32_t* d_rec_r = nullptr;  // [nnz_rec]  (kind << 28) | r   kind: 0 direct, 1 transposed, 2 diagonal
+    double* d_rec_v = nullptr;   // [nnz_rec][2]
+
+    int64_t staged_bytes = 0;
+
+    // --- options ---
+    int eigensolver = TBK_EIG_AUTO;
+    int64_t k_chunk = 0;
+    bool timing = false;
+
+    // --- runtime ---
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    DevBuf ws_phase;  // [K2][nk_pad] cos/sin rows
+    DevBuf ws_H;      // [chunk][n_orb][n_orb] complex
+    DevBuf ws_E;      // [chunk][n_orb] rocSOLVER off-diagonal scratch
+    DevBuf ws_info;   // [chunk] int
+    DevBuf ws_k;      // host-entry staging of k / pos / E
+    DevBuf ws_pos;
+    DevBuf ws_out;
+    DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
+    std::vector<EventPair> events;
+    double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
+    int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};
+};
+
+struct tbk_kdotp {
+    tbk_model* core = nullptr;  // the dense pipeline with monomial rows in place of phase rows
+};
+
+// timing scope helper: records a start/stop pair on the model stream when timing is on
+struct StageTimer {
+    tbk_model* m;
+    EventPair ev;
+    bool on;
+    StageTimer(tbk_model* m_, int stage);
+    ~StageTimer();
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels (each .hip file exposes plain launchers)
+// ------------------------------------------------------------------------------------------------
+enum HkMode { HK_TRI = 0, HK_FULL = 1 };
+
+// tbk_phase.hip
+int tbk_launch_phase(tbk_model* m, const double* d_k, int64_t nk, int64_t nk_pad, double* d_A);
+int tbk_launch_monomials(hipStream_t s, const int32_t* d_powers, int dim, int64_t n_p,
+                         int64_t n_p_pad, const double* d_k, int64_t nk, int64_t nk_pad,
+                         double* d_A);
+
+// tbk_stage.hip
+int tbk_stage_dense(tbk_model* m, const double* d_hop_raw);
+int tbk_stage_kdotp(tbk_model* m, const double* d_coeff_raw);
+
+// tbk_hk_dense.hip
+int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
+                        int convention, const double* d_k, const double* d_pos, double* d_H);
+
+// tbk_hk_csr.hip
+int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
+                      int convention, const double* d_k, const double* d_pos, double* d_H);
+
+// tbk_eig.hip
+int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);
+size_t tbk_eig_scratch_per_k(const tbk_model* m);
+
+// tbk_peak.hip
+int tbk_run_mfma_f64_peak(double* tflops);

@@ -1,0 +1,97 @@
+"""
+``KdotpModel`` -- host-side mirror of ``tbmodels.kdotp.KdotpModel``
+(``/root/reference/src/tbmodels/kdotp.py:20-100``), evaluated on the GPU.
+
+``H(k) = sum_p prod_d k_d^{p_d} * C_p`` has the same shape as the tight-binding Fourier sum with the
+phase rows replaced by monomial rows, so it runs through the same MFMA contraction and batched
+eigensolver (``tbk_kdotp_*`` in ``include/tbk.h``).
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ("KdotpModel",)
+
+
+class KdotpModel:
+    """
+    A k.p model.  ``taylor_coefficients`` maps a tuple of powers of the k components to a Hermitian
+    matrix, e.g. ``{(1, 0, 2): [[1, 0], [0, -1]]}`` is ``k_x k_z^2 sigma_z``.
+    """
+
+    def __init__(self, taylor_coefficients):
+        for mat in taylor_coefficients.values():
+            if not np.allclose(mat, np.array(mat).T.conj()):
+                raise ValueError("The provided Taylor coefficient {} is not hermitian".format(mat))
+        self.taylor_coefficients = {
+            tuple(key): np.array(mat, dtype=complex) for key, mat in taylor_coefficients.items()
+        }
+        self._handle = None
+        self.device = 0
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_handle"] = None
+        return state
+
+    def __del__(self):
+        handle = getattr(self, "_handle", None)
+        if handle is not None:
+            try:
+                _lib.lib().tbk_kdotp_destroy(handle)
+            except Exception:  # pylint: disable=broad-except
+                pass
+        self._handle = None
+
+    def _shape(self):
+        if not self.taylor_coefficients:
+            raise ValueError("empty k.p model")
+        key, mat = next(iter(self.taylor_coefficients.items()))
+        return len(key), mat.shape[0]
+
+    def _staged(self):
+        if self._handle is None:
+            dim, size = self._shape()
+            keys = list(self.taylor_coefficients.keys())
+            powers = np.array(keys, dtype=np.int32).reshape(len(keys), dim)
+            coeffs = np.ascontiguousarray(np.stack([self.taylor_coefficients[k] for k in keys]), dtype=np.complex128)
+            handle = ctypes.c_void_p()
+            _lib.check(
+                _lib.lib().tbk_kdotp_create(
+                    self.device, dim, size, len(keys), _lib.ptr(powers), _lib.ptr(coeffs), ctypes.byref(handle)
+                )
+            )
+            self._handle = handle
+        return self._handle
+
+    def _k_array(self, k):
+        dim, _ = self._shape()
+        k_array = np.array(k, ndmin=1)
+        single = k_array.ndim == 1
+        if single:
+            k_array = k_array.reshape((1, -1))
+        k_array = np.ascontiguousarray(k_array, dtype=np.float64)
+        if k_array.ndim != 2 or k_array.shape[1] != dim:
+            raise ValueError("operands could not be broadcast together: k has shape {}".format(k_array.shape))
+        return k_array, single
+
+    def hamilton(self, k):
+        """H(k) at one k-point or a list of k-points (``kdotp.py:51-82``)."""
+        k_array, single = self._k_array(k)
+        _, size = self._shape()
+        out = np.empty((k_array.shape[0], size, size), dtype=np.complex128)
+        _lib.check(_lib.lib().tbk_kdotp_hamilton(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
+        return out[0] if single else out
+
+    def eigenval(self, k):
+        """Eigenvalues at one k-point or a list of k-points (``kdotp.py:84-100``)."""
+        k_array, single = self._k_array(k)
+        if not np.isfinite(k_array).all():
+            raise ValueError("array must not contain infs or NaNs")
+        _, size = self._shape()
+        out = np.empty((k_array.shape[0], size), dtype=np.float64)
+        _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
+        return out[0] if single else list(out)

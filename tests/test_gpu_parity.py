@@ -1,0 +1,207 @@
+"""
+GPU parity tests (``-m gpu``): the HIP path, called through tbmodels_amd.Model -> ctypes ->
+libtbk.so, against (a) the golden fixtures generated from the imported reference (which embed the
+reference's own stored goldens) and (b) the oracle on seeded inputs.  Tolerance: 1e-10 absolute on
+eigenvalues and on H(k) (BASELINE.json north_star; the reference's own known-answer test uses
+atol 1e-10, tests/test_cli_eigenvals.py:48-50).
+"""
+
+import pickle
+
+import numpy as np
+import pytest
+
+import tbmodels_amd
+from tbmodels_amd import synthetic as syn
+from oracle import tbk_oracle as oracle
+
+from conftest import KPT, T_VALUES
+from test_host_model import toy_model
+from test_oracle_golden import SYN_TAGS, synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= tol, err
+
+
+def test_silicon_known_answer(silicon):
+    """The reference's known-answer test (tests/test_cli_eigenvals.py): 11 k-points, atol 1e-10."""
+    model = tbmodels_amd.Model.from_packed(silicon["R"], silicon["hop"], pos=silicon["pos"], uc=silicon["uc"])
+    eig = model.eigenval(silicon["known_kpoints"])
+    assert isinstance(eig, list) and len(eig) == 11 and eig[0].shape == (8,)
+    _close(np.array(eig), silicon["known_eigenvals"])
+
+
+def test_silicon_config1_grid(silicon):
+    """BASELINE config 1: silicon, 10x10x10 grid, against the reference's output."""
+    model = tbmodels_amd.Model.from_packed(silicon["R"], silicon["hop"], pos=silicon["pos"])
+    _close(np.array(model.eigenval(silicon["grid"])), silicon["grid_eig"])
+    _close(model.hamilton(silicon["grid"][:16]), silicon["grid_h2_first16"])
+    _close(model.hamilton(silicon["grid"][:16], convention=1), silicon["grid_h1_first16"])
+    _close(model.hamilton(silicon["kpt"]), silicon["kpt_h2"])
+    _close(model.hamilton(silicon["kpt"], convention=1), silicon["kpt_h1"])
+    _close(np.array(model.eigenval(silicon["kpt"])), silicon["kpt_eig"])
+    ham = model.hamilton(silicon["grid"])
+    _close(ham, ham.conj().transpose(0, 2, 1), 0.0)  # exactly Hermitian, like H += H^H
+    assert np.all(ham.imag[:, np.arange(8), np.arange(8)] == 0.0)
+
+
+def test_silicon_wannier_stored_golden(silicon):
+    model = tbmodels_amd.Model.from_packed(silicon["wannier_R"], silicon["wannier_hop"], pos=silicon["wannier_pos"])
+    _close(np.array([model.hamilton(k) for k in KPT]), silicon["wannier_kpt_h2_stored"])
+
+
+@pytest.mark.parametrize("t_idx", range(6))
+@pytest.mark.parametrize("sparse", [False, True])
+def test_toy_stored_goldens(toy, t_idx, sparse):
+    """tests/test_hamilton.py / tests/test_eigenval.py of the reference, through the mirrored API."""
+    model = toy_model(*T_VALUES[t_idx], sparse=sparse)
+    tag = "t%d_%s" % (t_idx, "sparse" if sparse else "dense")
+    for conv in (1, 2):
+        per_k = np.array([model.hamilton(k, convention=conv) for k in KPT])
+        _close(per_k, toy[tag + "_h%d_stored" % conv])
+        # batch == per-k (tests/test_hamilton.py:21-32)
+        _close(model.hamilton(KPT, convention=conv), per_k, 1e-14)
+    eig = np.array([model.eigenval(k) for k in KPT])
+    _close(eig, toy[tag + "_eig_stored"])
+    _close(np.array(model.eigenval(KPT)), eig, 1e-14)
+
+
+@pytest.mark.parametrize("dim", [2, 4])
+def test_toy_other_dims(toy, dim):
+    tag = "dim%d" % dim
+    model = tbmodels_amd.Model.from_packed(toy[tag + "_R"], toy[tag + "_hop"], pos=toy[tag + "_pos"])
+    k = toy[tag + "_k"]
+    _close(model.hamilton(k), toy[tag + "_h2"])
+    _close(model.hamilton(k, convention=1), toy[tag + "_h1"])
+    _close(np.array(model.eigenval(k)), toy[tag + "_eig"])
+
+
+@pytest.mark.parametrize("tag", SYN_TAGS)
+@pytest.mark.parametrize("sparse", [False, True])
+def test_synthetic_cases(synthetic, tag, sparse):
+    """Dense kernel and CSR kernel on the same models: both must match the reference (sparse == dense)."""
+    r_vec, hop, pos, k = synthetic_case(synthetic, tag)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=sparse)
+    n_h = len(synthetic[tag + "_h2"])
+    _close(model.hamilton(k[:n_h]), synthetic[tag + "_h2"])
+    _close(model.hamilton(k[:n_h], convention=1), synthetic[tag + "_h1"])
+    _close(np.array(model.eigenval(k)), synthetic[tag + "_eig"])
+
+
+def test_scalar_k_single_point_and_empty(synthetic):
+    model = tbmodels_amd.Model.from_packed(synthetic["dim1_R"], synthetic["dim1_hop"], pos=synthetic["dim1_pos"])
+    k = float(synthetic["dim1_scalar_k"])
+    ham = model.hamilton(k)
+    assert ham.shape == (6, 6)
+    _close(ham, synthetic["dim1_scalar_h2"])
+    _close(model.hamilton(k, convention=1), synthetic["dim1_scalar_h1"])
+    eig = model.eigenval(k)
+    assert isinstance(eig, np.ndarray) and eig.shape == (6,)
+    _close(eig, synthetic["dim1_scalar_eig"])
+    model = tbmodels_amd.Model.from_packed(synthetic["single_R"], synthetic["single_hop"])
+    _close(model.hamilton(synthetic["single_k"][0]), synthetic["single_k0_h2"])
+    _close(model.eigenval(synthetic["single_k"][0]), synthetic["single_k0_eig"])
+    empty = tbmodels_amd.Model(size=3, dim=3)
+    k = [[0.1, 0.2, 0.3], [0.5, 0.5, 0.5]]
+    _close(empty.hamilton(k), synthetic["empty_h2"])
+    _close(np.array(empty.eigenval(k)), synthetic["empty_eig"])
+    assert len(empty.eigenval(np.zeros((0, 3)))) == 0  # an empty batch is an empty list
+    assert empty.hamilton(np.zeros((0, 3))).shape == (0, 3, 3)
+
+
+def test_restaging_after_mutation(toy):
+    """add_hop / in-place edits / set_sparse between calls must be seen by the next call."""
+    model = toy_model(0.2, -0.2)
+    first = model.hamilton(KPT)
+    model.add_hop(0.3 + 0.1j, 0, 1, (2, -1, 0))
+    r_vec, hop = model.packed_hop()
+    _close(model.hamilton(KPT), oracle.hamilton(r_vec, hop, KPT))
+    assert np.abs(model.hamilton(KPT) - first).max() > 1e-3
+    model.hop[(0, 0, 0)] += 0.05 * np.eye(2)
+    r_vec, hop = model.packed_hop()
+    _close(np.array(model.eigenval(KPT)), np.array(oracle.eigenval(r_vec, hop, KPT)))
+    model.set_sparse(True)
+    _close(np.array(model.eigenval(KPT)), np.array(oracle.eigenval(r_vec, hop, KPT)))
+    clone = pickle.loads(pickle.dumps(model))
+    _close(clone.hamilton(KPT, convention=1), model.hamilton(KPT, convention=1), 0.0)
+
+
+@pytest.mark.parametrize("n_orb,n_r,n_k", [(64, 96, 300), (24, 17, 1000), (96, 40, 130), (3, 5, 4097)])
+def test_seeded_dense_vs_oracle(n_orb, n_r, n_k):
+    """Sizes that cross tile boundaries (k tiles of 128, element tiles of 64, K stages of 8 R) and the XCD walk."""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + n_orb)
+    k = syn.random_kpoints(n_k, seed=n_k) * 2 - 1
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    _close(np.array(model.eigenval(k)), np.array(oracle.eigenval(r_vec, hop, k)))
+    sub = k[: min(n_k, 64)]
+    _close(model.hamilton(sub), oracle.hamilton(r_vec, hop, sub))
+    _close(model.hamilton(sub, convention=1), oracle.hamilton(r_vec, hop, sub, 1, pos=pos))
+
+
+def test_seeded_csr_vs_oracle():
+    """BASELINE config 3 shape at reduced size: N=128, N_R=64, 2 % fill."""
+    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(128, 64, syn.MODEL_SEED + 3)
+    hop = syn.csr_to_dense(128, r_ptr, row, col, val)
+    k = syn.random_kpoints(200)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=True)
+    _close(np.array(model.eigenval(k)), np.array(oracle.eigenval(r_vec, hop, k)))
+    _close(model.hamilton(k[:32], convention=1), oracle.hamilton(r_vec, hop, k[:32], 1, pos=pos))
+    dense = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=False)
+    _close(dense.hamilton(k[:32]), model.hamilton(k[:32]), 1e-13)  # tests/test_sparse_dense.py
+
+
+def test_chunked_pipeline_matches_single_chunk():
+    """k chunks (TBK_OPT_K_CHUNK) must not change results; order of k is preserved."""
+    from tbmodels_amd import _lib
+
+    r_vec, hop, pos = syn.dense_model_arrays(32, 24, syn.MODEL_SEED + 77)
+    k = syn.random_kpoints(1000)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    whole = np.array(model.eigenval(k))
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 128)
+    _close(np.array(model.eigenval(k)), whole, 0.0)
+    _close(np.array(model.eigenval(k[::-1]))[::-1], whole, 1e-13)
+
+
+def test_kdotp_models(kdotp_golden):
+    g = kdotp_golden
+    for order in (0, 1, 2, 3):
+        powers, coeffs = g["order%d_powers" % order], g["order%d_coeffs" % order]
+        kp = tbmodels_amd.KdotpModel({tuple(p): c for p, c in zip(powers.tolist(), coeffs)})
+        dk = g["order%d_dk" % order]
+        _close(kp.hamilton(dk), g["order%d_h" % order])
+        _close(np.array(kp.eigenval(dk)), g["order%d_eig" % order])
+        _close(kp.hamilton(dk[0]), g["order%d_h_single" % order])
+        _close(kp.eigenval(dk[0]), g["order%d_eig_single" % order])
+
+
+def test_non_finite_k_is_value_error(silicon):
+    model = tbmodels_amd.Model.from_packed(silicon["R"], silicon["hop"])
+    with pytest.raises(ValueError):
+        model.eigenval([[0.1, np.nan, 0.2]])
+    assert np.isnan(model.hamilton([0.1, np.nan, 0.2])).any()
+
+
+def test_periodicity_and_linearity_properties():
+    """Size-independent properties at the headline orbital count: H(k + G) = H(k); H is additive in hop."""
+    r_vec, hop, pos = syn.dense_model_arrays(64, 256, syn.MODEL_SEED + 1)
+    k = syn.random_kpoints(256)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    h0 = model.hamilton(k)
+    shift = np.array([1.0, -2.0, 3.0])
+    _close(model.hamilton(k + shift), h0, 1e-11)
+    half_a = tbmodels_amd.Model.from_packed(r_vec[:100], hop[:100], pos=pos)
+    half_b = tbmodels_amd.Model.from_packed(r_vec[100:], hop[100:], pos=pos)
+    _close(half_a.hamilton(k) + half_b.hamilton(k), h0, 1e-12)
+    eig = np.array(model.eigenval(k))
+    assert np.all(np.diff(eig, axis=1) >= 0)  # ascending, like eigvalsh
+    _close(eig.sum(axis=1), np.trace(h0, axis1=1, axis2=2).real, 1e-10)

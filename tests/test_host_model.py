@@ -1,0 +1,186 @@
+"""
+Host-side logic of tbmodels_amd.Model (no GPU): construction semantics against what the reference
+itself built (fixtures), argument handling, error behaviour, pickling, the C-ABI surface.
+"""
+
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+import tbmodels_amd
+from tbmodels_amd import _lib
+
+from conftest import KPT, T_VALUES, ROOT
+
+
+def toy_model(t1, t2, sparse=False, dim=3):
+    """The toy model of the reference's tests/conftest.py:155-189, built through the mirrored API."""
+    import itertools
+
+    pos = [[0] * 2, [0.5] * 2]
+    for position in pos:
+        position.extend([0] * (dim - 2))
+    model = tbmodels_amd.Model(pos=pos, occ=1, on_site=(1, -1), size=2, dim=None, sparse=sparse)
+    for phase, r_part in zip([1, -1j, 1j, -1], itertools.product([0, -1], [0, -1])):
+        r_vec = list(r_part) + [0] * (dim - 2)
+        model.add_hop(t1 * phase, 0, 1, r_vec)
+    for r_part in itertools.permutations([0, 1]):
+        r_vec = list(r_part) + [0] * (dim - 2)
+        model.add_hop(t2, 0, 0, r_vec)
+        model.add_hop(-t2, 1, 1, r_vec)
+    return model
+
+
+@pytest.mark.parametrize("t_idx", range(6))
+@pytest.mark.parametrize("sparse", [False, True])
+def test_toy_hop_matches_reference_construction(toy, t_idx, sparse):
+    """add_hop / on_site bookkeeping gives exactly the hop dict the reference builds."""
+    model = toy_model(*T_VALUES[t_idx], sparse=sparse)
+    tag = "t%d_%s" % (t_idx, "sparse" if sparse else "dense")
+    r_ref, hop_ref = toy[tag + "_R"], toy[tag + "_hop"]
+    got = {key: np.array(mat) for key, mat in model.hop.items()}
+    assert set(got) == {tuple(r) for r in r_ref.tolist()}
+    for r, h in zip(r_ref.tolist(), hop_ref):
+        assert np.abs(got[tuple(r)] - h).max() < 1e-15
+    assert np.allclose(model.pos, toy[tag + "_pos"])
+    assert model._sparse is sparse
+
+
+def test_packed_roundtrip_dense_and_sparse(synthetic):
+    r_vec, hop, pos = synthetic["dense16_R"], synthetic["dense16_hop"], synthetic["dense16_pos"]
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    r2, h2 = model.packed_hop()
+    assert np.array_equal(r2, r_vec) and np.array_equal(h2, hop)
+    model.set_sparse(True)
+    r3, (r_ptr, row, col, val) = model.packed_hop()
+    assert np.array_equal(r3, r_vec)
+    dense = tbmodels_amd.synthetic.csr_to_dense(16, r_ptr, row, col, val)
+    assert np.array_equal(dense, hop)
+    assert np.array_equal(np.array(model.hop[tuple(r_vec[3])]), hop[3])  # __array__ of the CSR wrapper
+    model.set_sparse(False)
+    assert np.array_equal(model.packed_hop()[1], hop)
+
+
+def test_contains_cc_reduction():
+    """Full (+R and -R) input is halved onto the half-space; non-Hermitian input is rejected (:247-279)."""
+    a = np.array([[0.1, 0.2j], [0.3, -0.1]])
+    on = np.array([[1.0, 0.5], [0.5, -1.0]])
+    model = tbmodels_amd.Model(hop={(1, 0): a, (-1, 0): a.conj().T, (0, 0): on}, size=2)
+    assert set(model.hop) == {(1, 0), (0, 0)}
+    assert np.allclose(model.hop[(1, 0)], a)
+    assert np.allclose(model.hop[(0, 0)], on / 2)
+    with pytest.raises(ValueError):
+        tbmodels_amd.Model(hop={(1, 0): a, (-1, 0): a}, size=2)
+    # contains_cc=False: negative R folds to +R conjugated
+    model = tbmodels_amd.Model(hop={(-1, 0): a}, size=2, contains_cc=False)
+    assert np.allclose(model.hop[(1, 0)], a.conj().T)
+
+
+def test_positions_mapped_into_home_cell():
+    """pos outside [0,1) moves hoppings between lattice vectors (:221-245)."""
+    a = np.array([[0, 0.3], [0, 0]], dtype=complex)
+    model = tbmodels_amd.Model(hop={(1,): a}, pos=[[0.25], [1.5]], contains_cc=False)
+    assert np.allclose(model.pos, [[0.25], [0.5]])
+    assert set(model.hop) == {(2,)}
+    assert model.hop[(2,)][0, 1] == 0.3
+
+
+def test_size_dim_inference_errors():
+    with pytest.raises(ValueError):
+        tbmodels_amd.Model()
+    with pytest.raises(ValueError):
+        tbmodels_amd.Model(size=2)
+    with pytest.raises(ValueError):
+        tbmodels_amd.Model(size=2, dim=2, pos=[[0, 0]])
+    with pytest.raises(ValueError):
+        tbmodels_amd.Model(on_site=(1, 2), dim=2, hop={(1, 0): np.ones((3, 3))}, contains_cc=False)
+    with pytest.raises(ValueError):
+        tbmodels_amd.Model.from_hop_list(hop_list=[(1.0, 0, 1, (1, 0))])
+    model = tbmodels_amd.Model.from_hop_list(
+        hop_list=[(1.0, 0, 1, (1, 0)), (0.5, 0, 1, (1, 0))], size=2, contains_cc=False
+    )
+    assert model.hop[(1, 0)][0, 1] == 1.5
+    with pytest.raises(ValueError):
+        model.add_hop(1.0, 0, 1, (1, 0, 0))
+    with pytest.raises(ValueError):
+        model.add_on_site((1, 2, 3))
+
+
+@pytest.mark.parametrize("convention", ["a", "1", None, 3])
+def test_invalid_convention_raises_before_any_device_work(convention):
+    """tests/test_hamilton.py:35-42 of the reference; must hold on a machine without a GPU."""
+    model = toy_model(0, 0.1)
+    with pytest.raises(ValueError):
+        model.hamilton((0, 0, 0), convention=convention)
+
+
+def test_k_shape_mismatch_is_value_error():
+    model = toy_model(0.1, 0.2)
+    with pytest.raises(ValueError):
+        model.hamilton((0.0, 0.0))
+    with pytest.raises(ValueError):
+        model.eigenval([[0.0, 0.0, 0.0, 0.0]])
+
+
+def test_pickle_drops_device_state():
+    """tests/test_pickle.py of the reference: models survive pickling (multiprocessing use)."""
+    model = toy_model(0.1, 0.2, sparse=True)
+    clone = pickle.loads(pickle.dumps(model))
+    assert clone._handle is None
+    assert set(clone.hop) == set(model.hop)
+    for key in model.hop:
+        assert np.array_equal(np.array(clone.hop[key]), np.array(model.hop[key]))
+    clone.add_hop(0.1, 0, 1, (5, 0, 0))  # defaultdict factory still works after unpickling
+    assert (5, 0, 0) in clone.hop
+
+
+def test_fingerprint_tracks_in_place_mutation():
+    model = toy_model(0.1, 0.2)
+    before = model._fingerprint()
+    assert before == model._fingerprint()
+    model.hop[(0, 0, 0)][0, 0] += 1e-9
+    assert model._fingerprint() != before
+    before = model._fingerprint()
+    model.add_hop(0.01, 0, 1, (3, 0, 0))
+    assert model._fingerprint() != before
+    before = model._fingerprint()
+    model.set_sparse(True)
+    assert model._fingerprint() != before
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports exactly what include/tbk.h declares."""
+    with open(os.path.join(ROOT, "include", "tbk.h")) as handle:
+        header = handle.read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tbk_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert _lib.lib().tbk_version().startswith(b"tbk")
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the compute entry points raise; nothing silently computes on the host."""
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    model = toy_model(0.1, 0.2)
+    with pytest.raises(RuntimeError):
+        model.hamilton((0, 0, 0))
+    with pytest.raises(RuntimeError):
+        model.eigenval(KPT)
+
+
+def test_product_package_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "tbmodels_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(dirpath, name)) as handle:
+                    text = handle.read()
+                assert "import oracle" not in text and "from oracle" not in text, name
