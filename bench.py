@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--nk", type=int, default=0, help="override k-points per GPU")
     ap.add_argument("--nr", type=int, default=0, help="override N_R (exploration only)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="k-points for the CPU baseline (0 = skip)")
-    ap.add_argument("--eigensolver", default="auto", choices=["auto", "jacobi", "rocsolver"])
+    ap.add_argument("--eigensolver", default="auto", choices=["auto", "wave", "rocsolver"])
     ap.add_argument("--k-chunk", type=int, default=0)
     ap.add_argument("--construct-only", action="store_true", help="time H(k) construction alone (not the metric)")
     return ap.parse_args()
@@ -150,7 +150,7 @@ def main():
     k_slab = np.ascontiguousarray(k_slab)
 
     model = stage(lib, device, arrays)
-    solver = {"auto": _lib.TBK_EIG_AUTO, "jacobi": _lib.TBK_EIG_JACOBI, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[args.eigensolver]
+    solver = {"auto": _lib.TBK_EIG_AUTO, "wave": _lib.TBK_EIG_WAVE, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[args.eigensolver]
     _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, solver))
     if args.k_chunk:
         _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_K_CHUNK, args.k_chunk))

@@ -54,8 +54,11 @@ typedef enum tbk_status {
     TBK_ERR_NO_CONVERGENCE = 5 /* eigensolver did not converge                    -> LinAlgError  */
 } tbk_status;
 
-/* eigensolver selection for tbk_model_set_option(TBK_OPT_EIGENSOLVER, ...) */
-enum { TBK_EIG_AUTO = 0, TBK_EIG_JACOBI = 1, TBK_EIG_ROCSOLVER = 2 };
+/* eigensolver selection for tbk_model_set_option(TBK_OPT_EIGENSOLVER, ...):
+ *   WAVE      hand-written wave-per-matrix Householder + QL (n_orb <= 64 only)
+ *   ROCSOLVER rocsolver_zheevd_strided_batched
+ *   AUTO      WAVE when n_orb <= 64, ROCSOLVER otherwise */
+enum { TBK_EIG_AUTO = 0, TBK_EIG_WAVE = 1, TBK_EIG_ROCSOLVER = 2 };
 enum {
     TBK_OPT_EIGENSOLVER = 1, /* one of TBK_EIG_*                                           */
     TBK_OPT_K_CHUNK = 2,     /* max k-points per internal chunk (0 = choose from free HBM) */
@@ -116,8 +119,10 @@ int tbk_memcpy_h2d(int device, void* d_dst, const void* h_src, int64_t bytes);
 int tbk_memcpy_d2h(int device, void* h_dst, const void* d_src, int64_t bytes);
 int tbk_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
 
-/* ---- timing: HIP events on the model's stream around every kernel of the path ------------ */
-enum { TBK_T_PHASE = 0, TBK_T_HK = 1, TBK_T_EIG = 2, TBK_T_EXPAND = 3, TBK_T_COUNT = 4 };
+/* ---- timing: HIP events around every kernel of the path, on the stream it is launched on -------
+ * stages: PHASE phase rows; HK the H(k) contraction; EIG reduction to tridiagonal form (or the whole
+ * rocSOLVER call); QL tridiagonal QL + sort.  Stages of different k chunks may overlap in time. */
+enum { TBK_T_PHASE = 0, TBK_T_HK = 1, TBK_T_EIG = 2, TBK_T_QL = 3, TBK_T_COUNT = 4 };
 /* ms[i] = summed duration of stage i, launches[i] = number of timed launches; reset = 1 clears. */
 int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int reset);
 

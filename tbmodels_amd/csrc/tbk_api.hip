@@ -55,20 +55,21 @@ void DevBuf::release() {
     bytes = 0;
 }
 
-StageTimer::StageTimer(tbk_model* m_, int stage) : m(m_), on(m_->timing) {
+StageTimer::StageTimer(tbk_model* m_, int stage, hipStream_t s)
+    : m(m_), on(m_->timing), stream(s ? s : m_->stream) {
     ev.stage = stage;
     if (on) {
         if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
             on = false;
             return;
         }
-        (void)hipEventRecord(ev.start, m->stream);
+        (void)hipEventRecord(ev.start, stream);
     }
 }
 
 StageTimer::~StageTimer() {
     if (on) {
-        (void)hipEventRecord(ev.stop, m->stream);
+        (void)hipEventRecord(ev.stop, stream);
         m->events.push_back(ev);
     }
 }
@@ -98,7 +99,7 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     TBK_ARG(dim >= 1 && dim <= TBK_MAX_DIM, "dim must be in [1, 8]");
     TBK_ARG(n_orb >= 1 && n_orb <= 32768, "n_orb must be in [1, 32768]");
     TBK_ARG(n_r >= 0 && n_r < (int64_t(1) << 28), "n_r out of range");
-    TBK_ARG(n_r == 0 || R != nullptr, "R is NULL");
+    TBK_ARG(n_r == 0 || R != nullptr || k_rows_per_r == 1, "R is NULL");  // k.p rows carry no R
     TBK_CHECK(require_device(device));
 
     tbk_model* m = new (std::nothrow) tbk_model();
@@ -131,6 +132,13 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     } while (0)
 
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)));
+    TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_eig, hipStreamNonBlocking)));
+    TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_ql, hipStreamNonBlocking)));
+    for (int b = 0; b < 2; ++b) {
+        TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_hk[b], hipEventDisableTiming)));
+        TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_tri[b], hipEventDisableTiming)));
+        TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_ql[b], hipEventDisableTiming)));
+    }
     TBK_TRY(TBK_ROCBLAS(rocblas_create_handle(&m->blas)));
     TBK_TRY(TBK_ROCBLAS(rocblas_set_stream(m->blas, m->stream)));
     TBK_TRY(TBK_CHECK(m->ws_flag.reserve(2 * sizeof(int))));
@@ -257,18 +265,26 @@ extern "C" int tbk_model_create_csr(int device, int dim, int n_orb, int64_t n_r,
 extern "C" void tbk_model_destroy(tbk_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    hipStream_t streams[] = {m->stream, m->stream_eig, m->stream_ql};
+    for (hipStream_t st : streams)
+        if (st) (void)hipStreamSynchronize(st);
+    for (int b = 0; b < 2; ++b) {
+        if (m->ev_hk[b]) (void)hipEventDestroy(m->ev_hk[b]);
+        if (m->ev_tri[b]) (void)hipEventDestroy(m->ev_tri[b]);
+        if (m->ev_ql[b]) (void)hipEventDestroy(m->ev_ql[b]);
+    }
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.start);
         (void)hipEventDestroy(ev.stop);
     }
     if (m->blas) (void)rocblas_destroy_handle(m->blas);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (hipStream_t st : streams)
+        if (st) (void)hipStreamDestroy(st);
     void* ptrs[] = {m->d_R, m->d_colmap, m->d_B, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_powers};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E, &m->ws_info, &m->ws_k,
-                      &m->ws_pos,   &m->ws_out, &m->ws_flag};
+    DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_H2, &m->ws_E,   &m->ws_E2,
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag};
     for (DevBuf* b : bufs) b->release();
     delete m;
 }
@@ -357,12 +373,67 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
     return TBK_OK;
 }
 
+// Eigenvalues with the hand-written wave solver (n_orb <= 64), software-pipelined over k chunks on
+// three streams:   main: phase(c) -> H(c)      eig: tridiag(c)      ql: QL(c)
+// with two H buffers and two (d, e) buffers, so that the latency-bound QL of chunk c and the VALU-bound
+// reduction of chunk c run under the MFMA-bound H(k) contraction of chunk c+1.
+static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
+    const int64_t chunk = choose_chunk(m, nk, true);
+    const size_t n = (size_t)m->n_orb;
+    const size_t nn2 = n * n * 2;
+    DevBuf* hbuf[2] = {&m->ws_H, &m->ws_H2};
+    DevBuf* debuf[2] = {&m->ws_E, &m->ws_E2};
+    const int64_t n_chunks = (nk + chunk - 1) / chunk;
+    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) {
+        TBK_CHECK(hbuf[b]->reserve((size_t)std::min(chunk, nk) * nn2 * sizeof(double)));
+        TBK_CHECK(debuf[b]->reserve((size_t)std::min(chunk, nk) * n * 2 * sizeof(double)));
+    }
+    // the caller's previous work on the main stream (k upload, earlier calls) precedes everything
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int b = (int)(c & 1);
+        const int64_t c0 = c * chunk;
+        const int64_t nkc = std::min(chunk, nk - c0);
+        const int64_t nk_pad = round_up(nkc, TBK_BM);
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        double* d_A = m->ws_phase.as<double>();
+        double* d_H = hbuf[b]->as<double>();
+        double* d_de = debuf[b]->as<double>();
+        const double* kc = d_k + c0 * m->dim;
+        if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b], 0));  // H[b] free again
+        TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
+        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H));
+        TBK_HIP(hipEventRecord(m->ev_hk[b], m->stream));
+
+        TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_hk[b], 0));
+        if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_ql[b], 0));  // (d, e)[b] free again
+        TBK_CHECK(tbk_launch_tridiag(m, m->stream_eig, d_H, nkc, d_de));
+        TBK_HIP(hipEventRecord(m->ev_tri[b], m->stream_eig));
+
+        TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b], 0));
+        TBK_CHECK(tbk_launch_ql(m, m->stream_ql, d_de, nkc, d_E + (size_t)c0 * n));
+        TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_ql));
+    }
+    // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues
+    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) {
+        TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b], 0));
+        TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
+    }
+    return TBK_OK;
+}
+
 extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
     TBK_ARG(m != nullptr, "model is NULL");
     TBK_ARG(nk >= 0, "nk < 0");
     if (nk == 0) return TBK_OK;
     TBK_ARG(d_k && d_E, "k / E is NULL");
     TBK_HIP(hipSetDevice(m->device));
+    if (m->eigensolver == TBK_EIG_WAVE && !tbk_eig_small_supported(m->n_orb)) {
+        tbk_set_error("TBK_EIG_WAVE handles n_orb <= 64 only (n_orb = %d)", m->n_orb);
+        return TBK_ERR_ARGUMENT;
+    }
+    if (m->eigensolver != TBK_EIG_ROCSOLVER && tbk_eig_small_supported(m->n_orb))
+        return eigenval_wave_pipeline(m, d_k, nk, d_E);
+
     const int64_t chunk = choose_chunk(m, nk, true);
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
     for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
@@ -558,6 +629,8 @@ extern "C" int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int r
     TBK_ARG(m != nullptr, "model is NULL");
     TBK_HIP(hipSetDevice(m->device));
     TBK_HIP(hipStreamSynchronize(m->stream));
+    TBK_HIP(hipStreamSynchronize(m->stream_eig));
+    TBK_HIP(hipStreamSynchronize(m->stream_ql));
     for (auto& ev : m->events) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, ev.start, ev.stop) == hipSuccess) {

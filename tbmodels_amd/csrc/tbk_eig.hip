@@ -22,7 +22,7 @@ __global__ void count_info_kernel(const int* __restrict__ info, int64_t n, int* 
 }  // namespace
 
 size_t tbk_eig_scratch_per_k(const tbk_model* m) {
-    return (size_t)m->n_orb * sizeof(double) + sizeof(int);
+    return (size_t)m->n_orb * 2 * sizeof(double) + sizeof(int);
 }
 
 int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E) {

@@ -115,11 +115,18 @@ struct tbk_model {
     bool timing = false;
 
     // --- runtime ---
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // phase rows, H(k), rocSOLVER, collectives
+    hipStream_t stream_eig = nullptr;  // wave eigensolver: reduction to tridiagonal form
+    hipStream_t stream_ql = nullptr;   // wave eigensolver: tridiagonal QL (latency-bound, overlaps the rest)
+    hipEvent_t ev_hk[2] = {nullptr, nullptr};   // H[buf] written
+    hipEvent_t ev_tri[2] = {nullptr, nullptr};  // H[buf] consumed, (d, e)[buf] written
+    hipEvent_t ev_ql[2] = {nullptr, nullptr};   // (d, e)[buf] consumed, eigenvalues written
     rocblas_handle blas = nullptr;
     DevBuf ws_phase;  // [K2][nk_pad] cos/sin rows
     DevBuf ws_H;      // [chunk][n_orb][n_orb] complex
-    DevBuf ws_E;      // [chunk][n_orb] rocSOLVER off-diagonal scratch
+    DevBuf ws_H2;     // second H buffer of the pipelined wave eigensolver
+    DevBuf ws_E;      // rocSOLVER: [chunk][n_orb] off-diagonal scratch; wave solver: (d, e) of buffer 0
+    DevBuf ws_E2;     // wave solver: (d, e) of buffer 1
     DevBuf ws_info;   // [chunk] int
     DevBuf ws_k;      // host-entry staging of k / pos / E
     DevBuf ws_pos;
@@ -139,7 +146,8 @@ struct StageTimer {
     tbk_model* m;
     EventPair ev;
     bool on;
-    StageTimer(tbk_model* m_, int stage);
+    hipStream_t stream;
+    StageTimer(tbk_model* m_, int stage, hipStream_t s = nullptr);
     ~StageTimer();
 };
 
@@ -169,6 +177,11 @@ int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
 // tbk_eig.hip
 int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);
 size_t tbk_eig_scratch_per_k(const tbk_model* m);
+
+// tbk_eig_small.hip
+bool tbk_eig_small_supported(int n);
+int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t nk, double* d_de);
+int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E);
 
 // tbk_peak.hip
 int tbk_run_mfma_f64_peak(double* tflops);

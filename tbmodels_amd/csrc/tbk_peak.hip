@@ -4,6 +4,8 @@
 // 78.6 TFLOP/s.  bench.py reports both the spec and what this loop sustains on the device it runs
 // on, so roofline fractions can be read against either.
 
+#include <cstdlib>
+
 #include "tbk_internal.h"
 
 namespace {
@@ -14,7 +16,8 @@ __global__ void __launch_bounds__(256) mfma_f64_loop(double* out, int iters, dou
     d4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    double a = seed == 0.0 ? 0.0 : seed + threadIdx.x * 1e-3;
+    double b = seed == 0.0 ? 0.0 : seed - threadIdx.x * 1e-3;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -33,24 +36,37 @@ int tbk_run_mfma_f64_peak(double* tflops) {
     int dev = 0;
     TBK_HIP(hipGetDevice(&dev));
     TBK_HIP(hipGetDeviceProperties(&prop, dev));
-    const int grid = prop.multiProcessorCount * 4;
     const int iters = 4000;
+    const bool verbose = getenv("TBK_VERBOSE") != nullptr;
     double* d_out = nullptr;
-    TBK_HIP(hipMalloc((void**)&d_out, (size_t)grid * 256 * sizeof(double)));
+    TBK_HIP(hipMalloc((void**)&d_out, (size_t)prop.multiProcessorCount * 4 * 256 * sizeof(double)));
     hipEvent_t e0, e1;
     TBK_HIP(hipEventCreate(&e0));
     TBK_HIP(hipEventCreate(&e1));
     double best = 0.0;
-    for (int rep = 0; rep < 4; ++rep) {
-        TBK_HIP(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(mfma_f64_loop, dim3(grid), dim3(256), 0, 0, d_out, iters, 1.0 + rep);
-        TBK_HIP(hipEventRecord(e1, 0));
-        TBK_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        TBK_HIP(hipEventElapsedTime(&ms, e0, e1));
-        const double flops = (double)grid * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
-        const double tf = flops / (ms * 1e-3) / 1e12;
-        if (rep > 0 && tf > best) best = tf;
+    // waves per SIMD x {non-trivial operands, all-zero operands}: the chip clocks to its power budget, so
+    // the sustained rate depends on both (MI355X_MICROARCH.md, DVFS give-back)
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        const int grid = prop.multiProcessorCount * wps;
+        for (int zero = 0; zero < 2; ++zero) {
+            double best_cfg = 0.0;
+            for (int rep = 0; rep < 3; ++rep) {
+                TBK_HIP(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(mfma_f64_loop, dim3(grid), dim3(256), 0, 0, d_out, iters,
+                                   zero ? 0.0 : 1.0 + rep);
+                TBK_HIP(hipEventRecord(e1, 0));
+                TBK_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                TBK_HIP(hipEventElapsedTime(&ms, e0, e1));
+                const double flops = (double)grid * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
+                const double tf = flops / (ms * 1e-3) / 1e12;
+                if (rep > 0 && tf > best_cfg) best_cfg = tf;
+            }
+            if (verbose)
+                fprintf(stderr, "[tbk] mfma_f64 loop: %d waves/SIMD, %s operands: %.2f TFLOP/s\n", wps,
+                        zero ? "zero" : "non-zero", best_cfg);
+            if (!zero && best_cfg > best) best = best_cfg;
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

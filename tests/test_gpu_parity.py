@@ -205,3 +205,59 @@ def test_periodicity_and_linearity_properties():
     eig = np.array(model.eigenval(k))
     assert np.all(np.diff(eig, axis=1) >= 0)  # ascending, like eigvalsh
     _close(eig.sum(axis=1), np.trace(h0, axis1=1, axis2=2).real, 1e-10)
+
+
+def _onsite_model(mat):
+    """A model whose H(k) is the constant Hermitian matrix `mat` (R = 0 block stored halved)."""
+    mat = np.asarray(mat, dtype=complex)
+    return tbmodels_amd.Model(hop={(0, 0, 0): mat / 2}, size=len(mat), dim=3, contains_cc=False)
+
+
+@pytest.mark.parametrize("solver", ["wave", "rocsolver"])
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 9, 16, 17, 32, 33, 63, 64])
+def test_eigensolver_structured_matrices(solver, n):
+    """Both eigensolvers on matrices that stress deflation: diagonal, degenerate, block, graded, random."""
+    from tbmodels_amd import _lib
+
+    rng = np.random.default_rng(100 + n)
+    rand = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    rand = (rand + rand.conj().T) / 2
+    cases = {
+        "diagonal": np.diag(rng.standard_normal(n)).astype(complex),
+        "identity": np.eye(n, dtype=complex) * 0.75,
+        "random": rand,
+        "graded": rand * np.outer(10.0 ** -np.arange(n) / max(1, n // 8), np.ones(n)),
+        "imag_offdiag": np.diag(np.arange(n, dtype=float)) + 1j * (np.eye(n, k=1) - np.eye(n, k=-1)),
+    }
+    cases["graded"] = (cases["graded"] + cases["graded"].conj().T) / 2
+    if n >= 4:
+        blk = np.zeros((n, n), dtype=complex)
+        h = n // 2
+        blk[:h, :h] = rand[:h, :h]
+        blk[h:, h:] = rand[:n - h, :n - h]
+        cases["two_equal_blocks"] = blk
+        proj = np.outer(rand[:, 0], rand[:, 0].conj())
+        cases["rank_one"] = proj
+    code = {"wave": _lib.TBK_EIG_WAVE, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[solver]
+    for name, mat in cases.items():
+        model = _onsite_model(mat)
+        if not model.hop:  # all-zero matrices are dropped, like the reference
+            continue
+        model.set_option(_lib.TBK_OPT_EIGENSOLVER, code)
+        eig = np.array(model.eigenval([[0.1, 0.2, 0.3], [0.0, 0.0, 0.0]]))
+        ref = np.linalg.eigvalsh(mat)
+        err = np.abs(eig - ref[None]).max()
+        assert err <= 1e-12 * max(1.0, np.abs(ref).max()) * n, (name, err)
+
+
+def test_wave_solver_rejects_large_n():
+    from tbmodels_amd import _lib
+
+    r_vec, hop, pos = syn.dense_model_arrays(80, 3, syn.MODEL_SEED + 5)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.set_option(_lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_WAVE)
+    with pytest.raises(ValueError):
+        model.eigenval([0.1, 0.2, 0.3])
+    model.set_option(_lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_AUTO)  # falls back to rocSOLVER above 64
+    k = syn.random_kpoints(5)
+    _close(np.array(model.eigenval(k)), np.array(oracle.eigenval(r_vec, hop, k)))
