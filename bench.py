@@ -11,9 +11,11 @@ holds the same staged model and evaluates its own contiguous slab of an N x 100k
 scaling, per-GPU work fixed), followed by the RCCL all-gather of eigenvalue slabs inside the timed
 region.  k-points and eigenvalues are resident in HBM when the clock starts.
 
-Host side: Python + ctypes -> libtbk.so (include/tbk.h).  torch is imported only for N>1, and only
-as the rendezvous the driver's launcher expects (torch.distributed, gloo): barrier, max-over-ranks
-and handing the RCCL unique id to the ranks.  The data path never touches torch.
+Host side: Python + ctypes -> libtbk.so (include/tbk.h), no torch in the process: the torch wheel
+bundles its own ROCm runtime, and a second runtime build next to the system one that libtbk links
+crashes at import.  ``python -m torch.distributed.run`` is only the launcher (it sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*); barrier, max-over-ranks and handing the RCCL unique id to the ranks go through
+``tbmodels_amd.rendezvous.FileGroup`` (single node).  The eigenvalue all-gather is RCCL.
 
 Rank 0 prints ONE JSON line with the contract fields plus ``roofline`` (the H(k) MFMA kernel, timed
 with HIP events on the library's stream) and ``cpu_baseline`` (the oracle = port of the reference's
@@ -35,6 +37,7 @@ if ROOT not in sys.path:
 
 # load libtbk (system ROCm runtime) before anything else can pull in another copy of the runtime
 from tbmodels_amd import _lib, synthetic  # noqa: E402  pylint: disable=wrong-import-position
+from tbmodels_amd.rendezvous import group_from_env  # noqa: E402  pylint: disable=wrong-import-position
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD public spec for MI355X (vector = matrix FP64); see DESIGN.md
 
@@ -122,12 +125,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: libtbk has no CPU path")
     device = local_rank % _lib.device_count()
 
-    dist = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    group = group_from_env() if world > 1 else None
 
     kind, n_orb, n_r, nk_gpu, cfg_idx = CONFIGS[args.config]
     if args.nk:
@@ -169,17 +167,34 @@ def main():
         d_h = dmalloc(nk_gpu * n_orb * n_orb * 16)
     d_gather = None
     comm = None
-    if world > 1:
+    collective = "none"
+    host_gather = None
+    force_comm = os.environ.get("TBK_BENCH_FORCE_COMM") == "1"  # exercise RCCL with a 1-rank communicator
+    if world > 1 or force_comm:
         d_gather = dmalloc(world * e_count * 8)
         uid = np.zeros(128, dtype=np.uint8)
         if rank == 0:
             _lib.check(lib.tbk_comm_unique_id(_lib.ptr(uid)))
-        import torch  # pylint: disable=import-outside-toplevel
-
-        t_uid = torch.from_numpy(uid)
-        dist.broadcast(t_uid, src=0)
+        if group is not None:
+            uid = np.frombuffer(group.broadcast_bytes(uid.tobytes(), src=0), dtype=np.uint8).copy()
         comm = ctypes.c_void_p()
-        _lib.check(lib.tbk_comm_create(device, world, rank, _lib.ptr(uid), ctypes.byref(comm)))
+        status = lib.tbk_comm_create(device, world, rank, _lib.ptr(uid), ctypes.byref(comm))
+        all_ok = (status == 0) if group is None else group.allreduce_min(1.0 if status == 0 else 0.0) == 1.0
+        if all_ok:
+            collective = "rccl all-gather (xGMI), device buffers"
+        else:
+            # e.g. several ranks sharing one GPU: RCCL refuses; gather on the host instead and say so
+            sys.stderr.write("[bench] RCCL communicator unavailable (%s); falling back to a host all-gather\n"
+                             % _lib.last_error())
+            if status == 0:
+                lib.tbk_comm_destroy(comm)
+            comm = None
+            collective = "host all-gather (RCCL unavailable)"
+            h_slab = np.empty((nk_gpu, n_orb))
+
+            def host_gather():
+                _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(h_slab), d_e, h_slab.nbytes))
+                group.all_gather_array(h_slab)
 
     def step():
         if args.construct_only:
@@ -188,11 +203,14 @@ def main():
         _lib.check(lib.tbk_eigenval_device(model, d_k, nk_gpu, d_e))
         if comm is not None:
             _lib.check(lib.tbk_comm_allgather_f64(comm, model, d_e, d_gather, e_count))
+        elif host_gather is not None:
+            _lib.check(lib.tbk_synchronize(model))
+            host_gather()
 
     def barrier():
         _lib.check(lib.tbk_synchronize(model))
-        if dist is not None:
-            dist.barrier()
+        if group is not None:
+            group.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -210,12 +228,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch  # pylint: disable=import-outside-toplevel
-
-        t_el = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        elapsed = float(t_el.item())
+    if group is not None:
+        elapsed = group.allreduce_max(elapsed)
     if not args.construct_only:
         _lib.check(lib.tbk_eigenval_check(model))
     _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
@@ -296,8 +310,9 @@ def main():
                             % (args.config, arrays["kind"], n_orb, n_r, nk_gpu,
                                "grid" if args.config == "cfg1" else "random"),
                 "kpoints_per_gpu": nk_gpu,
-                "sharding": "contiguous k slabs, hoppings replicated, RCCL all-gather of eigenvalues" if world > 1
+                "sharding": "contiguous k slabs, hoppings replicated, all-gather of eigenvalue slabs" if world > 1
                             else "single GPU",
+                "collective": collective,
                 "eigensolver": args.eigensolver,
             },
             "roofline": roofline,
@@ -310,9 +325,8 @@ def main():
     if comm is not None:
         lib.tbk_comm_destroy(comm)
     lib.tbk_model_destroy(model)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.close()
     if rank == 0 and result and result.get("max_abs_err_vs_oracle") is not None:
         if result["max_abs_err_vs_oracle"] > 1e-10:
             raise SystemExit("parity failure: max|dE| = %g" % result["max_abs_err_vs_oracle"])

@@ -1,0 +1,163 @@
+"""
+Process groups for the sharded path: the few host-side collectives it needs (rank / world, barrier,
+broadcast of the 128-byte RCCL id, max-reduce of a timing, host all-gather for GPU-less runs).
+
+Two implementations of one small interface (``rank``, ``world``, ``barrier()``, ``broadcast_bytes()``,
+``allreduce_max()``, ``all_gather_array()``):
+
+``FileGroup``   torch-free, single node: a directory of atomically renamed files.  This is what
+                ``bench.py`` uses under ``python -m torch.distributed.run`` (which only has to set
+                RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT): importing torch next to libtbk would put a
+                second ROCm runtime build into the process (the wheel bundles its own), which crashes
+                when the system runtime is already loaded.
+``TorchGroup``  adapter over an initialised ``torch.distributed`` (gloo or nccl) for callers that live
+                in a torch process anyway; import torch BEFORE the first ``tbmodels_amd`` GPU call there.
+
+The data path (eigenvalue slabs) never goes through these on a GPU box: it is the RCCL all-gather of
+``tbk_comm_allgather_f64``.
+"""
+
+import os
+import shutil
+import time
+
+import numpy as np
+
+__all__ = ("FileGroup", "TorchGroup", "group_from_env")
+
+
+class FileGroup:
+    """Single-node process group backed by a shared directory (``/dev/shm`` when available)."""
+
+    def __init__(self, rank, world, path, poll_s=2e-4, timeout_s=600.0):
+        self.rank = int(rank)
+        self.world = int(world)
+        self.path = path
+        self.poll_s = poll_s
+        self.timeout_s = timeout_s
+        self._seq = 0
+        os.makedirs(path, exist_ok=True)
+
+    # -- primitives ---------------------------------------------------------------------------
+    def _put(self, name, data):
+        tmp = os.path.join(self.path, ".%s.%d.tmp" % (name, self.rank))
+        with open(tmp, "wb") as handle:
+            handle.write(data)
+        os.replace(tmp, os.path.join(self.path, name))  # atomic: readers never see a partial file
+
+    def _get(self, name):
+        target = os.path.join(self.path, name)
+        deadline = time.monotonic() + self.timeout_s
+        while True:
+            try:
+                with open(target, "rb") as handle:
+                    return handle.read()
+            except FileNotFoundError:
+                if time.monotonic() > deadline:
+                    raise TimeoutError("rendezvous: waited %.0f s for %s" % (self.timeout_s, target))
+                time.sleep(self.poll_s)
+
+    def _next(self, tag):
+        self._seq += 1
+        return "%s.%06d" % (tag, self._seq)
+
+    # -- collectives --------------------------------------------------------------------------
+    def all_gather_bytes(self, data):
+        """Every rank contributes ``data``; returns the list of all contributions in rank order."""
+        key = self._next("ag")
+        self._put("%s.r%d" % (key, self.rank), bytes(data))
+        return [self._get("%s.r%d" % (key, r)) for r in range(self.world)]
+
+    def barrier(self):
+        self.all_gather_bytes(b"\x01")
+
+    def broadcast_bytes(self, data, src=0):
+        key = self._next("bc")
+        if self.rank == src:
+            self._put(key, bytes(data))
+            return bytes(data)
+        return self._get(key)
+
+    def allreduce_max(self, value):
+        parts = self.all_gather_bytes(np.float64(value).tobytes())
+        return float(max(np.frombuffer(p, dtype=np.float64)[0] for p in parts))
+
+    def allreduce_min(self, value):
+        parts = self.all_gather_bytes(np.float64(value).tobytes())
+        return float(min(np.frombuffer(p, dtype=np.float64)[0] for p in parts))
+
+    def all_gather_array(self, array):
+        """All-gather of equally shaped float64 arrays; returns a list of arrays in rank order."""
+        array = np.ascontiguousarray(array, dtype=np.float64)
+        parts = self.all_gather_bytes(array.tobytes())
+        return [np.frombuffer(p, dtype=np.float64).reshape(array.shape) for p in parts]
+
+    def close(self):
+        """Final barrier; rank 0 removes the directory once every other rank has said it is done reading."""
+        self.barrier()
+        if self.rank != 0:
+            self._put("bye.r%d" % self.rank, b"\x01")
+            return
+        for r in range(1, self.world):
+            self._get("bye.r%d" % r)
+        shutil.rmtree(self.path, ignore_errors=True)
+
+
+class TorchGroup:
+    """The same interface over ``torch.distributed`` (CPU tensors; works with gloo and nccl groups)."""
+
+    def __init__(self, dist):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        self._torch = torch
+        self._dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def broadcast_bytes(self, data, src=0):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        tensor = self._torch.from_numpy(buf)
+        self._dist.broadcast(tensor, src=src)
+        return buf.tobytes()
+
+    def _reduce(self, value, op):
+        tensor = self._torch.tensor([float(value)], dtype=self._torch.float64)
+        self._dist.all_reduce(tensor, op=op)
+        return float(tensor.item())
+
+    def allreduce_max(self, value):
+        return self._reduce(value, self._dist.ReduceOp.MAX)
+
+    def allreduce_min(self, value):
+        return self._reduce(value, self._dist.ReduceOp.MIN)
+
+    def all_gather_array(self, array):
+        array = np.ascontiguousarray(array, dtype=np.float64)
+        pieces = [self._torch.zeros(array.shape, dtype=self._torch.float64) for _ in range(self.world)]
+        self._dist.all_gather(pieces, self._torch.from_numpy(array))
+        return [p.numpy() for p in pieces]
+
+    def close(self):
+        self.barrier()
+
+
+def group_from_env():
+    """
+    The :class:`FileGroup` of a ``torch.distributed.run`` / ``torchrun`` launch on one node: ranks from
+    RANK / WORLD_SIZE, directory keyed by MASTER_PORT and the launcher's pid (all workers share one parent).
+    ``TBK_RDZV_DIR`` overrides the directory.
+    """
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    path = os.environ.get("TBK_RDZV_DIR")
+    if not path:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        path = os.path.join(
+            base,
+            "tbk_rdzv_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"),
+                                   os.getppid()),
+        )
+    return FileGroup(rank, world, path)

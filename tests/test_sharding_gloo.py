@@ -1,0 +1,95 @@
+"""
+The N > 1 path on CPU: world_size-2 ``gloo`` process group, contiguous k slabs, all-gather of
+eigenvalue slabs, result in caller order on every rank.  The per-rank evaluator is the oracle here
+(no GPU in this suite); on a GPU box the same class evaluates slabs through libtbk and gathers over RCCL.
+"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tbmodels_amd.sharding import slab_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slab_bounds_cover_and_order():
+    for n_k in (0, 1, 2, 7, 8, 9, 1000, 100_000):
+        for world in (1, 2, 3, 4, 8):
+            edges = [slab_bounds(n_k, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n_k
+            for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+                assert a1 == b0 and a0 <= a1 and b0 <= b1
+            per = -(-n_k // world)
+            assert all(hi - lo <= per for lo, hi in edges)
+
+
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _worker(rank, world, port, n_k, out_dir, backend="gloo"):
+    sys.path.insert(0, ROOT)
+    import tbmodels_amd
+    from tbmodels_amd import synthetic as syn
+    from tbmodels_amd.sharding import ShardedEigenval
+    from oracle import tbk_oracle as oracle
+
+    if backend == "gloo":
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        group = dist
+    else:
+        from tbmodels_amd.rendezvous import FileGroup
+
+        group = FileGroup(rank, world, os.path.join(out_dir, "rdzv"))
+    r_vec, hop, pos = syn.dense_model_arrays(6, 10, syn.MODEL_SEED + 42)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    calls = []
+
+    def evaluate(k_slab):
+        calls.append(len(k_slab))
+        return np.array(oracle.eigenval(r_vec, hop, k_slab))
+
+    sharded = ShardedEigenval(model, group, device=None, evaluate=evaluate)
+    k = syn.random_kpoints(n_k)
+    result = sharded(k)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), result)
+    np.save(os.path.join(out_dir, "calls%d.npy" % rank), np.array(calls))
+    if backend == "gloo":
+        group.barrier()
+        group.destroy_process_group()
+    else:
+        assert sharded.group.allreduce_max(float(rank)) == world - 1
+        assert sharded.group.broadcast_bytes(b"id-%d" % rank, src=1) == b"id-1"
+        sharded.group.close()
+
+
+@pytest.mark.parametrize("backend,n_k", [("gloo", 11), ("gloo", 64), ("gloo", 1), ("file", 11), ("file", 2)])
+def test_world_size_2_allgather(tmp_path, backend, n_k):
+    import torch.multiprocessing as mp
+
+    from tbmodels_amd import synthetic as syn
+    from oracle import tbk_oracle as oracle
+
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_k, str(tmp_path), backend), nprocs=world, join=True)
+    r_vec, hop, _ = syn.dense_model_arrays(6, 10, syn.MODEL_SEED + 42)
+    expected = np.array(oracle.eigenval(r_vec, hop, syn.random_kpoints(n_k)))
+    total_calls = 0
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
+        assert got.shape == expected.shape
+        assert np.abs(got - expected).max() < 1e-13  # every rank holds the full, ordered result
+        calls = np.load(os.path.join(str(tmp_path), "calls%d.npy" % rank))
+        lo, hi = slab_bounds(n_k, world, rank)
+        assert calls.sum() == hi - lo  # each rank evaluated exactly its slab
+        total_calls += calls.sum()
+    assert total_calls == n_k
