@@ -73,14 +73,22 @@ def _worker(rank, world, port, n_k, out_dir, backend="gloo"):
 
 @pytest.mark.parametrize("backend,n_k", [("gloo", 11), ("gloo", 64), ("gloo", 1), ("file", 11), ("file", 2)])
 def test_world_size_2_allgather(tmp_path, backend, n_k):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
 
     from tbmodels_amd import synthetic as syn
     from oracle import tbk_oracle as oracle
 
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n_k, str(tmp_path), backend), nprocs=world, join=True)
+    # fresh interpreters: torch (gloo) is imported only inside the workers -- never in this process,
+    # which may already hold libtbk and its system ROCm runtime (see tbmodels_amd/rendezvous.py)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(rank, world, port, n_k, str(tmp_path), backend)) for rank in range(world)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(timeout=300)
+        assert proc.exitcode == 0, "worker exited with %r" % proc.exitcode
     r_vec, hop, _ = syn.dense_model_arrays(6, 10, syn.MODEL_SEED + 42)
     expected = np.array(oracle.eigenval(r_vec, hop, syn.random_kpoints(n_k)))
     total_calls = 0
