@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -374,21 +375,25 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 }
 
 // Eigenvalues with the hand-written wave solver (n_orb <= 64), software-pipelined over k chunks on
-// three streams:   main: phase(c) -> H(c)      eig: tridiag(c)      ql: QL(c)
-// with two H buffers and two (d, e) buffers, so that the latency-bound QL of chunk c and the VALU-bound
-// reduction of chunk c run under the MFMA-bound H(k) contraction of chunk c+1.
+// three streams:   main: phase(c) -> H(c)      eig: tridiag(c)      ql: QL(c - 1)
+//
+//     | H(c) | tridiag(c) || QL(c-1) | H(c+1) | tridiag(c+1) || QL(c) | ...
+//
+// The MFMA contraction runs alone: it fills the LDS (2 x 72 KiB per CU), so anything co-scheduled with
+// it only displaces its workgroups.  The two eigensolver kernels are complementary -- the reduction is
+// VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
+// workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
 static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
     const int64_t chunk = choose_chunk(m, nk, true);
     const size_t n = (size_t)m->n_orb;
     const size_t nn2 = n * n * 2;
-    DevBuf* hbuf[2] = {&m->ws_H, &m->ws_H2};
     DevBuf* debuf[2] = {&m->ws_E, &m->ws_E2};
     const int64_t n_chunks = (nk + chunk - 1) / chunk;
-    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) {
-        TBK_CHECK(hbuf[b]->reserve((size_t)std::min(chunk, nk) * nn2 * sizeof(double)));
+    TBK_CHECK(m->ws_H.reserve((size_t)std::min(chunk, nk) * nn2 * sizeof(double)));
+    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)std::min(chunk, nk) * n * 2 * sizeof(double)));
-    }
-    // the caller's previous work on the main stream (k upload, earlier calls) precedes everything
+    double* d_H = m->ws_H.as<double>();
+    int64_t prev_c0 = 0, prev_nkc = 0;
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int b = (int)(c & 1);
         const int64_t c0 = c * chunk;
@@ -396,28 +401,39 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         const int64_t nk_pad = round_up(nkc, TBK_BM);
         TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();
-        double* d_H = hbuf[b]->as<double>();
         double* d_de = debuf[b]->as<double>();
         const double* kc = d_k + c0 * m->dim;
-        if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b], 0));  // H[b] free again
+        if (c >= 1) {
+            // H(c) overwrites the single H buffer and must not share the chip with the eigensolver
+            TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b ^ 1], 0));
+            if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
+        }
         TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
         TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H));
         TBK_HIP(hipEventRecord(m->ev_hk[b], m->stream));
 
         TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_hk[b], 0));
-        if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_ql[b], 0));  // (d, e)[b] free again
         TBK_CHECK(tbk_launch_tridiag(m, m->stream_eig, d_H, nkc, d_de));
         TBK_HIP(hipEventRecord(m->ev_tri[b], m->stream_eig));
 
+        if (c >= 1) {  // QL of the previous chunk, alongside this chunk's reduction
+            TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
+            TBK_CHECK(tbk_launch_ql(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
+                                    d_E + (size_t)prev_c0 * n));
+            TBK_HIP(hipEventRecord(m->ev_ql[b ^ 1], m->stream_ql));
+        }
+        prev_c0 = c0;
+        prev_nkc = nkc;
+    }
+    {  // QL of the last chunk
+        const int b = (int)((n_chunks - 1) & 1);
         TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b], 0));
-        TBK_CHECK(tbk_launch_ql(m, m->stream_ql, d_de, nkc, d_E + (size_t)c0 * n));
+        TBK_CHECK(tbk_launch_ql(m, m->stream_ql, debuf[b]->as<double>(), prev_nkc, d_E + (size_t)prev_c0 * n));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_ql));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues
-    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) {
-        TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b], 0));
-        TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
-    }
+    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
+    TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[(n_chunks - 1) & 1], 0));
     return TBK_OK;
 }
 

@@ -20,15 +20,42 @@
 // lane), ~0.3 Mflop in kernel 2; H is read once (16 n^2 B), eigenvalues written once (8 n B).
 // Accuracy: backward stable, |dE| ~ n eps ||H||; the parity tests hold it to 1e-10 absolute.
 
+#include <cstdlib>
+
 #include "tbk_internal.h"
 
 namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// 64-lane all-reduce without LDS: rotate-adds inside each row of 16 lanes (DPP row_ror), then the two
+// gfx950 row / half swaps.  Every lane ends with the bitwise-identical sum (each stage adds a commutative
+// pair), which the wave-uniform branches on the result rely on.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
     return v;
 }
 
@@ -231,6 +258,168 @@ herm_tridiag_kernel(const double* __restrict__ H, int n, double* __restrict__ D,
 }
 
 // ------------------------------------------------------------------------------------------------
+// kernel 1b: the same reduction with FOUR waves per matrix (256 threads): wave q holds columns
+// c = 4 t + q of every row (16 complex = 64 VGPRs per lane instead of 256), so the kernel fits
+// beside the MFMA contraction's waves on a SIMD and its f64 VALU work runs in the shadow of their
+// matrix-pipe time.  Per Householder step the four waves exchange two things through LDS -- the new
+// column x (written by the wave that owns column j) and their partial products A v -- at the cost of
+// two workgroup barriers; v and w are recomputed by every wave (each has all rows) and broadcast
+// from a wave-private LDS copy, which needs no barrier.
+// ------------------------------------------------------------------------------------------------
+template <int NR>
+__global__ void __launch_bounds__(256)
+herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
+    constexpr int NW = 4;        // waves per matrix
+    constexpr int NT = NR / NW;  // columns per lane
+    __shared__ d2 sx[2][NR];     // Householder column of step j (double-buffered across steps)
+    __shared__ d2 sp[NW][NR];    // per-wave partial products
+    __shared__ d2 sv[NW][NR];    // per-wave copy of v
+    __shared__ d2 sw[NW][NR];    // per-wave copy of w
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t mat = blockIdx.x;
+    const double* Hm = H + mat * (size_t)n * n * 2;
+    double* Dm = D + mat * (size_t)n;
+    double* Em = E + mat * (size_t)n;
+
+    double ar[NT], ai[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = NW * t + q;
+        double re = 0.0, im = 0.0;
+        if (lane < n && c < n) {
+            if (c >= lane) {
+                const d2 v = *reinterpret_cast<const d2*>(Hm + ((size_t)lane * n + c) * 2);
+                re = v[0];
+                im = v[1];
+            } else {
+                const d2 v = *reinterpret_cast<const d2*>(Hm + ((size_t)c * n + lane) * 2);
+                re = v[0];
+                im = -v[1];
+            }
+        }
+        ar[t] = re;
+        ai[t] = im;
+    }
+    if (q == 0 && lane < NR) sx[0][lane] = (d2){ar[0], ai[0]};  // column 0 lives in wave 0, t = 0
+
+    for (int j = 0; j < n - 1; ++j) {
+        const int buf = j & 1;
+        __syncthreads();  // B1: sx[buf] = column j
+        const d2 xme = (lane < NR) ? sx[buf][lane] : (d2){0.0, 0.0};
+        const double xr = xme[0], xi = xme[1];
+        if (q == 0 && lane == j) Dm[j] = xr;
+        const d2 al = sx[buf][j + 1];
+        const double alr = al[0], ali = al[1];
+        const bool below = (lane > j + 1) && (lane < n);
+        const double sigma = wave_sum(below ? (xr * xr + xi * xi) : 0.0);
+
+        const int jn = j + 1;          // next column, owned by wave jn % 4 at local index jn / 4
+        const bool own_next = (jn & (NW - 1)) == q;
+        double nxr = 0.0, nxi = 0.0;
+        if (sigma == 0.0 && ali == 0.0) {
+            if (q == 0 && lane == 0) Em[j] = alr;
+            if (own_next) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t == jn / NW) {
+                        nxr = ar[t];
+                        nxi = ai[t];
+                    }
+                if (lane < NR) sx[buf ^ 1][lane] = (d2){nxr, nxi};
+            }
+            __syncthreads();  // keep the barrier count of both branches equal
+            continue;
+        }
+        const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
+        const double rbeta = 1.0 / beta;
+        const double tr = (beta - alr) * rbeta, ti = -ali * rbeta;
+        const double qr = alr - beta, qi = ali;
+        const double qn = 1.0 / (qr * qr + qi * qi);
+        const double scr = qr * qn, sci = -qi * qn;
+        if (q == 0 && lane == 0) Em[j] = beta;
+
+        double vr = 0.0, vi = 0.0;
+        if (below) {
+            vr = xr * scr - xi * sci;
+            vi = xr * sci + xi * scr;
+        } else if (lane == j + 1) {
+            vr = 1.0;
+        }
+        if (lane < NR) sv[q][lane] = (d2){vr, vi};  // wave-private: ordered by this wave's own LDS queue
+
+        // partial p = A v over this wave's columns
+        double par[2] = {0.0, 0.0}, pai[2] = {0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = NW * t + q;
+            if (NW * t + (NW - 1) > j) {  // uniform: any column of this group still active
+                const d2 vc = sv[q][c];
+                par[t & 1] = fma(ar[t], vc[0], par[t & 1]);
+                pai[t & 1] = fma(ar[t], vc[1], pai[t & 1]);
+                par[t & 1] = fma(-ai[t], vc[1], par[t & 1]);
+                pai[t & 1] = fma(ai[t], vc[0], pai[t & 1]);
+            }
+        }
+        if (lane < NR) sp[q][lane] = (d2){par[0] + par[1], pai[0] + pai[1]};
+        __syncthreads();  // B2: partial products of all four waves
+        double pr = 0.0, pi = 0.0;
+        if (lane > j && lane < n) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const d2 t = sp[w][lane];
+                pr += t[0];
+                pi += t[1];
+            }
+        }
+        {
+            const double t = pr * tr - pi * ti;
+            pi = pr * ti + pi * tr;
+            pr = t;
+        }
+        const double dr = wave_sum(pr * vr + pi * vi);
+        const double di = wave_sum(pr * vi - pi * vr);
+        const double a2r = -0.5 * (tr * dr - ti * di), a2i = -0.5 * (tr * di + ti * dr);
+        const double wr = pr + (a2r * vr - a2i * vi);
+        const double wi = pi + (a2r * vi + a2i * vr);
+        if (lane < NR) sw[q][lane] = (d2){wr, wi};
+
+        // A -= v w^H + w v^H on this wave's columns
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = NW * t + q;
+            if (NW * t + (NW - 1) > j) {
+                const d2 vc = sv[q][c];
+                const d2 wc = sw[q][c];
+                double r = ar[t], m = ai[t];
+                r = fma(-vr, wc[0], r);
+                m = fma(-vi, wc[0], m);
+                r = fma(-vi, wc[1], r);
+                m = fma(vr, wc[1], m);
+                r = fma(-wr, vc[0], r);
+                m = fma(-wi, vc[0], m);
+                r = fma(-wi, vc[1], r);
+                m = fma(wr, vc[1], m);
+                ar[t] = r;
+                ai[t] = m;
+            }
+        }
+        if (own_next) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t == jn / NW) {
+                    nxr = ar[t];
+                    nxi = ai[t];
+                }
+            if (lane < NR) sx[buf ^ 1][lane] = (d2){nxr, nxi};
+        }
+    }
+    __syncthreads();
+    if (q == 0 && lane == n - 1) Dm[n - 1] = sx[(n - 1) & 1][lane][0];
+    if (q == 0 && lane == 0) Em[n - 1] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel 2: implicit QL with Wilkinson shift on 64 tridiagonals per wave (one per lane)
 // ------------------------------------------------------------------------------------------------
 constexpr int QL_LD = 64;  // [index][lane]: a lane walks its own column, 8 B apart from its neighbours
@@ -334,6 +523,12 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
     const dim3 grid((unsigned)nk), block(64);
+    static const bool one_wave = getenv("TBK_TRIDIAG_1WAVE") != nullptr;  // A/B switch while tuning
+    if (n > 32 && !one_wave) {
+        hipLaunchKernelGGL(herm_tridiag4_kernel<64>, grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+        TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    }
     if (n <= 8)
         hipLaunchKernelGGL(herm_tridiag_kernel<8>, grid, block, 0, s, d_H, n, d_D, d_Eo);
     else if (n <= 16)

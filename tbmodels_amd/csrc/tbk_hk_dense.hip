@@ -14,8 +14,8 @@
 //     D[row = (lane >> 4) + 4 reg][col = lane & 15].
 //   * workgroup = 4 waves = 128 k-points x 64 packed elements (128 real columns); wave (wm, wn)
 //     owns 64 k-points x 32 elements = 4 x 2 x {re, im} = 16 accumulators (128 VGPRs).
-//   * K is walked in stages of 16 rows through double-buffered LDS: global -> registers (issued
-//     before the MFMAs of the current stage) -> LDS (after them), one barrier per stage.
+//   * K is walked in stages of 16 rows through double-buffered LDS, filled by LDS-DMA
+//     (global_load_lds_dwordx4) issued before the MFMAs of the current stage; one barrier per stage.
 //     LDS rows are padded by 16 doubles so that the two K rows a 32-lane group reads with
 //     ds_read_b64 fall in different halves of the 64-bank row: conflict-free.
 //   * both operands are K-major with the fast index contiguous, so every staging load is a
@@ -33,6 +33,8 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int LDA = TBK_BM + 16;       // doubles per K row of the A stage
 constexpr int LDB = 2 * TBK_BNP + 16;  // doubles per K row of the B stage
@@ -109,38 +111,31 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) acc[i][j][p] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    d2 ra[4], rb[4];
     const int n_stage = (int)(a.k2 / TBK_BK);
 
-    auto load_stage = [&](int s) {
+    // global -> LDS without a register round trip (global_load_lds_dwordx4): every wave-instruction
+    // copies one 1 KiB K row; the LDS destination is the wave-uniform row base + 16 B per lane, which is
+    // exactly the padded row layout.  No staging VGPRs: the kernel stays under 184 registers, so two of
+    // its workgroups leave room on every SIMD for a wave of the eigensolver's tridiagonalisation.
+    auto issue_stage = [&](int s, int buf) {
         const int64_t kk0 = (int64_t)s * TBK_BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t kk = kk0 + wave + 4 * i;
-            ra[i] = *reinterpret_cast<const d2*>(gA + kk * ldgA);
-            rb[i] = *reinterpret_cast<const d2*>(gB + kk * ldgB);
-        }
-    };
-    auto store_stage = [&](int buf) {
         double* sA = smem + buf * STAGE_DOUBLES;
         double* sB = sA + TBK_BK * LDA;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave + 4 * i;
-            *reinterpret_cast<d2*>(sA + row * LDA + lane * 2) = ra[i];
-            *reinterpret_cast<d2*>(sB + row * LDB + lane * 2) = rb[i];
+            const int64_t kk = kk0 + row;
+            __builtin_amdgcn_global_load_lds((gptr_t)(gA + kk * ldgA), (lptr_t)(sA + row * LDA), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gB + kk * ldgB), (lptr_t)(sB + row * LDB), 16, 0, 0);
         }
     };
 
-    if (n_stage > 0) {
-        load_stage(0);
-        store_stage(0);
-    }
-    __syncthreads();
+    if (n_stage > 0) issue_stage(0, 0);
+    __syncthreads();  // drains the LDS-DMA queue (vmcnt) before the barrier
 
     for (int s = 0; s < n_stage; ++s) {
         const int buf = s & 1;
-        if (s + 1 < n_stage) load_stage(s + 1);
+        if (s + 1 < n_stage) issue_stage(s + 1, buf ^ 1);  // lands during this stage's MFMAs
 
         const double* sA = smem + buf * STAGE_DOUBLES + wm * 64 + l15;
         const double* sB = smem + buf * STAGE_DOUBLES + TBK_BK * LDA + wn * 64 + l15;
@@ -163,9 +158,7 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                     acc[i][j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j][1], acc[i][j][1], 0, 0, 0);
                 }
         }
-
-        if (s + 1 < n_stage) store_stage(buf ^ 1);
-        __syncthreads();
+        __syncthreads();  // next stage has landed (vmcnt(0)) and everyone is done reading this one
     }
 
     // ---- epilogue: scatter the packed tile into H[k][i][j] (and H[k][j][i]) ----

@@ -29,14 +29,83 @@ __global__ void __launch_bounds__(256) mfma_f64_loop(double* out, int iters, dou
     if (s == 12345.678) out[blockIdx.x * blockDim.x + threadIdx.x] = s;  // keep the loop alive
 }
 
+__global__ void __launch_bounds__(256) fma_f64_loop(double* out, int iters, double seed) {
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = seed * (i + 1);
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-7;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fma(acc[i], a, b);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    if (s == 12345.678) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 }  // namespace
+
+// TBK_VERBOSE probe: does a VALU-f64 kernel run in the shadow of an MFMA-f64 kernel on the same SIMDs?
+static int overlap_probe(int cus, double* d_out) {
+    hipStream_t sa, sb;
+    TBK_HIP(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    TBK_HIP(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipEvent_t e0, e1, f0, f1;
+    TBK_HIP(hipEventCreate(&e0));
+    TBK_HIP(hipEventCreate(&e1));
+    TBK_HIP(hipEventCreate(&f0));
+    TBK_HIP(hipEventCreate(&f1));
+    const int it_m = 100000, it_f = 400000;
+    float ms_m = 0, ms_f = 0, ms_m2 = 0, ms_f2 = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int rep = 0; rep < 2; ++rep) {
+            TBK_HIP(hipDeviceSynchronize());
+            if (mode == 0) {  // each alone
+                TBK_HIP(hipEventRecord(e0, sa));
+                hipLaunchKernelGGL(mfma_f64_loop, dim3(cus * 2), dim3(256), 0, sa, d_out, it_m, 1.5);
+                TBK_HIP(hipEventRecord(e1, sa));
+                TBK_HIP(hipEventSynchronize(e1));
+                TBK_HIP(hipEventRecord(f0, sb));
+                hipLaunchKernelGGL(fma_f64_loop, dim3(cus), dim3(256), 0, sb, d_out, it_f, 1.5);
+                TBK_HIP(hipEventRecord(f1, sb));
+                TBK_HIP(hipEventSynchronize(f1));
+                TBK_HIP(hipEventElapsedTime(&ms_m, e0, e1));
+                TBK_HIP(hipEventElapsedTime(&ms_f, f0, f1));
+            } else {  // together
+                TBK_HIP(hipEventRecord(e0, sa));
+                hipLaunchKernelGGL(mfma_f64_loop, dim3(cus * 2), dim3(256), 0, sa, d_out, it_m, 1.5);
+                TBK_HIP(hipEventRecord(e1, sa));
+                TBK_HIP(hipEventRecord(f0, sb));
+                hipLaunchKernelGGL(fma_f64_loop, dim3(cus), dim3(256), 0, sb, d_out, it_f, 1.5);
+                TBK_HIP(hipEventRecord(f1, sb));
+                TBK_HIP(hipEventSynchronize(e1));
+                TBK_HIP(hipEventSynchronize(f1));
+                TBK_HIP(hipEventElapsedTime(&ms_m2, e0, e1));
+                TBK_HIP(hipEventElapsedTime(&ms_f2, f0, f1));
+            }
+        }
+    }
+    const double fma_tf = (double)cus * 256 * it_f * 8.0 * 2.0 / (ms_f * 1e-3) / 1e12;
+    fprintf(stderr,
+            "[tbk] overlap probe: mfma alone %.2f ms, fma alone %.2f ms (%.1f TFLOP/s VALU f64); together: mfma %.2f ms, "
+            "fma %.2f ms\n",
+            ms_m, ms_f, fma_tf, ms_m2, ms_f2);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(f0);
+    (void)hipEventDestroy(f1);
+    (void)hipStreamDestroy(sa);
+    (void)hipStreamDestroy(sb);
+    return TBK_OK;
+}
 
 int tbk_run_mfma_f64_peak(double* tflops) {
     hipDeviceProp_t prop;
     int dev = 0;
     TBK_HIP(hipGetDevice(&dev));
     TBK_HIP(hipGetDeviceProperties(&prop, dev));
-    const int iters = 4000;
+    const int iters = 100000;  // ~20 ms per launch: long enough for the clock to settle
     const bool verbose = getenv("TBK_VERBOSE") != nullptr;
     double* d_out = nullptr;
     TBK_HIP(hipMalloc((void**)&d_out, (size_t)prop.multiProcessorCount * 4 * 256 * sizeof(double)));
@@ -68,6 +137,7 @@ int tbk_run_mfma_f64_peak(double* tflops) {
             if (!zero && best_cfg > best) best = best_cfg;
         }
     }
+    if (verbose) (void)overlap_probe(prop.multiProcessorCount, d_out);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(d_out);
