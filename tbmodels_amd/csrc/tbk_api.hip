@@ -335,8 +335,15 @@ static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
     int64_t chunk = budget / per_k / TBK_BM * TBK_BM;
     chunk = std::max<int64_t>(TBK_BM, std::min<int64_t>(chunk, 32768));
     if (m->k_chunk > 0) chunk = round_up(m->k_chunk, TBK_BM);
+    // full chunks are multiples of 4096 k-points (32 k tiles = whole XCD patches of the tile walk, see
+    // tbk_hk_dense.hip): measured 1.00 us per k-point at 24576 / 28672 / 32768 against 1.14 us at
+    // 25088 / 25600.  The remainder goes into one last, shorter chunk.
+    else if (chunk >= 4096) chunk = chunk / 4096 * 4096;
     return std::min(chunk, round_up(nk, TBK_BM));
 }
+
+// leading dimension (in k-points) of the phase-row matrix A[K][ld]: whole k tiles
+static inline int64_t phase_ld(int64_t nk) { return round_up(nk, TBK_BM); }
 
 static int fill_rows(tbk_model* m, const double* d_k, int64_t nk, int64_t nk_pad, double* d_A) {
     if (m->kdotp)
@@ -364,7 +371,7 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
     for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
         const int64_t nkc = std::min(chunk, nk - c0);
-        const int64_t nk_pad = round_up(nkc, TBK_BM);
+        const int64_t nk_pad = phase_ld(nkc);
         TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();
         const double* kc = d_k + c0 * m->dim;
@@ -398,7 +405,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         const int b = (int)(c & 1);
         const int64_t c0 = c * chunk;
         const int64_t nkc = std::min(chunk, nk - c0);
-        const int64_t nk_pad = round_up(nkc, TBK_BM);
+        const int64_t nk_pad = phase_ld(nkc);
         TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();
         double* d_de = debuf[b]->as<double>();
@@ -454,7 +461,7 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
     for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
         const int64_t nkc = std::min(chunk, nk - c0);
-        const int64_t nk_pad = round_up(nkc, TBK_BM);
+        const int64_t nk_pad = phase_ld(nkc);
         TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
         TBK_CHECK(m->ws_H.reserve((size_t)nkc * nn2 * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();

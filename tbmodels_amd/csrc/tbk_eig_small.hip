@@ -59,6 +59,16 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Workgroup barrier with the LDS wait spelled out.  hipcc (ROCm 7.2) emitted the barrier at the head of
+// the Householder loop without an s_waitcnt for the LDS store issued at the end of the previous
+// iteration (the store reaches the barrier over the loop back edge): other waves then read the old
+// column whenever LDS was slow -- wrong eigenvalues for ~50 of 100 000 matrices, and only while another
+// kernel loaded the LDS pipe.  `tests/test_gpu_fullsize.py` catches it.
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
 template <int NR>
@@ -305,7 +315,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
 
     for (int j = 0; j < n - 1; ++j) {
         const int buf = j & 1;
-        __syncthreads();  // B1: sx[buf] = column j
+        wg_sync();  // B1: sx[buf] = column j
         const d2 xme = (lane < NR) ? sx[buf][lane] : (d2){0.0, 0.0};
         const double xr = xme[0], xi = xme[1];
         if (q == 0 && lane == j) Dm[j] = xr;
@@ -328,7 +338,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
                     }
                 if (lane < NR) sx[buf ^ 1][lane] = (d2){nxr, nxi};
             }
-            __syncthreads();  // keep the barrier count of both branches equal
+            wg_sync();  // keep the barrier count of both branches equal
             continue;
         }
         const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
@@ -362,7 +372,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             }
         }
         if (lane < NR) sp[q][lane] = (d2){par[0] + par[1], pai[0] + pai[1]};
-        __syncthreads();  // B2: partial products of all four waves
+        wg_sync();  // B2: partial products of all four waves
         double pr = 0.0, pi = 0.0;
         if (lane > j && lane < n) {
 #pragma unroll
@@ -414,7 +424,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             if (lane < NR) sx[buf ^ 1][lane] = (d2){nxr, nxi};
         }
     }
-    __syncthreads();
+    wg_sync();
     if (q == 0 && lane == n - 1) Dm[n - 1] = sx[(n - 1) & 1][lane][0];
     if (q == 0 && lane == 0) Em[n - 1] = 0.0;
 }
@@ -422,8 +432,8 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
 // ------------------------------------------------------------------------------------------------
 // kernel 2: implicit QL with Wilkinson shift on 64 tridiagonals per wave (one per lane)
 // ------------------------------------------------------------------------------------------------
-constexpr int QL_LD = 64;  // [index][lane]: a lane walks its own column, 8 B apart from its neighbours
 
+template <int QL_LD>  // matrices per block = row length of the [index][lane] LDS arrays
 __global__ void __launch_bounds__(64)
 tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, int n, int64_t nk,
                   double* __restrict__ out, int* __restrict__ fail_count) {
@@ -431,8 +441,8 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
     double* sd = ql_smem;
     double* se = ql_smem + (size_t)n * QL_LD;
     const int lane = threadIdx.x;
-    const int64_t m0 = (int64_t)blockIdx.x * 64;
-    const int nmat = (int)min((int64_t)64, nk - m0);
+    const int64_t m0 = (int64_t)blockIdx.x * QL_LD;
+    const int nmat = (int)min((int64_t)QL_LD, nk - m0);
 
     // coalesced fill: the 64 x n block of (d, e) is contiguous in memory
     for (int idx = lane; idx < nmat * n; idx += 64) {
@@ -523,8 +533,7 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
     const dim3 grid((unsigned)nk), block(64);
-    static const bool one_wave = getenv("TBK_TRIDIAG_1WAVE") != nullptr;  // A/B switch while tuning
-    if (n > 32 && !one_wave) {
+    if (n > 32) {
         hipLaunchKernelGGL(herm_tridiag4_kernel<64>, grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
@@ -545,8 +554,8 @@ int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, d
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_QL, s);
-    hipLaunchKernelGGL(tridiag_ql_kernel, dim3((unsigned)((nk + 63) / 64)), dim3(64),
-                       (size_t)2 * n * QL_LD * sizeof(double), s, d_de, d_de + (size_t)nk * n, n, nk, d_E,
+    hipLaunchKernelGGL(tridiag_ql_kernel<64>, dim3((unsigned)((nk + 63) / 64)), dim3(64),
+                       (size_t)2 * n * 64 * sizeof(double), s, d_de, d_de + (size_t)nk * n, n, nk, d_E,
                        m->ws_flag.as<int>());
     TBK_HIP(hipGetLastError());
     return TBK_OK;

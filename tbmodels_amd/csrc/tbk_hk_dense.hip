@@ -229,7 +229,7 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.ncol_pad = m->ncol_pad;
     a.n_orb = m->n_orb;
     a.dim = m->dim;
-    a.mt_count = (int)(nk_pad / TBK_BM);
+    a.mt_count = (int)((nk + TBK_BM - 1) / TBK_BM);  // nk_pad is only the row stride of A
     a.nt_count = m->ncol_pad / TBK_BNP;
     int grid;
     if (a.mt_count >= 32) {

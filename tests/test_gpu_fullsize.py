@@ -1,0 +1,109 @@
+"""
+BASELINE.json's full sizes on the GPU, checked through size-independent properties (the oracle needs
+~17 ms per k-point at the headline shape, so only a small subset is compared with it directly):
+
+* sum_i E_i(k) = tr H(k) = sum_R 2 Re(exp(2 pi i k.R) tr hop[R])   (computed independently on the host)
+* E(k + G) = E(k) for integer G                                      (periodicity of the Fourier sum)
+* eigenvalues ascending per k; result independent of the order / chunking of the k list
+* a random subset against the oracle at 1e-10
+"""
+
+import numpy as np
+import pytest
+
+import tbmodels_amd
+from tbmodels_amd import _lib
+from tbmodels_amd import synthetic as syn
+from oracle import tbk_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _trace_from_hoppings(r_vec, traces, k):
+    """tr H(k) from the per-R traces: O(NK * N_R) host work, independent of the GPU path."""
+    out = np.empty(len(k))
+    r_f = r_vec.astype(float)
+    for lo in range(0, len(k), 8192):
+        phase = np.exp(2j * np.pi * (k[lo:lo + 8192] @ r_f.T))
+        out[lo:lo + 8192] = 2.0 * (phase @ traces).real
+    return out
+
+
+def test_config2_headline_shape_100k():
+    """Config 2: dense N_orb=64, N_R=4096, 100 000 random k-points."""
+    r_vec, hop, pos = syn.dense_model_arrays(64, 4096, syn.MODEL_SEED + 2)
+    k = syn.random_kpoints(100_000)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.pin_staging()
+    eig = np.array(model.eigenval(k))
+    assert eig.shape == (100_000, 64) and np.isfinite(eig).all()
+    assert np.all(np.diff(eig, axis=1) >= 0)
+    traces = np.einsum("rii->r", hop)
+    assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    # periodicity, and independence of position in the batch (different chunk / tile for every k)
+    perm = np.random.default_rng(3).permutation(len(k))
+    shifted = k[perm] + np.array([2.0, -1.0, 5.0])
+    eig2 = np.array(model.eigenval(shifted))
+    assert np.abs(eig2 - eig[perm]).max() < 1e-10
+    # direct comparison on a subset
+    idx = np.random.default_rng(4).choice(len(k), 48, replace=False)
+    ref = np.array(oracle.eigenval(r_vec, hop, k[idx]))
+    assert np.abs(eig[idx] - ref).max() < 1e-10
+    # H(k) itself on a few points, both conventions
+    ham = model.hamilton(k[idx[:8]])
+    assert np.abs(ham - oracle.hamilton(r_vec, hop, k[idx[:8]])).max() < 1e-10
+    ham1 = model.hamilton(k[idx[:8]], convention=1)
+    assert np.abs(ham1 - oracle.hamilton(r_vec, hop, k[idx[:8]], 1, pos=pos)).max() < 1e-10
+
+
+def test_config3_sparse_shape():
+    """Config 3: CSR N_orb=256, N_R=512, 2 % fill (k list shortened: the N=256 eigensolve is ~0.1 ms per k)."""
+    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(256, 512, syn.MODEL_SEED + 3)
+    hop_dict = {}
+    import scipy.sparse as sp
+
+    for idx, r in enumerate(r_vec):
+        sl = slice(r_ptr[idx], r_ptr[idx + 1])
+        hop_dict[tuple(int(x) for x in r)] = sp.csr_matrix((val[sl], (row[sl], col[sl])), shape=(256, 256))
+    model = tbmodels_amd.Model(hop=hop_dict, pos=pos, size=256, contains_cc=False, sparse=True)
+    k = syn.random_kpoints(4096)
+    eig = np.array(model.eigenval(k))
+    assert np.all(np.diff(eig, axis=1) >= 0)
+    diag = row == col
+    traces = np.zeros(len(r_vec), dtype=complex)
+    np.add.at(traces, np.searchsorted(r_ptr, np.flatnonzero(diag), side="right") - 1, val[diag])
+    assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    dense_hop = syn.csr_to_dense(256, r_ptr, row, col, val)
+    ref = np.array(oracle.eigenval(r_vec, dense_hop, k[:6]))
+    assert np.abs(eig[:6] - ref).max() < 1e-10
+    # the sparse kernel and the dense MFMA kernel agree on H(k) (tests/test_sparse_dense.py of the reference)
+    dense = tbmodels_amd.Model.from_packed(r_vec, dense_hop, pos=pos)
+    assert np.abs(model.hamilton(k[:16]) - dense.hamilton(k[:16])).max() < 1e-12
+
+
+def test_config5_large_orbital_shape_reduced_R():
+    """Config 5 orbital count (N_orb=512, rocSOLVER path) at reduced N_R so the host model stays small."""
+    r_vec, hop, pos = syn.dense_model_arrays(512, 64, syn.MODEL_SEED + 5)
+    k = syn.random_kpoints(64)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    eig = np.array(model.eigenval(k))
+    traces = np.einsum("rii->r", hop)
+    assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    ref = np.array(oracle.eigenval(r_vec, hop, k[:4]))
+    assert np.abs(eig[:4] - ref).max() < 1e-10
+
+
+def test_config4_grid_slabs_match_whole():
+    """Config 4 sharding logic on one GPU: contiguous slabs of the uniform grid, evaluated one by one, equal the whole."""
+    from tbmodels_amd.sharding import slab_bounds
+
+    r_vec, hop, pos = syn.dense_model_arrays(16, 64, syn.MODEL_SEED + 4)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    n = 24
+    whole = np.array(model.eigenval(syn.uniform_grid(n)))
+    world = 8
+    parts = []
+    for rank in range(world):
+        lo, hi = slab_bounds(n ** 3, world, rank)
+        parts.append(np.array(model.eigenval(syn.grid_slab(n, lo, hi))).reshape(hi - lo, 16))
+    assert np.abs(np.concatenate(parts) - whole).max() == 0.0
