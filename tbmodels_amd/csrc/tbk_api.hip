@@ -335,10 +335,7 @@ static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
     int64_t chunk = budget / per_k / TBK_BM * TBK_BM;
     chunk = std::max<int64_t>(TBK_BM, std::min<int64_t>(chunk, 32768));
     if (m->k_chunk > 0) chunk = round_up(m->k_chunk, TBK_BM);
-    // full chunks are multiples of 4096 k-points (32 k tiles = whole XCD patches of the tile walk, see
-    // tbk_hk_dense.hip): measured 1.00 us per k-point at 24576 / 28672 / 32768 against 1.14 us at
-    // 25088 / 25600.  The remainder goes into one last, shorter chunk.
-    else if (chunk >= 4096) chunk = chunk / 4096 * 4096;
+    else if (chunk >= 4096) chunk = chunk / 4096 * 4096;  // 32 k tiles: equal shares for the 8 XCDs
     return std::min(chunk, round_up(nk, TBK_BM));
 }
 

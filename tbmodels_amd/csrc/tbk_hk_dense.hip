@@ -66,17 +66,31 @@ __device__ __forceinline__ bool tile_of_block(const HkArgs& a, int b, int& mt, i
         mt = b / a.nt_count;
         return mt < a.mt_count;
     }
-    // XCD-aware walk: XCD x owns the k tiles {mt : mt % 8 == x}; inside an XCD consecutive blocks
-    // sweep `xcd_rows` k tiles for one element tile, then the next element tile, so the ~32
-    // co-resident workgroups of an XCD form an (xcd_rows x 32/xcd_rows) patch of the tile grid.
+    // XCD-aware walk (block b is dispatched to XCD b % 8): XCD x owns a contiguous range of k tiles;
+    // inside it consecutive blocks sweep `xcd_rows` k tiles for one element tile, then the next element
+    // tile, so the ~64 co-resident workgroups of an XCD form an (xcd_rows x 16) patch of the tile grid and
+    // share A row-panels and Bt column-panels in that XCD's private L2.  The last group of an XCD may
+    // hold fewer rows; it is walked densely as well (no interleaved empty blocks).
     const int x = b & 7;
     const int t = b >> 3;
+    const int base = a.mt_count >> 3, extra = a.mt_count & 7;
+    const int rows = base + (x < extra ? 1 : 0);
+    if (t >= rows * a.nt_count) return false;
+    const int start = x * base + (x < extra ? x : extra);
+    const int full = rows / a.xcd_rows;
     const int per_group = a.xcd_rows * a.nt_count;
-    const int g = t / per_group;
-    const int r = t % per_group;
-    nt = r / a.xcd_rows;
-    mt = (g * a.xcd_rows + r % a.xcd_rows) * 8 + x;
-    return mt < a.mt_count;
+    int row;
+    if (t < full * per_group) {
+        const int g = t / per_group, r = t % per_group;
+        row = g * a.xcd_rows + r % a.xcd_rows;
+        nt = r / a.xcd_rows;
+    } else {
+        const int tt = t - full * per_group, rr = rows - full * a.xcd_rows;
+        row = full * a.xcd_rows + tt % rr;
+        nt = tt / rr;
+    }
+    mt = start + row;
+    return true;
 }
 
 template <int MODE, int CONV>
@@ -232,10 +246,10 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.mt_count = (int)((nk + TBK_BM - 1) / TBK_BM);  // nk_pad is only the row stride of A
     a.nt_count = m->ncol_pad / TBK_BNP;
     int grid;
-    if (a.mt_count >= 32) {
+    if (a.mt_count >= 32) {  // below that a plain round-robin over the XCDs balances better
         a.xcd_rows = 4;
-        const int groups = (a.mt_count + 8 * a.xcd_rows - 1) / (8 * a.xcd_rows);
-        grid = groups * a.xcd_rows * a.nt_count * 8;
+        const int max_rows = (a.mt_count + 7) / 8;
+        grid = max_rows * a.nt_count * 8;
     } else {
         a.xcd_rows = 0;
         grid = a.mt_count * a.nt_count;
