@@ -382,16 +382,13 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
                 pi += t[1];
             }
         }
-        {
-            const double t = pr * tr - pi * ti;
-            pi = pr * ti + pi * tr;
-            pr = t;
-        }
-        const double dr = wave_sum(pr * vr + pi * vi);
-        const double di = wave_sum(pr * vi - pi * vr);
-        const double a2r = -0.5 * (tr * dr - ti * di), a2i = -0.5 * (tr * di + ti * dr);
-        const double wr = pr + (a2r * vr - a2i * vi);
-        const double wi = pi + (a2r * vi + a2i * vr);
+        // u = A v is in (pr, pi).  A is Hermitian, so rho = v^H u is real: one reduction instead of the
+        // complex dot product p^H v of zhetd2 (p = tau u, p^H v = conj(tau) rho), and
+        // w = p - (tau/2)(p^H v) v = tau u - (|tau|^2 rho / 2) v.
+        const double rho = wave_sum(pr * vr + pi * vi);
+        const double a2 = -0.5 * (tr * tr + ti * ti) * rho;
+        const double wr = fma(a2, vr, pr * tr - pi * ti);
+        const double wi = fma(a2, vi, pr * ti + pi * tr);
         if (lane < NR) sw[q][lane] = (d2){wr, wi};
 
         // A -= v w^H + w v^H on this wave's columns
@@ -459,10 +456,13 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
         for (int l = 0; l < n && !failed; ++l) {
             int iter = 0;
             while (true) {
+                // look for a negligible off-diagonal; |d[m]| is carried over from the previous step
                 int m = l;
+                double ad = fabs(d[l * QL_LD]);
                 for (; m < n - 1; ++m) {
-                    const double dd = fabs(d[m * QL_LD]) + fabs(d[(m + 1) * QL_LD]);
-                    if (fabs(e[m * QL_LD]) <= 2.220446049250313e-16 * dd) break;
+                    const double ad1 = fabs(d[(m + 1) * QL_LD]);
+                    if (fabs(e[m * QL_LD]) <= 2.220446049250313e-16 * (ad + ad1)) break;
+                    ad = ad1;
                 }
                 if (m == l) break;
                 if (++iter > 60) {
@@ -470,34 +470,46 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
                     break;
                 }
                 const double el = e[l * QL_LD];
-                double g = (d[(l + 1) * QL_LD] - d[l * QL_LD]) / (2.0 * el);
+                const double dl = d[l * QL_LD];
+                double g = (d[(l + 1) * QL_LD] - dl) / (2.0 * el);
                 double r = sqrt(fma(g, g, 1.0));
-                g = d[m * QL_LD] - d[l * QL_LD] + el / (g + copysign(r, g));
+                g = d[m * QL_LD] - dl + el / (g + copysign(r, g));
                 double s = 1.0, c = 1.0, p = 0.0;
-                int i = m - 1;
+                // The sweep is one long dependent chain per lane (this kernel is latency-bound), so it is
+                // kept short: d[i+1] stays in a register from the previous step, (d[i-1], e[i-1]) are
+                // fetched from LDS one step ahead, and the rotation uses one rsqrt instead of sqrt + divide
+                // (|T| = O(1..10): no overflow guard needed).
+                double d_up = d[m * QL_LD];                                      // d[i + 1]
+                double d_i = d[(m - 1) * QL_LD], e_i = e[(m - 1) * QL_LD];       // step i = m - 1
                 bool underflow = false;
-                for (; i >= l; --i) {
-                    const double f = s * e[i * QL_LD];
-                    const double b = c * e[i * QL_LD];
-                    r = sqrt(fma(f, f, g * g));  // |T| = O(1..10): no overflow guard needed
-                    e[(i + 1) * QL_LD] = r;
-                    if (r == 0.0) {
-                        d[(i + 1) * QL_LD] -= p;
+                for (int i = m - 1; i >= l; --i) {
+                    const int ip = (i > l) ? i - 1 : l;
+                    const double d_nx = d[ip * QL_LD], e_nx = e[ip * QL_LD];     // for step i - 1
+                    const double f = s * e_i;
+                    const double b = c * e_i;
+                    const double h2 = fma(f, f, g * g);
+                    if (h2 == 0.0) {
+                        e[(i + 1) * QL_LD] = 0.0;
+                        d[(i + 1) * QL_LD] = d_up - p;
                         e[m * QL_LD] = 0.0;
                         underflow = true;
                         break;
                     }
-                    const double rinv = 1.0 / r;
+                    const double rinv = rsqrt(h2);
+                    e[(i + 1) * QL_LD] = h2 * rinv;
                     s = f * rinv;
                     c = g * rinv;
-                    g = d[(i + 1) * QL_LD] - p;
-                    r = (d[i * QL_LD] - g) * s + 2.0 * c * b;
+                    const double gg = d_up - p;
+                    r = (d_i - gg) * s + 2.0 * c * b;
                     p = s * r;
-                    d[(i + 1) * QL_LD] = g + p;
+                    d[(i + 1) * QL_LD] = gg + p;
                     g = c * r - b;
+                    d_up = d_i;
+                    d_i = d_nx;
+                    e_i = e_nx;
                 }
                 if (underflow) continue;
-                d[l * QL_LD] -= p;
+                d[l * QL_LD] = d_up - p;
                 e[l * QL_LD] = g;
                 e[m * QL_LD] = 0.0;
             }
