@@ -94,6 +94,26 @@ def stage(lib, device, arrays):
     return handle
 
 
+def measured_traffic(kernel, k_per_launch):
+    """
+    HBM bytes per launch of `kernel` from the newest profiles/*_traffic.json (rocprofv3 PMC passes,
+    tools/summarize_profiles.py): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per full k chunk, scaled linearly to
+    this run's k-points per launch.  bench.py cannot read PMC counters itself; None when no profile exists.
+    """
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as handle:
+        data = json.load(handle)
+    entry = data.get(kernel)
+    if not entry or "hbm_bytes_per_launch" not in entry:
+        return None, None
+    scaled = entry["hbm_bytes_per_launch"] * k_per_launch / entry["kpoints_per_launch"]
+    return scaled, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(arrays, kpts, sample):
     """The oracle (NumPy/SciPy port of the reference loop), single process, on `sample` k-points."""
     from oracle import tbk_oracle as oracle  # checker / baseline only
@@ -275,10 +295,16 @@ def main():
         k_per_launch = nk_gpu * args.steps / hk_launches
         if arrays["kind"] == "dense":
             achieved = f_k * k_per_launch / (hk_ms_avg * 1e-3) / 1e12 if hk_ms_avg > 0 else 0.0
+            traffic, traffic_src = (None, None)
+            if args.config == "cfg2" and not args.nr:
+                traffic, traffic_src = measured_traffic("hk_dense", k_per_launch)
             roofline = {
                 "kernel": "hk_dense_kernel", "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE+WRITE_SIZE)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": (16.0 * n_orb * (n_orb + 1) / 2 + 8 * dim) * k_per_launch
+                                                + 16.0 * n_orb * n_orb * n_r,
                 "executed_tflops": round(f_exec * k_per_launch / (hk_ms_avg * 1e-3) / 1e12, 3) if hk_ms_avg > 0 else 0.0,
                 "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
                 "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
