@@ -112,6 +112,12 @@ void tbk_kdotp_destroy(tbk_kdotp* m);
 int tbk_kdotp_hamilton(tbk_kdotp* m, const double* k, int64_t nk, double* H_out);
 int tbk_kdotp_eigenval(tbk_kdotp* m, const double* k, int64_t nk, double* E_out);
 
+/* Model.construct_kdotp (_tb_model.py:942-982): Taylor coefficients of H(k) around k0 for n_p power
+ * tuples.  powers: int32 [n_p][dim]; prefactor: double [n_p][2] = (2 pi i)^{|p|} / prod p_d! as (re, im);
+ * coeffs_out: double [n_p][n_orb][n_orb][2] (Hermitian matrices).  Host buffers; dense handles only. */
+int tbk_kdotp_coefficients(tbk_model* m, const double* k0, int64_t n_p, const int32_t* powers,
+                           const double* prefactor, double* coeffs_out);
+
 /* ---- device memory helpers (so a Python host needs no other GPU runtime) ----------------- */
 int tbk_device_malloc(int device, int64_t bytes, void** d_ptr);
 int tbk_device_free(int device, void* d_ptr);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "tbk_kdotp_destroy": (None, [_vp]),
     "tbk_kdotp_hamilton": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "tbk_kdotp_eigenval": (_c_int, [_vp, _vp, _c_i64, _vp]),
+    "tbk_kdotp_coefficients": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _vp]),
     "tbk_device_malloc": (_c_int, [_c_int, _c_i64, _pp]),
     "tbk_device_free": (_c_int, [_c_int, _vp]),
     "tbk_memcpy_h2d": (_c_int, [_c_int, _vp, _vp, _c_i64]),

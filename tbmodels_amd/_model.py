@@ -467,6 +467,40 @@ class Model:
             raise ValueError("array must not contain infs or NaNs")
         return out[0] if single else list(out)
 
+    def construct_kdotp(self, k, order):
+        """
+        k.p model around the k-point ``k``: the Taylor expansion of H(k) (convention 2) up to total power
+        ``order``, evaluated on the GPU (``Model.construct_kdotp``, ``_tb_model.py:942-982``).
+        """
+        import itertools  # pylint: disable=import-outside-toplevel
+        import math  # pylint: disable=import-outside-toplevel
+
+        from .kdotp import KdotpModel  # pylint: disable=import-outside-toplevel
+
+        if order < 0:
+            raise ValueError("The order for the k.p model must be positive.")
+        k0 = np.ascontiguousarray(np.array(k, ndmin=1), dtype=np.float64)
+        if k0.shape != (self.dim,):
+            raise ValueError("k has shape {} but the model has dimension {}".format(k0.shape, self.dim))
+        powers = [p for p in itertools.product(range(order + 1), repeat=self.dim) if sum(p) <= order]
+        pw = np.array(powers, dtype=np.int32).reshape(len(powers), self.dim)
+        pref = np.array(
+            [(2j * np.pi) ** sum(p) / np.prod([math.factorial(x) for x in p]) for p in powers], dtype=np.complex128
+        )
+        source = self
+        if self._sparse:  # the derivative kernel reads the dense staged operand
+            r_vec, _ = self.packed_hop()
+            dense = np.stack([np.array(m) for m in self.hop.values()]) if len(self.hop) else np.zeros((0, self.size, self.size))
+            source = Model.from_packed(r_vec, dense, size=self.size, dim=self.dim)
+            source.device = self.device
+        coeffs = np.empty((len(powers), self.size, self.size), dtype=np.complex128)
+        _lib.check(
+            _lib.lib().tbk_kdotp_coefficients(
+                source._staged(), _lib.ptr(k0), len(powers), _lib.ptr(pw), _lib.ptr(pref), _lib.ptr(coeffs)
+            )
+        )
+        return KdotpModel(taylor_coefficients={p: coeffs[i] for i, p in enumerate(powers)})
+
     # ------------------------------------------------------------------ introspection
     def timing(self, reset=True):
         """Per-stage HIP-event times of the staged model: ``{stage: (ms, launches)}`` (needs TBK_OPT_TIMING)."""
