@@ -267,6 +267,53 @@ class Model:
         blocks = {tuple(int(x) for x in r): h for r, h in zip(r_vec, hop)}
         return cls(hop=blocks, pos=pos, contains_cc=False, **kwargs)
 
+    @classmethod
+    def from_wannier_files(
+        cls,
+        *,
+        hr_file,
+        wsvec_file=None,
+        xyz_file=None,
+        win_file=None,
+        h_cutoff=0.0,
+        ignore_orbital_order=False,
+        pos_kind="wannier",
+        distance_ratio_threshold=3.0,
+        **kwargs,
+    ):
+        """
+        Build a model from Wannier90 output (``*_hr.dat`` and optionally ``*_wsvec.dat``, ``*_centres.xyz``,
+        ``*.win``): same keywords and results as ``tbmodels.Model.from_wannier_files``
+        (``_tb_model.py:565-715``); the files are parsed array-wise by :mod:`tbmodels_amd.wannier`.
+        """
+        from . import wannier  # pylint: disable=import-outside-toplevel
+
+        if win_file is not None:
+            if "uc" in kwargs:
+                raise ValueError(
+                    "Ambiguous unit cell: It can be given either via 'uc' or the 'win_file' keywords, but not both."
+                )
+            kwargs["uc"] = wannier.read_win(win_file)["unit_cell_cart"]
+        if xyz_file is not None:
+            if "pos" in kwargs:
+                raise ValueError(
+                    "Ambiguous orbital positions: The positions can be given either via the 'pos' or the "
+                    "'xyz_file' keywords, but not both."
+                )
+            if "uc" not in kwargs:
+                raise ValueError(
+                    "Positions cannot be read from .xyz file without unit cell given: Transformation from "
+                    "cartesian to reduced coordinates not possible. Specify the unit cell using one of the "
+                    "keywords 'uc' or 'win_file'."
+                )
+            kwargs["pos"] = wannier.positions_from_xyz(
+                xyz_file, kwargs["uc"], pos_kind=pos_kind, distance_ratio_threshold=distance_ratio_threshold
+            )
+        num_wann, blocks = wannier.hop_blocks_from_wannier(
+            hr_file, wsvec_file=wsvec_file, h_cutoff=h_cutoff, ignore_orbital_order=ignore_orbital_order
+        )
+        return cls(size=num_wann, hop=blocks, **kwargs)
+
     # ------------------------------------------------------------------ mutators (reference API)
     def add_hop(self, overlap, orbital_1, orbital_2, R):
         """

@@ -33,6 +33,8 @@ The fixtures (all ``.npz``, < 2 MB in total) and what produced them:
                      uses at full size) pushed through the reference: dense, CSR, dim 1/2,
                      scalar k, empty hop, convention 1 with non-zero positions.
 ``kdotp.npz``        ``KdotpModel`` + ``Model.construct_kdotp`` outputs.
+``wannier.npz``      ``Model.from_wannier_files`` on the reference's silicon sample files (section 8f rank 4);
+                     the four Wannier90 input files themselves are stored gzip-ed under ``wannier/``.
 """
 
 import importlib.util
@@ -371,6 +373,70 @@ def gen_kdotp(tbmodels, syn):
     np.savez_compressed(os.path.join(OUT, "kdotp.npz"), **out)
 
 
+def gen_wannier(tbmodels):
+    """
+    SURVEY section 8(f) rank 4: Model.from_wannier_files (_tb_model.py:399-441, :565-852) on the reference's
+    own silicon sample files.  The four input files are copied (gzip) next to the expected outputs: they are
+    data files of the reference's test-suite (tests/samples/silicon_*).
+    """
+    import gzip  # pylint: disable=import-outside-toplevel
+    import shutil  # pylint: disable=import-outside-toplevel
+
+    samples = os.path.join(REF, "tests", "samples")
+    wdir = os.path.join(OUT, "wannier")
+    os.makedirs(wdir, exist_ok=True)
+    names = ["silicon_hr.dat", "silicon_wsvec.dat", "silicon_centres.xyz", "silicon.win"]
+    for name in names:
+        with open(os.path.join(samples, name), "rb") as src, gzip.GzipFile(
+            os.path.join(wdir, name + ".gz"), "wb", mtime=0
+        ) as dst:
+            shutil.copyfileobj(src, dst)
+    path = lambda name: os.path.join(samples, name)  # noqa: E731
+    out = {"kpt": np.array(KPT)}
+
+    def record(tag, model):
+        r_vec, hop = _pack_hop(model)
+        # dict order differs between implementations: store sorted by R
+        order = np.lexsort(r_vec.T[::-1])
+        out[tag + "_R"] = r_vec[order]
+        out[tag + "_hop"] = hop[order]
+        out[tag + "_pos"] = np.array(model.pos)
+        if model.uc is not None:
+            out[tag + "_uc"] = np.array(model.uc)
+        out[tag + "_h2"] = np.array(model.hamilton(KPT))
+        out[tag + "_h1"] = np.array(model.hamilton(KPT, convention=1))
+        out[tag + "_eig"] = _eig(model, KPT)
+
+    record("hr", tbmodels.Model.from_wannier_files(hr_file=path("silicon_hr.dat")))
+    stored = _regression("test_wannier", "test_wannier_hr_only[silicon_hr.dat]")
+    assert np.abs(out["hr_h2"] - stored).max() < 1e-12
+    out["hr_h2_stored"] = stored
+    record("hr_ws", tbmodels.Model.from_wannier_files(hr_file=path("silicon_hr.dat"), wsvec_file=path("silicon_wsvec.dat")))
+    record(
+        "all",
+        tbmodels.Model.from_wannier_files(
+            hr_file=path("silicon_hr.dat"), wsvec_file=path("silicon_wsvec.dat"),
+            xyz_file=path("silicon_centres.xyz"), win_file=path("silicon.win"),
+        ),
+    )
+    stored = _regression(
+        "test_wannier",
+        "test_wannier_all[silicon_hr.dat-silicon_wsvec.dat-silicon_centres.xyz-silicon.win-pos0-uc0-reciprocal_lattice0-wannier]",
+    )
+    assert np.abs(out["all_h2"] - stored).max() < 1e-12
+    out["all_h2_stored"] = stored
+    record(
+        "nearest",
+        tbmodels.Model.from_wannier_files(
+            hr_file=path("silicon_hr.dat"), wsvec_file=path("silicon_wsvec.dat"),
+            xyz_file=path("silicon_centres.xyz"), win_file=path("silicon.win"), pos_kind="nearest_atom",
+            distance_ratio_threshold=1.0,
+        ),
+    )
+    record("cutoff", tbmodels.Model.from_wannier_files(hr_file=path("silicon_hr.dat"), h_cutoff=0.05, sparse=True))
+    np.savez_compressed(os.path.join(OUT, "wannier.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tbmodels = _import_reference()
@@ -380,6 +446,7 @@ def main():
     gen_toy(tbmodels)
     gen_synthetic(tbmodels, syn)
     gen_kdotp(tbmodels, syn)
+    gen_wannier(tbmodels)
     for name in sorted(os.listdir(OUT)):
         print("%-16s %8d bytes" % (name, os.path.getsize(os.path.join(OUT, name))))
 
