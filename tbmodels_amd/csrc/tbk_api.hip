@@ -466,7 +466,10 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
         const double* kc = d_k + c0 * m->dim;
         TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
         TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H));
-        TBK_CHECK(tbk_eig_batched(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
+        if (m->eigensolver == TBK_EIG_AUTO && m->n_orb <= 512)
+            TBK_CHECK(tbk_eig_hetrd_ql(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
+        else
+            TBK_CHECK(tbk_eig_batched(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
     }
     return TBK_OK;
 }

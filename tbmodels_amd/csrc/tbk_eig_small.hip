@@ -566,9 +566,24 @@ int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, d
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_QL, s);
-    hipLaunchKernelGGL(tridiag_ql_kernel<64>, dim3((unsigned)((nk + 63) / 64)), dim3(64),
-                       (size_t)2 * n * 64 * sizeof(double), s, d_de, d_de + (size_t)nk * n, n, nk, d_E,
-                       m->ws_flag.as<int>());
+    // matrices per block: as many as fit 64 KiB of LDS (2 n doubles per matrix), at most one per lane
+#define TBK_QL_LAUNCH(MPB)                                                                                  \
+    hipLaunchKernelGGL(tridiag_ql_kernel<MPB>, dim3((unsigned)((nk + MPB - 1) / MPB)), dim3(64),             \
+                       (size_t)2 * n * MPB * sizeof(double), s, d_de, d_de + (size_t)nk * n, n, nk, d_E,     \
+                       m->ws_flag.as<int>())
+    if (n <= 64) {
+        TBK_QL_LAUNCH(64);
+    } else if (n <= 128) {
+        TBK_QL_LAUNCH(32);
+    } else if (n <= 256) {
+        TBK_QL_LAUNCH(16);
+    } else if (n <= 512) {
+        TBK_QL_LAUNCH(8);
+    } else {
+        tbk_set_error("tridiagonal QL kernel handles n <= 512 (n = %d)", n);
+        return TBK_ERR_ARGUMENT;
+    }
+#undef TBK_QL_LAUNCH
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

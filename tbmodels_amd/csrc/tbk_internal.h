@@ -175,7 +175,8 @@ int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
                       int convention, const double* d_k, const double* d_pos, double* d_H);
 
 // tbk_eig.hip
-int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);
+int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);    // full rocSOLVER zheevd
+int tbk_eig_hetrd_ql(tbk_model* m, double* d_H, int64_t nk, double* d_E);   // rocSOLVER zhetrd + own QL
 size_t tbk_eig_scratch_per_k(const tbk_model* m);
 
 // tbk_eig_small.hip
