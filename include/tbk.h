@@ -57,8 +57,8 @@ typedef enum tbk_status {
 /* eigensolver selection for tbk_model_set_option(TBK_OPT_EIGENSOLVER, ...):
  *   WAVE      hand-written wave-per-matrix Householder + QL (n_orb <= 64 only)
  *   ROCSOLVER rocsolver_zheevd_strided_batched
- *   AUTO      WAVE when n_orb <= 64; rocsolver_zhetrd + the library's tridiagonal QL kernel up to
- *             n_orb = 512; ROCSOLVER above */
+ *   AUTO      WAVE when n_orb <= 64; the streaming Householder kernel + tridiagonal QL up to n_orb = 512;
+ *             ROCSOLVER above */
 enum { TBK_EIG_AUTO = 0, TBK_EIG_WAVE = 1, TBK_EIG_ROCSOLVER = 2 };
 enum {
     TBK_OPT_EIGENSOLVER = 1, /* one of TBK_EIG_*                                           */

@@ -378,7 +378,8 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
     return TBK_OK;
 }
 
-// Eigenvalues with the hand-written wave solver (n_orb <= 64), software-pipelined over k chunks on
+// Eigenvalues with the hand-written solvers (register-resident reduction for n_orb <= 64, blocked streaming
+// reduction up to 512), software-pipelined over k chunks on
 // three streams:   main: phase(c) -> H(c)      eig: tridiag(c)      ql: QL(c - 1)
 //
 //     | H(c) | tridiag(c) || QL(c-1) | H(c+1) | tridiag(c+1) || QL(c) | ...
@@ -417,7 +418,10 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         TBK_HIP(hipEventRecord(m->ev_hk[b], m->stream));
 
         TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_hk[b], 0));
-        TBK_CHECK(tbk_launch_tridiag(m, m->stream_eig, d_H, nkc, d_de));
+        if (tbk_eig_small_supported(m->n_orb))
+            TBK_CHECK(tbk_launch_tridiag(m, m->stream_eig, d_H, nkc, d_de));
+        else
+            TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream_eig, d_H, nkc, d_de));
         TBK_HIP(hipEventRecord(m->ev_tri[b], m->stream_eig));
 
         if (c >= 1) {  // QL of the previous chunk, alongside this chunk's reduction
@@ -451,11 +455,13 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
         tbk_set_error("TBK_EIG_WAVE handles n_orb <= 64 only (n_orb = %d)", m->n_orb);
         return TBK_ERR_ARGUMENT;
     }
-    if (m->eigensolver != TBK_EIG_ROCSOLVER && tbk_eig_small_supported(m->n_orb))
+    if (m->eigensolver != TBK_EIG_ROCSOLVER &&
+        (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb))))
         return eigenval_wave_pipeline(m, d_k, nk, d_E);
 
     const int64_t chunk = choose_chunk(m, nk, true);
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
+    // rocSOLVER path: TBK_EIG_ROCSOLVER, or n_orb > 512
     for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
         const int64_t nkc = std::min(chunk, nk - c0);
         const int64_t nk_pad = phase_ld(nkc);
@@ -466,10 +472,7 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
         const double* kc = d_k + c0 * m->dim;
         TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
         TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H));
-        if (m->eigensolver == TBK_EIG_AUTO && m->n_orb <= 512)
-            TBK_CHECK(tbk_eig_hetrd_ql(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
-        else
-            TBK_CHECK(tbk_eig_batched(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
+        TBK_CHECK(tbk_eig_batched(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
     }
     return TBK_OK;
 }

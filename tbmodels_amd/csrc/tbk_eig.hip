@@ -25,27 +25,6 @@ size_t tbk_eig_scratch_per_k(const tbk_model* m) {
     return (size_t)m->n_orb * 4 * sizeof(double) + sizeof(int);  // (d, e) + complex tau
 }
 
-// 64 < n <= 512: rocSOLVER's blocked Householder reduction (zhetrd) followed by this library's own
-// tridiagonal QL kernel.  zheevd(evect = none) spends half of its time in the divide-and-conquer tridiagonal
-// solver (stedc_* kernels, ~49 us of ~93 us per matrix at n = 256), which builds eigenvector data nobody
-// asked for; the lane-per-matrix QL needs ~5 us.
-int tbk_eig_hetrd_ql(tbk_model* m, double* d_H, int64_t nk, double* d_E) {
-    if (nk == 0 || m->n_orb == 0) return TBK_OK;
-    const int n = m->n_orb;
-    TBK_CHECK(m->ws_E.reserve((size_t)nk * n * 4 * sizeof(double)));
-    double* d_de = m->ws_E.as<double>();
-    double* d_tau = d_de + (size_t)nk * n * 2;
-    {
-        StageTimer t(m, TBK_T_EIG);
-        TBK_HIP(hipMemsetAsync(d_de + (size_t)nk * n, 0, (size_t)nk * n * sizeof(double), m->stream));  // e[n-1] = 0
-        TBK_ROCBLAS(rocsolver_zhetrd_strided_batched(
-            m->blas, rocblas_fill_lower, n, reinterpret_cast<rocblas_double_complex*>(d_H), n,
-            (rocblas_stride)n * n, d_de, (rocblas_stride)n, d_de + (size_t)nk * n, (rocblas_stride)n,
-            reinterpret_cast<rocblas_double_complex*>(d_tau), (rocblas_stride)n, (rocblas_int)nk));
-    }
-    return tbk_launch_ql(m, m->stream, d_de, nk, d_E);
-}
-
 int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E) {
     if (nk == 0 || m->n_orb == 0) return TBK_OK;
     const int n = m->n_orb;

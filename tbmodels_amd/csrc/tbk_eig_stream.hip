@@ -1,0 +1,333 @@
+// tbk_eig_stream.hip -- Householder tridiagonalisation for 64 < n_orb <= 512: one workgroup per matrix,
+// the matrix stays in HBM / L2; blocked and symmetric, so that per Householder step only the stored
+// (upper) triangle of the trailing matrix is READ, and it is written back once every NB steps.
+//
+// Reference step: scipy.linalg.eigvalsh per k-point (/root/reference/src/tbmodels/_tb_model.py:1147-1150).
+// Above 64 orbitals the matrix no longer fits the registers of a workgroup (tbk_eig_small.hip); rocSOLVER's
+// batched zhetrd needs 46 us per 256x256 matrix (hundreds of her2 / hemv launches) and 260 us at n = 512.
+// An unblocked reduction that streams the full matrix once per step is HBM bound at 2 * 16 n^3 / 3 bytes
+// per matrix (measured: 5.1 TB/s, 35 us at n = 256 -- no better than the vendor path).  So, LAPACK-latrd
+// style, the rank-2 updates are kept as a panel (V, W) of up to NB pairs in LDS and applied lazily:
+//
+//     1. column j of the up-to-date matrix = conj(row j of the stored triangle) - panel terms        O(n NB)
+//     2. reflector from it: beta, tau, v'                                                             O(n)
+//     3. ONE pass over the stored triangle of the trailing matrix, A[r][c], c >= r:
+//          (only when the panel is full: A[r][c] -= sum_b V_b[r] conj(W_b[c]) + W_b[r] conj(V_b[c]); store)
+//          u_r += A[r][c] v'_c          (row part: wave reduction)
+//          u_c += conj(A[r][c]) v'_r    (column part, c > r: per-lane accumulators, added wave by wave)
+//        and, while the panel is not applied, u -= V (W^H v') + W (V^H v')                          O(n NB)
+//     4. rho = v'^H u (real), w' = tau u - (|tau|^2 rho / 2) v';  append (v', w') to the panel        O(n)
+//
+// Traffic per matrix: 16 n^3 / 6 bytes of reads plus 2 * 16 n^3 / (6 NB) for the flushes -- 56 MB at
+// n = 256, NB = 8 instead of 178 MB.  Rows are contiguous in the stored triangle (the H(k) kernels' TRI
+// output is used as is), a wave owns whole rows (16 B per lane, coalesced), per-row scalars come from LDS,
+// summation order is fixed (no floating-point atomics): results are reproducible.
+
+#include <cstdlib>
+
+#include "tbk_internal.h"
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return v;
+}
+
+// barrier with explicit waits: LDS stores (lgkmcnt) and the global row stores other waves will re-read (vmcnt)
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+constexpr int ST_THREADS = 512;
+constexpr int ST_WAVES = ST_THREADS / 64;
+constexpr int ST_MAXN = 512;
+
+__device__ __forceinline__ d2 cmul(d2 a, d2 b) { return (d2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
+// a * conj(b)
+__device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1] * b[1], a[1] * b[0] - a[0] * b[1]}; }
+
+template <int NU, int NB>  // 64-column chunks per row (n <= 64 NU); panel width
+__global__ void __launch_bounds__(ST_THREADS)
+herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) double st_smem[];
+    constexpr int NP = 64 * NU;  // padded vector length
+    d2* sV = reinterpret_cast<d2*>(st_smem);  // [NB][NP] pending v
+    d2* sW = sV + NB * NP;                    // [NB][NP] pending w
+    d2* sx = sW + NB * NP;                    // [NP] column j, then the new reflector v'
+    d2* su = sx + NP;                         // [NP] u = A v'
+    __shared__ d2 stau;
+    __shared__ d2 sg[NB], sh[NB];             // W_b^H v', V_b^H v'
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t mat = blockIdx.x;
+    double* A = H + mat * (size_t)n * n * 2;
+    double* Dm = D + mat * (size_t)n;
+    double* Em = E + mat * (size_t)n;
+
+    for (int i = tid; i < (2 * NB + 2) * NP; i += ST_THREADS) sV[i] = (d2){0.0, 0.0};
+    int p = 0;  // pending (v, w) pairs in the panel
+    wg_sync();
+
+    for (int j = 0; j < n - 1; ++j) {
+        // ---- 1. column j of the up-to-date matrix, from row j of the stored triangle ----
+        for (int i = tid; i < NP; i += ST_THREADS) {
+            d2 x = (d2){0.0, 0.0};
+            if (i >= j && i < n) {
+                const d2 a = *reinterpret_cast<const d2*>(A + ((size_t)j * n + i) * 2);
+                x = (d2){a[0], -a[1]};
+                for (int b = 0; b < p; ++b) {
+                    const d2 t1 = cmulc(sV[b * NP + i], sW[b * NP + j]);
+                    const d2 t2 = cmulc(sW[b * NP + i], sV[b * NP + j]);
+                    x[0] -= t1[0] + t2[0];
+                    x[1] -= t1[1] + t2[1];
+                }
+            }
+            sx[i] = x;
+            su[i] = (d2){0.0, 0.0};
+        }
+        wg_sync();
+
+        // ---- 2. reflector (every wave computes the scalars; everyone writes its share of v') ----
+        {
+            double part = 0.0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = lane + 64 * u;
+                if (i > j + 1 && i < n) {
+                    const d2 x = sx[i];
+                    part = fma(x[0], x[0], part);
+                    part = fma(x[1], x[1], part);
+                }
+            }
+            const double sigma = wave_sum(part);
+            const d2 al = sx[j + 1];
+            const double alr = al[0], ali = al[1];
+            double tr = 0.0, ti = 0.0, scr = 0.0, sci = 0.0, one = 0.0, ej = alr;
+            if (!(sigma == 0.0 && ali == 0.0)) {
+                const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
+                const double rbeta = 1.0 / beta;
+                tr = (beta - alr) * rbeta;
+                ti = -ali * rbeta;
+                const double qr = alr - beta, qi = ali;
+                const double qn = 1.0 / (qr * qr + qi * qi);
+                scr = qr * qn;
+                sci = -qi * qn;
+                one = 1.0;
+                ej = beta;
+            }
+            const d2 dj = sx[j];
+            wg_sync();  // everyone has read x before it is overwritten by v'
+            if (tid == 0) {
+                Dm[j] = dj[0];
+                Em[j] = ej;
+                stau = (d2){tr, ti};
+            }
+            for (int i = tid; i < NP; i += ST_THREADS) {
+                d2 v = (d2){0.0, 0.0};
+                if (i > j + 1 && i < n) {
+                    v = cmul(sx[i], (d2){scr, sci});
+                } else if (i == j + 1) {
+                    v[0] = one;
+                }
+                sx[i] = v;  // a thread overwrites only the entries it read itself
+            }
+        }
+        wg_sync();
+        d2 nv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) nv[u] = sx[lane + 64 * u];
+
+        // ---- 3. one pass over the stored triangle of the trailing matrix ----
+        const bool flush = (p == NB);
+        d2 colacc[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) colacc[u] = (d2){0.0, 0.0};
+        for (int r = j + 1 + wave; r < n; r += ST_WAVES) {
+            const d2 vr = sx[r];
+            const int u_first = r >> 6;
+            double* row = A + (size_t)r * n * 2;
+            d2 rowsum = (d2){0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = lane + 64 * u;
+                if (u >= u_first && c >= r && c < n) {
+                    d2 a = *reinterpret_cast<const d2*>(row + (size_t)c * 2);
+                    if (flush) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const d2 t1 = cmulc(sV[b * NP + r], sW[b * NP + c]);
+                            const d2 t2 = cmulc(sW[b * NP + r], sV[b * NP + c]);
+                            a[0] -= t1[0] + t2[0];
+                            a[1] -= t1[1] + t2[1];
+                        }
+                        *reinterpret_cast<d2*>(row + (size_t)c * 2) = a;
+                    }
+                    const d2 t = cmul(a, nv[u]);
+                    rowsum[0] += t[0];
+                    rowsum[1] += t[1];
+                    if (c > r) {
+                        const d2 tc = cmulc(vr, a);  // conj(a) * v'_r
+                        colacc[u][0] += tc[0];
+                        colacc[u][1] += tc[1];
+                    }
+                }
+            }
+            const double sr = wave_sum(rowsum[0]);
+            const double si = wave_sum(rowsum[1]);
+            if (lane == 0) su[r] = (d2){sr, si};  // one writer per row
+        }
+        wg_sync();
+        // column parts, one wave after the other: fixed summation order
+        for (int w = 0; w < ST_WAVES; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = lane + 64 * u;
+                    const d2 t = su[c];
+                    su[c] = (d2){t[0] + colacc[u][0], t[1] + colacc[u][1]};
+                }
+            }
+            wg_sync();
+        }
+        // panel not applied to memory: u -= V (W^H v') + W (V^H v');  wave b reduces pair b
+        if (!flush && p > 0) {
+            if (wave < p) {
+                d2 g = (d2){0.0, 0.0}, h = (d2){0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int i = lane + 64 * u;
+                    const d2 tg = cmulc(nv[u], sW[wave * NP + i]);  // conj(W) v'
+                    const d2 th = cmulc(nv[u], sV[wave * NP + i]);
+                    g[0] += tg[0];
+                    g[1] += tg[1];
+                    h[0] += th[0];
+                    h[1] += th[1];
+                }
+                g[0] = wave_sum(g[0]);
+                g[1] = wave_sum(g[1]);
+                h[0] = wave_sum(h[0]);
+                h[1] = wave_sum(h[1]);
+                if (lane == 0) {
+                    sg[wave] = g;
+                    sh[wave] = h;
+                }
+            }
+            wg_sync();
+            for (int i = tid; i < NP; i += ST_THREADS) {
+                d2 acc = su[i];
+                for (int b = 0; b < p; ++b) {
+                    const d2 t1 = cmul(sV[b * NP + i], sg[b]);
+                    const d2 t2 = cmul(sW[b * NP + i], sh[b]);
+                    acc[0] -= t1[0] + t2[0];
+                    acc[1] -= t1[1] + t2[1];
+                }
+                su[i] = acc;
+            }
+            wg_sync();
+        }
+        if (flush) p = 0;
+
+        // ---- 4. w' = tau u - (|tau|^2 rho / 2) v', rho = v'^H u real; append (v', w') to the panel ----
+        {
+            double part = 0.0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = lane + 64 * u;
+                if (i > j && i < n) {
+                    const d2 uu = su[i];
+                    part = fma(nv[u][0], uu[0], part);
+                    part = fma(nv[u][1], uu[1], part);
+                }
+            }
+            const double rho = wave_sum(part);
+            const d2 tau = stau;
+            const double a2 = -0.5 * (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+            for (int i = tid; i < NP; i += ST_THREADS) {
+                const d2 v = sx[i];
+                d2 w = (d2){0.0, 0.0};
+                if (i > j && i < n) {
+                    const d2 t = cmul(su[i], tau);
+                    w[0] = fma(a2, v[0], t[0]);
+                    w[1] = fma(a2, v[1], t[1]);
+                }
+                sV[p * NP + i] = v;
+                sW[p * NP + i] = w;
+            }
+            ++p;
+        }
+        wg_sync();
+    }
+    // last diagonal element, with whatever is still pending in the panel
+    if (tid == 0) {
+        const int i = n - 1;
+        double d = A[((size_t)i * n + i) * 2];
+        for (int b = 0; b < p; ++b) {
+            const d2 v = sV[b * NP + i], w = sW[b * NP + i];
+            d -= 2.0 * (v[0] * w[0] + v[1] * w[1]);
+        }
+        Dm[i] = d;
+        Em[i] = 0.0;
+    }
+}
+
+template <int NU, int NB>
+hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E) {
+    const size_t lds = (size_t)(2 * NB + 2) * 64 * NU * sizeof(d2);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((herm_tridiag_stream_kernel<NU, NB>), dim3(nk), dim3(ST_THREADS), lds, s, d_H, n, d_D, d_E);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool tbk_eig_stream_supported(int n) { return n > 64 && n <= ST_MAXN; }
+
+// d_de: d[nk][n] followed by e[nk][n]; d_H (upper triangle of the row-major H) is overwritten
+int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de) {
+    const int n = m->n_orb;
+    if (nk == 0) return TBK_OK;
+    double* d_D = d_de;
+    double* d_Eo = d_de + (size_t)nk * n;
+    StageTimer t(m, TBK_T_EIG, s);
+    if (n <= 128)
+        TBK_HIP((launch_stream<2, 8>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+    else if (n <= 256)
+        TBK_HIP((launch_stream<4, 8>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+    else
+        TBK_HIP((launch_stream<8, 4>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+    return TBK_OK;
+}

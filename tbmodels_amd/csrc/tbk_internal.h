@@ -176,7 +176,10 @@ int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
 
 // tbk_eig.hip
 int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);    // full rocSOLVER zheevd
-int tbk_eig_hetrd_ql(tbk_model* m, double* d_H, int64_t nk, double* d_E);   // rocSOLVER zhetrd + own QL
+
+// tbk_eig_stream.hip
+bool tbk_eig_stream_supported(int n);
+int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
 size_t tbk_eig_scratch_per_k(const tbk_model* m);
 
 // tbk_eig_small.hip

@@ -282,3 +282,15 @@ def test_construct_kdotp(kdotp_golden, sparse):
     _close(kp.eigenval([0.0, 0.0, 0.0]), model.eigenval(g["k0"]))
     with pytest.raises(ValueError):
         model.construct_kdotp(g["k0"], -1)
+
+
+@pytest.mark.parametrize("n_r", [300, 700, 1500, 2400, 3000])
+def test_csr_kernel_variants(n_r):
+    """Every phase-tile width of the LDS sparse kernel (8/4/2/1 k-points) and the global-gather fallback."""
+    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(12, n_r, syn.MODEL_SEED + n_r, fill=0.2)
+    hop = syn.csr_to_dense(12, r_ptr, row, col, val)
+    k = syn.random_kpoints(77, seed=n_r)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=True)
+    _close(model.hamilton(k), oracle.hamilton(r_vec, hop, k))
+    _close(model.hamilton(k, convention=1), oracle.hamilton(r_vec, hop, k, 1, pos=pos))
+    _close(np.array(model.eigenval(k)), np.array(oracle.eigenval(r_vec, hop, k)))
