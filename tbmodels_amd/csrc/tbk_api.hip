@@ -285,7 +285,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_H2, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb};
     for (DevBuf* b : bufs) b->release();
     delete m;
 }
@@ -373,7 +373,13 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
         double* d_A = m->ws_phase.as<double>();
         const double* kc = d_k + c0 * m->dim;
         TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
-        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_FULL, convention, kc, d_pos, d_H + (size_t)c0 * nn2));
+        const double* d_orb = nullptr;
+        if (convention == 1) {
+            TBK_CHECK(m->ws_orb.reserve((size_t)nkc * m->n_orb * 2 * sizeof(double)));
+            TBK_CHECK(tbk_launch_orbital_phases(m, kc, d_pos, nkc, m->ws_orb.as<double>()));
+            d_orb = m->ws_orb.as<double>();
+        }
+        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_FULL, convention, kc, d_orb, d_H + (size_t)c0 * nn2));
     }
     return TBK_OK;
 }

@@ -80,11 +80,9 @@ hk_csr_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr,
         if (kq >= nk) break;
         double vr = re[q], vi = im[q];
         if (CONV == 1) {
-            double dot = 0.0;
-            for (int d = 0; d < dim; ++d)
-                dot = fma(kpts[kq * dim + d], pos[oj * dim + d] - pos[oi * dim + d], dot);
-            double sn, cs;
-            sincospi(2.0 * dot, &sn, &cs);
+            const d2 ei = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oi) * 2);  // e[k][p] table
+            const d2 ej = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oj) * 2);
+            const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
             const double t = vr * cs - vi * sn;
             vi = vr * sn + vi * cs;
             vr = t;
@@ -155,11 +153,9 @@ hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr
             if (kq >= nk) break;
             double vr = re[q], vi = im[q];
             if (CONV == 1) {
-                double dot = 0.0;
-                for (int d = 0; d < dim; ++d)
-                    dot = fma(kpts[kq * dim + d], pos[oj * dim + d] - pos[oi * dim + d], dot);
-                double sn, cs;
-                sincospi(2.0 * dot, &sn, &cs);
+                const d2 ei = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oi) * 2);  // e[k][p] table
+                const d2 ej = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oj) * 2);
+                const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
                 const double t = vr * cs - vi * sn;
                 vi = vr * sn + vi * cs;
                 vr = t;

@@ -46,8 +46,8 @@ struct HkArgs {
     const double* A;
     const double* Bt;
     const int32_t* colmap;
-    const double* kpts;  // [nk][dim], convention 1 only
-    const double* pos;   // [n_orb][dim], convention 1 only
+    const double* kpts;  // unused
+    const double* pos;   // convention 1 only: orbital phase table e[k][p] = exp(2 pi i k.pos_p), [nk][n_orb][2]
     double* H;
     int64_t k2;
     int64_t nk;
@@ -192,12 +192,11 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                 double re = acc[i][j][0][r];
                 double im = acc[i][j][1][r];
                 if (CONV == 1) {
-                    // H[i][j] *= conj(e_i) e_j,  e_p = exp(2 pi i k.pos_p)   (_tb_model.py:1124-1128)
-                    double dot = 0.0;
-                    for (int d = 0; d < a.dim; ++d)
-                        dot = fma(a.kpts[kq * a.dim + d], a.pos[oj * a.dim + d] - a.pos[oi * a.dim + d], dot);
-                    double sn, cs;
-                    sincospi(2.0 * dot, &sn, &cs);
+                    // H[i][j] *= conj(e_i) e_j,  e_p = exp(2 pi i k.pos_p)   (_tb_model.py:1124-1128);
+                    // the table e[k][p] is filled once per chunk by tbk_launch_orbital_phases
+                    const d2 ei = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oi) * 2);
+                    const d2 ej = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oj) * 2);
+                    const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
                     const double t = re * cs - im * sn;
                     im = re * sn + im * cs;
                     re = t;

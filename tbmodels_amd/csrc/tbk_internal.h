@@ -130,6 +130,7 @@ struct tbk_model {
     DevBuf ws_info;   // [chunk] int
     DevBuf ws_k;      // host-entry staging of k / pos / E
     DevBuf ws_pos;
+    DevBuf ws_orb;    // convention 1: orbital phase table of the current chunk
     DevBuf ws_out;
     DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
     std::vector<EventPair> events;
@@ -158,6 +159,7 @@ enum HkMode { HK_TRI = 0, HK_FULL = 1 };
 
 // tbk_phase.hip
 int tbk_launch_phase(tbk_model* m, const double* d_k, int64_t nk, int64_t nk_pad, double* d_A);
+int tbk_launch_orbital_phases(tbk_model* m, const double* d_k, const double* d_pos, int64_t nk, double* d_orb);
 int tbk_launch_monomials(hipStream_t s, const int32_t* d_powers, int dim, int64_t n_p,
                          int64_t n_p_pad, const double* d_k, int64_t nk, int64_t nk_pad,
                          double* d_A);

@@ -58,7 +58,32 @@ monomial_rows_kernel(const double* __restrict__ k, const int32_t* __restrict__ p
     A[p * nk_pad + kidx] = v;
 }
 
+// convention 1 (_tb_model.py:1124-1128): e[k][p] = exp(2 pi i k.pos_p), one (cos, sin) pair per (k, orbital)
+__global__ void __launch_bounds__(256)
+orbital_phase_kernel(const double* __restrict__ k, const double* __restrict__ pos, int dim, int64_t nk,
+                     int n_orb, double* __restrict__ orb) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nk * n_orb) return;
+    const int64_t kq = idx / n_orb;
+    const int p = (int)(idx % n_orb);
+    double dot = 0.0;
+    for (int d = 0; d < dim; ++d) dot = fma(k[kq * dim + d], pos[p * dim + d], dot);
+    double s, c;
+    sincospi(2.0 * dot, &s, &c);
+    orb[2 * idx] = c;
+    orb[2 * idx + 1] = s;
+}
+
 }  // namespace
+
+int tbk_launch_orbital_phases(tbk_model* m, const double* d_k, const double* d_pos, int64_t nk, double* d_orb) {
+    if (nk == 0) return TBK_OK;
+    const int64_t total = nk * m->n_orb;
+    hipLaunchKernelGGL(orbital_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, d_k,
+                       d_pos, m->dim, nk, m->n_orb, d_orb);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
 
 int tbk_launch_phase(tbk_model* m, const double* d_k, int64_t nk, int64_t nk_pad, double* d_A) {
     if (m->n_r_pad == 0 || nk_pad == 0) return TBK_OK;
