@@ -394,6 +394,12 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // it only displaces its workgroups.  The two eigensolver kernels are complementary -- the reduction is
 // VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
 // workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
+// tridiagonal stage on the QL stream: lane-per-matrix QL up to 64 orbitals, bisection above
+static int launch_tridiag_eigenvalues(tbk_model* m, const double* d_de, int64_t nk, double* d_E) {
+    if (tbk_eig_small_supported(m->n_orb)) return tbk_launch_ql(m, m->stream_ql, d_de, nk, d_E);
+    return tbk_launch_bisect(m, m->stream_ql, d_de, nk, d_E);
+}
+
 static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
     const int64_t chunk = choose_chunk(m, nk, true);
     const size_t n = (size_t)m->n_orb;
@@ -432,8 +438,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
 
         if (c >= 1) {  // QL of the previous chunk, alongside this chunk's reduction
             TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
-            TBK_CHECK(tbk_launch_ql(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
-                                    d_E + (size_t)prev_c0 * n));
+            TBK_CHECK(launch_tridiag_eigenvalues(m, debuf[b ^ 1]->as<double>(), prev_nkc, d_E + (size_t)prev_c0 * n));
             TBK_HIP(hipEventRecord(m->ev_ql[b ^ 1], m->stream_ql));
         }
         prev_c0 = c0;
@@ -442,7 +447,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     {  // QL of the last chunk
         const int b = (int)((n_chunks - 1) & 1);
         TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b], 0));
-        TBK_CHECK(tbk_launch_ql(m, m->stream_ql, debuf[b]->as<double>(), prev_nkc, d_E + (size_t)prev_c0 * n));
+        TBK_CHECK(launch_tridiag_eigenvalues(m, debuf[b]->as<double>(), prev_nkc, d_E + (size_t)prev_c0 * n));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_ql));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues

@@ -23,8 +23,6 @@
 // output is used as is), a wave owns whole rows (16 B per lane, coalesced), per-row scalars come from LDS,
 // summation order is fixed (no floating-point atomics): results are reproducible.
 
-#include <cstdlib>
-
 #include "tbk_internal.h"
 
 namespace {
@@ -298,6 +296,102 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Eigenvalues of the tridiagonal (d, e) by bisection on Sturm counts: one workgroup per matrix, one
+// lane per eigenvalue (lane m brackets the m-th smallest, so the output is ascending by construction).
+// The lane-per-matrix QL of tbk_eig_small.hip is a serial chain of O(n^2) dependent steps per matrix:
+// at n = 256 it ran 71 ms per 8192 matrices on half-empty SIMDs and held 64 KiB of LDS per block, which
+// kept a second reduction workgroup off every CU.  Here the n * ~55 Sturm sweeps of a matrix run in
+// parallel lanes, (d, e^2) are broadcast from 8 KiB of LDS, and there is no division in the sweep:
+// the characteristic polynomials p_i(x) = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} are carried directly and
+// rescaled by a power of two every 8 steps; the number of sign changes is the number of eigenvalues < x.
+// Accuracy: the bracket is halved until it is below 2 ulp of the spectrum's scale (backward stable).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(ST_MAXN)
+tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E, int n, double* __restrict__ out) {
+    __shared__ double sd[ST_MAXN];
+    __shared__ double se2[ST_MAXN];  // se2[i] = e_i^2 couples i and i+1
+    __shared__ double sred[2][ST_MAXN / 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nwave = blockDim.x >> 6;
+    const size_t mat = blockIdx.x;
+    double lo_g = 1e300, hi_g = -1e300;
+    if (tid < n) {
+        const double d = D[mat * n + tid];
+        const double e = (tid < n - 1) ? E[mat * n + tid] : 0.0;
+        const double em = (tid > 0) ? E[mat * n + tid - 1] : 0.0;
+        sd[tid] = d;
+        se2[tid] = e * e;
+        const double rad = fabs(e) + fabs(em);  // Gershgorin disc
+        lo_g = d - rad;
+        hi_g = d + rad;
+    }
+    lo_g = wave_min(lo_g);
+    hi_g = wave_max(hi_g);
+    if (lane == 0) {
+        sred[0][wave] = lo_g;
+        sred[1][wave] = hi_g;
+    }
+    __syncthreads();
+    double gl = sred[0][0], gu = sred[1][0];
+    for (int w = 1; w < nwave; ++w) {
+        gl = fmin(gl, sred[0][w]);
+        gu = fmax(gu, sred[1][w]);
+    }
+    const double scale = fmax(fabs(gl), fabs(gu));
+    const double slack = 4.0 * 2.220446049250313e-16 * scale * n + 1e-300;
+    double lo = gl - slack, hi = gu + slack;
+    const double tol = 2.0 * 2.220446049250313e-16 * scale + 1e-300;
+    // same trip count for every lane: halve the Gershgorin interval down to `tol`
+    int iters = 2;
+    for (double w = hi - lo; w > tol && iters < 1100; w *= 0.5) ++iters;
+
+    const int m = tid;  // this lane's eigenvalue index
+    for (int it = 0; it < iters; ++it) {
+        const double x = 0.5 * (lo + hi);
+        // Sturm count at x
+        double pp = 1.0, p = sd[0] - x;
+        int cnt = (p < 0.0 || p == 0.0) ? 1 : 0;  // a zero takes the sign opposite to its predecessor (+1)
+        bool neg = cnt != 0;
+        for (int i0 = 1; i0 < n; i0 += 8) {
+            const int i1 = min(i0 + 8, n);
+            for (int i = i0; i < i1; ++i) {
+                const double pn = fma(sd[i] - x, p, -se2[i - 1] * pp);
+                pp = p;
+                p = pn;
+                const bool nneg = (p < 0.0) || (p == 0.0 && !neg);
+                cnt += (nneg != neg) ? 1 : 0;
+                neg = nneg;
+            }
+            // rescale (p, pp) by a common power of two: signs and the recurrence are unaffected
+            const double big = fmax(fabs(p), fabs(pp));
+            if (big > 0.0) {
+                const int ex = -ilogb(big);
+                p = ldexp(p, ex);
+                pp = ldexp(pp, ex);
+            }
+        }
+        if (cnt > m)
+            hi = x;  // more than m eigenvalues below x: the m-th lies left of x
+        else
+            lo = x;
+    }
+    if (tid < n) out[mat * n + tid] = 0.5 * (lo + hi);
+}
+
 template <int NU, int NB>
 hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E) {
     const size_t lds = (size_t)(2 * NB + 2) * 64 * NU * sizeof(d2);
@@ -329,5 +423,17 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
         TBK_HIP((launch_stream<4, 8>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     else
         TBK_HIP((launch_stream<8, 4>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+    return TBK_OK;
+}
+
+// eigenvalues of the tridiagonals d_de = (d[nk][n], e[nk][n]) -> d_E[nk][n], ascending
+int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E) {
+    const int n = m->n_orb;
+    if (nk == 0) return TBK_OK;
+    StageTimer t(m, TBK_T_QL, s);
+    const int threads = (n + 63) / 64 * 64;
+    hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)nk), dim3(threads), 0, s, d_de, d_de + (size_t)nk * n, n,
+                       d_E);
+    TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
