@@ -198,7 +198,15 @@ def main():
         if group is not None:
             uid = np.frombuffer(group.broadcast_bytes(uid.tobytes(), src=0), dtype=np.uint8).copy()
         comm = ctypes.c_void_p()
-        status = lib.tbk_comm_create(device, world, rank, _lib.ptr(uid), ctypes.byref(comm))
+        # RCCL prints a version banner when a communicator is created; keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            status = lib.tbk_comm_create(device, world, rank, _lib.ptr(uid), ctypes.byref(comm))
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         all_ok = (status == 0) if group is None else group.allreduce_min(1.0 if status == 0 else 0.0) == 1.0
         if all_ok:
             collective = "rccl all-gather (xGMI), device buffers"
