@@ -181,7 +181,8 @@ def main():
     d_k = dmalloc(k_slab.nbytes)
     _lib.check(lib.tbk_memcpy_h2d(device, d_k, _lib.ptr(k_slab), k_slab.nbytes))
     e_count = nk_gpu * n_orb
-    d_e = dmalloc(e_count * 8)
+    d_e_pair = [dmalloc(e_count * 8), dmalloc(e_count * 8)]  # alternate per step: a gather may still read one
+    d_e = d_e_pair[0]
     d_h = None
     if args.construct_only:
         d_h = dmalloc(nk_gpu * n_orb * n_orb * 16)
@@ -191,7 +192,8 @@ def main():
     host_gather = None
     force_comm = os.environ.get("TBK_BENCH_FORCE_COMM") == "1"  # exercise RCCL with a 1-rank communicator
     if world > 1 or force_comm:
-        d_gather = dmalloc(world * e_count * 8)
+        d_gather_pair = [dmalloc(world * e_count * 8), dmalloc(world * e_count * 8)]
+        d_gather = d_gather_pair[0]
         uid = np.zeros(128, dtype=np.uint8)
         if rank == 0:
             _lib.check(lib.tbk_comm_unique_id(_lib.ptr(uid)))
@@ -209,7 +211,7 @@ def main():
             os.close(saved_stdout)
         all_ok = (status == 0) if group is None else group.allreduce_min(1.0 if status == 0 else 0.0) == 1.0
         if all_ok:
-            collective = "rccl all-gather (xGMI), device buffers"
+            collective = "rccl all-gather (xGMI) of device buffers on its own stream, overlapping the next step"
         else:
             # e.g. several ranks sharing one GPU: RCCL refuses; gather on the host instead and say so
             sys.stderr.write("[bench] RCCL communicator unavailable (%s); falling back to a host all-gather\n"
@@ -221,22 +223,33 @@ def main():
             h_slab = np.empty((nk_gpu, n_orb))
 
             def host_gather():
-                _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(h_slab), d_e, h_slab.nbytes))
+                _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(h_slab), d_e_pair[(step_no[0] - 1) & 1], h_slab.nbytes))
                 group.all_gather_array(h_slab)
+
+    step_no = [0]
 
     def step():
         if args.construct_only:
             _lib.check(lib.tbk_hamilton_device(model, d_k, nk_gpu, 2, None, d_h))
             return
-        _lib.check(lib.tbk_eigenval_device(model, d_k, nk_gpu, d_e))
+        # the all-gather of step s runs on the communicator's stream under the kernels of step s+1; the
+        # eigenvalue / gather buffers alternate, and before a pair is reused its gather (two steps back) is done
+        pair = step_no[0] & 1
+        step_no[0] += 1
+        d_out = d_e_pair[pair]
         if comm is not None:
-            _lib.check(lib.tbk_comm_allgather_f64(comm, model, d_e, d_gather, e_count))
+            _lib.check(lib.tbk_comm_wait_slot(comm, model, pair))
+        _lib.check(lib.tbk_eigenval_device(model, d_k, nk_gpu, d_out))
+        if comm is not None:
+            _lib.check(lib.tbk_comm_allgather_f64_overlapped(comm, model, d_out, d_gather_pair[pair], e_count, pair))
         elif host_gather is not None:
             _lib.check(lib.tbk_synchronize(model))
             host_gather()
 
     def barrier():
         _lib.check(lib.tbk_synchronize(model))
+        if comm is not None:
+            _lib.check(lib.tbk_comm_synchronize(comm))
         if group is not None:
             group.barrier()
 
@@ -271,6 +284,7 @@ def main():
     eig_head = np.empty((min(nk_gpu, 64), n_orb))
     trace_err = None
     if not args.construct_only and rank == 0:
+        d_e = d_e_pair[(step_no[0] - 1) & 1]  # the buffer of the last step
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_head), d_e, eig_head.nbytes))
         eig_all = np.empty((nk_gpu, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_all), d_e, eig_all.nbytes))

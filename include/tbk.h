@@ -142,6 +142,14 @@ void tbk_comm_destroy(tbk_comm* c);
  * receives world_size * count doubles in rank order in d_recv.  Enqueued on `m`'s stream. */
 int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
                            int64_t count);
+/* The same gather on the communicator's own stream: it starts once the work enqueued on `m`'s stream so far
+ * is complete and overlaps whatever is enqueued on `m` afterwards.  Callers alternate two (send, recv) pairs,
+ * slot 0 / 1; tbk_comm_wait_slot makes `m`'s stream wait for the previous gather of a slot before its buffers
+ * are written again (stream dependency, the host does not block); tbk_comm_synchronize waits on the host. */
+int tbk_comm_allgather_f64_overlapped(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
+                                      int64_t count, int slot);
+int tbk_comm_wait_slot(tbk_comm* c, tbk_model* m, int slot);
+int tbk_comm_synchronize(tbk_comm* c);
 
 /* ---- microbenchmark: sustained v_mfma_f64_16x16x4_f64 rate of the device (TFLOP/s) -------- */
 int tbk_mfma_f64_peak(int device, double* tflops);

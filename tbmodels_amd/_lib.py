@@ -67,6 +67,9 @@ SIGNATURES = {
     "tbk_comm_create": (_c_int, [_c_int, _c_int, _c_int, _vp, _pp]),
     "tbk_comm_destroy": (None, [_vp]),
     "tbk_comm_allgather_f64": (_c_int, [_vp, _vp, _vp, _vp, _c_i64]),
+    "tbk_comm_allgather_f64_overlapped": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int]),
+    "tbk_comm_wait_slot": (_c_int, [_vp, _vp, _c_int]),
+    "tbk_comm_synchronize": (_c_int, [_vp]),
     "tbk_mfma_f64_peak": (_c_int, [_c_int, ctypes.POINTER(ctypes.c_double)]),
 }
 

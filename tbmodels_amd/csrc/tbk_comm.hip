@@ -18,6 +18,9 @@ struct tbk_comm {
     int world = 1;
     int rank = 0;
     ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;  // collectives that overlap the next batch's kernels run here
+    hipEvent_t ready = nullptr;    // "the send buffer is complete" on the model's stream
+    hipEvent_t done[2] = {nullptr, nullptr};  // gather of buffer slot 0 / 1 finished
 };
 
 #define TBK_NCCL(expr)                                                                           \
@@ -61,6 +64,14 @@ extern "C" int tbk_comm_create(int device, int world_size, int rank, const void*
         delete c;
         return TBK_ERR_DEVICE;
     }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess) {
+        tbk_set_error("cannot create the communicator's stream / event");
+        tbk_comm_destroy(c);
+        return TBK_ERR_DEVICE;
+    }
     *out = c;
     return TBK_OK;
 }
@@ -68,7 +79,12 @@ extern "C" int tbk_comm_create(int device, int world_size, int rank, const void*
 extern "C" void tbk_comm_destroy(tbk_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    for (hipEvent_t e : c->done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -80,5 +96,39 @@ extern "C" int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d
     TBK_ARG(d_send && d_recv, "send / recv is NULL");
     TBK_HIP(hipSetDevice(c->device));
     TBK_NCCL(ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, m->stream));
+    return TBK_OK;
+}
+
+// Same exchange, off the model's stream: the gather starts when everything enqueued on the model's stream so
+// far has finished, and runs on the communicator's own stream -- the next batch's kernels overlap it.
+// Callers alternate two (send, recv) buffer pairs, `slot` 0 / 1; before a pair is written again,
+// tbk_comm_wait_slot makes the model's stream wait for that pair's previous gather (a stream dependency, the
+// host does not block).
+extern "C" int tbk_comm_allgather_f64_overlapped(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
+                                                 int64_t count, int slot) {
+    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
+    TBK_ARG(count >= 0 && (slot == 0 || slot == 1), "bad count / slot");
+    if (count == 0) return TBK_OK;
+    TBK_ARG(d_send && d_recv, "send / recv is NULL");
+    TBK_HIP(hipSetDevice(c->device));
+    TBK_HIP(hipEventRecord(c->ready, m->stream));
+    TBK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    TBK_NCCL(ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, c->stream));
+    TBK_HIP(hipEventRecord(c->done[slot], c->stream));
+    return TBK_OK;
+}
+
+extern "C" int tbk_comm_wait_slot(tbk_comm* c, tbk_model* m, int slot) {
+    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
+    TBK_ARG(slot == 0 || slot == 1, "bad slot");
+    TBK_HIP(hipSetDevice(c->device));
+    TBK_HIP(hipStreamWaitEvent(m->stream, c->done[slot], 0));  // no-op if the slot was never used
+    return TBK_OK;
+}
+
+extern "C" int tbk_comm_synchronize(tbk_comm* c) {
+    TBK_ARG(c != nullptr, "comm is NULL");
+    TBK_HIP(hipSetDevice(c->device));
+    TBK_HIP(hipStreamSynchronize(c->stream));
     return TBK_OK;
 }
