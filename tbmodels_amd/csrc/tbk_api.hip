@@ -395,9 +395,35 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
 // workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
 // tridiagonal stage on the QL stream: lane-per-matrix QL up to 64 orbitals, bisection above
-static int launch_tridiag_eigenvalues(tbk_model* m, const double* d_de, int64_t nk, double* d_E) {
-    if (tbk_eig_small_supported(m->n_orb)) return tbk_launch_ql(m, m->stream_ql, d_de, nk, d_E);
-    return tbk_launch_bisect(m, m->stream_ql, d_de, nk, d_E);
+static int launch_tridiag_eigenvalues(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E,
+                                      bool beside_ql = false) {
+    if (tbk_eig_small_supported(m->n_orb)) return tbk_launch_ql(m, s, d_de, nk, d_E, beside_ql);
+    return tbk_launch_bisect(m, s, d_de, nk, d_E);
+}
+
+// k chunks of the pipeline.  The lane-per-matrix QL is a latency chain (~3 ms however few matrices it
+// gets), and the QL of the last chunk has nothing to hide behind: the schedule therefore ends on a short
+// chunk (one XCD round of k tiles plus the ragged remainder) whose reduction is brief, and that chunk's QL
+// runs next to the QL of the chunk before it.  All other chunks are multiples of 4096 k-points.
+static std::vector<int64_t> chunk_schedule(tbk_model* m, int64_t nk, int64_t chunk) {
+    std::vector<int64_t> out;
+    const int64_t unit = 4096;
+    if (!tbk_eig_small_supported(m->n_orb) || m->k_chunk > 0 || chunk < 2 * unit || nk < 3 * unit) {
+        for (int64_t c0 = 0; c0 < nk; c0 += chunk) out.push_back(std::min(chunk, nk - c0));
+        return out;
+    }
+    const int64_t last = unit + nk % unit;  // in [4096, 8192)
+    int64_t rest = nk - last;               // a multiple of 4096
+    const int64_t n_big = (rest + chunk - 1) / chunk;
+    for (int64_t i = 0; i < n_big; ++i) {
+        // as even as whole units allow, larger chunks first
+        const int64_t share = round_up((rest + (n_big - i) - 1) / (n_big - i), unit);
+        const int64_t take = std::min(std::min(share, chunk), rest);
+        out.push_back(take);
+        rest -= take;
+    }
+    out.push_back(last);
+    return out;
 }
 
 static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
@@ -405,18 +431,19 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const size_t n = (size_t)m->n_orb;
     const size_t nn2 = n * n * 2;
     DevBuf* debuf[2] = {&m->ws_E, &m->ws_E2};
-    const int64_t n_chunks = (nk + chunk - 1) / chunk;
-    TBK_CHECK(m->ws_H.reserve((size_t)std::min(chunk, nk) * nn2 * sizeof(double)));
+    const std::vector<int64_t> sched = chunk_schedule(m, nk, chunk);
+    const int64_t n_chunks = (int64_t)sched.size();
+    const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
+    TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
-        TBK_CHECK(debuf[b]->reserve((size_t)std::min(chunk, nk) * n * 2 * sizeof(double)));
+        TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
     double* d_H = m->ws_H.as<double>();
-    int64_t prev_c0 = 0, prev_nkc = 0;
+    int64_t prev_c0 = 0, prev_nkc = 0, c0 = 0;
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int b = (int)(c & 1);
-        const int64_t c0 = c * chunk;
-        const int64_t nkc = std::min(chunk, nk - c0);
+        const int64_t nkc = sched[c];
         const int64_t nk_pad = phase_ld(nkc);
-        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * phase_ld(max_chunk) * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();
         double* d_de = debuf[b]->as<double>();
         const double* kc = d_k + c0 * m->dim;
@@ -438,17 +465,19 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
 
         if (c >= 1) {  // QL of the previous chunk, alongside this chunk's reduction
             TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
-            TBK_CHECK(launch_tridiag_eigenvalues(m, debuf[b ^ 1]->as<double>(), prev_nkc, d_E + (size_t)prev_c0 * n));
+            TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
+                                                 d_E + (size_t)prev_c0 * n));
             TBK_HIP(hipEventRecord(m->ev_ql[b ^ 1], m->stream_ql));
         }
         prev_c0 = c0;
         prev_nkc = nkc;
+        c0 += nkc;
     }
-    {  // QL of the last chunk
+    {  // QL of the last chunk: behind its own reduction on the eig stream, i.e. next to QL(last - 1)
         const int b = (int)((n_chunks - 1) & 1);
-        TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b], 0));
-        TBK_CHECK(launch_tridiag_eigenvalues(m, debuf[b]->as<double>(), prev_nkc, d_E + (size_t)prev_c0 * n));
-        TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_ql));
+        TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_eig, debuf[b]->as<double>(), prev_nkc,
+                                             d_E + (size_t)prev_c0 * n, n_chunks > 1));
+        TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_eig));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));

@@ -34,8 +34,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);  // bound_ctrl: no 'old' to materialise
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -276,15 +276,31 @@ herm_tridiag_kernel(const double* __restrict__ H, int n, double* __restrict__ D,
 // two workgroup barriers; v and w are recomputed by every wave (each has all rows) and broadcast
 // from a wave-private LDS copy, which needs no barrier.
 // ------------------------------------------------------------------------------------------------
+// Householder scalars of one step, computed ONCE per matrix by the wave that owns the column and passed to
+// the other three through LDS (the f64 sqrt / divisions and the norm reduction cost ~100 VALU issues).
+struct HhScalars {
+    d2 scale;  // 1 / (alpha - beta): v = x * scale below the pivot
+    d2 tau;    // (beta - alpha) / beta
+    d2 flag;   // [0] != 0: column already reduced (H = I), [1] unused
+};
+
 template <int NR>
 __global__ void __launch_bounds__(256)
 herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
     constexpr int NW = 4;        // waves per matrix
     constexpr int NT = NR / NW;  // columns per lane
-    __shared__ d2 sx[2][NR];     // Householder column of step j (double-buffered across steps)
+    constexpr int TB = 2;        // column groups per skip block
+    typedef double dcol __attribute__((ext_vector_type(NT)));  // register array with a (uniform) dynamic index
+    // 7 KiB of LDS per matrix: four resident workgroups leave room for two 64 KiB QL workgroups on the CU
+    // (the QL of the previous chunk runs beside this kernel and must fit in one round).
+    __shared__ d2 sx[NR];        // Householder column of step j: written after B2(j - 1), read after B1(j)
+    __shared__ HhScalars ssc;    // its scalars
     __shared__ d2 sp[NW][NR];    // per-wave partial products
-    __shared__ d2 sv[NW][NR];    // per-wave copy of v
-    __shared__ d2 sw[NW][NR];    // per-wave copy of w
+    // v and w: every wave computes the same bits and stores them to the SAME slots, then reads back
+    // through its own LDS queue (ordered behind its own store) -- no barrier, one copy.  The next step's
+    // stores are behind B1 / B2, i.e. after every wave's reads of this step.
+    __shared__ d2 sv[NR];
+    __shared__ d2 sw[NR];
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t mat = blockIdx.x;
@@ -292,7 +308,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     double* Dm = D + mat * (size_t)n;
     double* Em = E + mat * (size_t)n;
 
-    double ar[NT], ai[NT];
+    dcol ar, ai;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int c = NW * t + q;
@@ -311,64 +327,86 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         ar[t] = re;
         ai[t] = im;
     }
-    if (q == 0 && lane < NR) sx[0][lane] = (d2){ar[0], ai[0]};  // column 0 lives in wave 0, t = 0
+
+    // The owner of column jc publishes it (x, lane i = A[i][jc]) with the scalars of the reflector that
+    // annihilates it below the sub-diagonal, and stores d[jc], e[jc].
+    auto publish = [&](int jc) {
+        const int tsel = jc / NW;
+        const double xr = ar[tsel], xi = ai[tsel];  // uniform dynamic index
+        if (lane < NR) sx[lane] = (d2){xr, xi};
+        if (lane == jc) Dm[jc] = xr;
+        if (jc >= n - 1) {
+            if (lane == 0) Em[n - 1] = 0.0;
+            return;
+        }
+        const double alr = bcast(xr, jc + 1), ali = bcast(xi, jc + 1);
+        const bool below = (lane > jc + 1) && (lane < n);
+        const double sigma = wave_sum(below ? (xr * xr + xi * xi) : 0.0);
+        HhScalars sc;
+        double e_out;
+        if (sigma == 0.0 && ali == 0.0) {
+            sc.scale = (d2){0.0, 0.0};
+            sc.tau = (d2){0.0, 0.0};
+            sc.flag = (d2){1.0, 0.0};
+            e_out = alr;
+        } else {
+            const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
+            const double rbeta = 1.0 / beta;
+            const double qr = alr - beta, qi = ali;
+            const double qn = 1.0 / (qr * qr + qi * qi);
+            sc.scale = (d2){qr * qn, -qi * qn};
+            sc.tau = (d2){(beta - alr) * rbeta, -ali * rbeta};
+            sc.flag = (d2){0.0, 0.0};
+            e_out = beta;
+        }
+        if (lane == 0) {
+            ssc = sc;
+            Em[jc] = e_out;
+        }
+    };
+    if (q == 0) publish(0);
 
     for (int j = 0; j < n - 1; ++j) {
-        const int buf = j & 1;
-        wg_sync();  // B1: sx[buf] = column j
-        const d2 xme = (lane < NR) ? sx[buf][lane] : (d2){0.0, 0.0};
-        const double xr = xme[0], xi = xme[1];
-        if (q == 0 && lane == j) Dm[j] = xr;
-        const d2 al = sx[buf][j + 1];
-        const double alr = al[0], ali = al[1];
-        const bool below = (lane > j + 1) && (lane < n);
-        const double sigma = wave_sum(below ? (xr * xr + xi * xi) : 0.0);
-
-        const int jn = j + 1;          // next column, owned by wave jn % 4 at local index jn / 4
+        wg_sync();  // B1: sx, ssc describe column j
+        const d2 xme = (lane < NR) ? sx[lane] : (d2){0.0, 0.0};
+        const HhScalars sc = ssc;
+        const int jn = j + 1;  // next column, owned by wave jn % 4
         const bool own_next = (jn & (NW - 1)) == q;
-        double nxr = 0.0, nxi = 0.0;
-        if (sigma == 0.0 && ali == 0.0) {
-            if (q == 0 && lane == 0) Em[j] = alr;
-            if (own_next) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (t == jn / NW) {
-                        nxr = ar[t];
-                        nxi = ai[t];
-                    }
-                if (lane < NR) sx[buf ^ 1][lane] = (d2){nxr, nxi};
-            }
-            wg_sync();  // keep the barrier count of both branches equal
+        if (__builtin_amdgcn_readfirstlane(__double2hiint(sc.flag[0])) != 0) {
+            wg_sync();  // B2 (keeps the barrier count of both branches equal; orders the reads above)
+            if (own_next) publish(jn);
             continue;
         }
-        const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
-        const double rbeta = 1.0 / beta;
-        const double tr = (beta - alr) * rbeta, ti = -ali * rbeta;
-        const double qr = alr - beta, qi = ali;
-        const double qn = 1.0 / (qr * qr + qi * qi);
-        const double scr = qr * qn, sci = -qi * qn;
-        if (q == 0 && lane == 0) Em[j] = beta;
-
+        const double xr = xme[0], xi = xme[1];
+        const double tr = sc.tau[0], ti = sc.tau[1];
+        const bool below = (lane > j + 1) && (lane < n);
         double vr = 0.0, vi = 0.0;
         if (below) {
-            vr = xr * scr - xi * sci;
-            vi = xr * sci + xi * scr;
+            vr = xr * sc.scale[0] - xi * sc.scale[1];
+            vi = xr * sc.scale[1] + xi * sc.scale[0];
         } else if (lane == j + 1) {
             vr = 1.0;
         }
-        if (lane < NR) sv[q][lane] = (d2){vr, vi};  // wave-private: ordered by this wave's own LDS queue
+        if (lane < NR) sv[lane] = (d2){vr, vi};
 
-        // partial p = A v over this wave's columns
+        // partial p = A v over this wave's columns.  (Retired columns carry v = w = 0, so skipping them is
+        // only an optimisation: it is done per block of TB column groups so that the TB broadcast reads of v
+        // are in flight together.)
         double par[2] = {0.0, 0.0}, pai[2] = {0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = NW * t + q;
-            if (NW * t + (NW - 1) > j) {  // uniform: any column of this group still active
-                const d2 vc = sv[q][c];
-                par[t & 1] = fma(ar[t], vc[0], par[t & 1]);
-                pai[t & 1] = fma(ar[t], vc[1], pai[t & 1]);
-                par[t & 1] = fma(-ai[t], vc[1], par[t & 1]);
-                pai[t & 1] = fma(ai[t], vc[0], pai[t & 1]);
+        for (int tb = 0; tb < NT; tb += TB) {
+            if (NW * (tb + TB) - 1 > j) {  // uniform: any column of this block still active
+                d2 vc[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) vc[u] = sv[NW * (tb + u) + q];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    const int t = tb + u;
+                    par[t & 1] = fma(ar[t], vc[u][0], par[t & 1]);
+                    pai[t & 1] = fma(ar[t], vc[u][1], pai[t & 1]);
+                    par[t & 1] = fma(-ai[t], vc[u][1], par[t & 1]);
+                    pai[t & 1] = fma(ai[t], vc[u][0], pai[t & 1]);
+                }
             }
         }
         if (lane < NR) sp[q][lane] = (d2){par[0] + par[1], pai[0] + pai[1]};
@@ -389,41 +427,37 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         const double a2 = -0.5 * (tr * tr + ti * ti) * rho;
         const double wr = fma(a2, vr, pr * tr - pi * ti);
         const double wi = fma(a2, vi, pr * ti + pi * tr);
-        if (lane < NR) sw[q][lane] = (d2){wr, wi};
+        if (lane < NR) sw[lane] = (d2){wr, wi};
 
         // A -= v w^H + w v^H on this wave's columns
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = NW * t + q;
-            if (NW * t + (NW - 1) > j) {
-                const d2 vc = sv[q][c];
-                const d2 wc = sw[q][c];
-                double r = ar[t], m = ai[t];
-                r = fma(-vr, wc[0], r);
-                m = fma(-vi, wc[0], m);
-                r = fma(-vi, wc[1], r);
-                m = fma(vr, wc[1], m);
-                r = fma(-wr, vc[0], r);
-                m = fma(-wi, vc[0], m);
-                r = fma(-wi, vc[1], r);
-                m = fma(wr, vc[1], m);
-                ar[t] = r;
-                ai[t] = m;
+        for (int tb = 0; tb < NT; tb += TB) {
+            if (NW * (tb + TB) - 1 > j) {
+                d2 vc[TB], wc[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    vc[u] = sv[NW * (tb + u) + q];
+                    wc[u] = sw[NW * (tb + u) + q];
+                }
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    const int t = tb + u;
+                    double r = ar[t], m = ai[t];
+                    r = fma(-vr, wc[u][0], r);
+                    m = fma(-vi, wc[u][0], m);
+                    r = fma(-vi, wc[u][1], r);
+                    m = fma(vr, wc[u][1], m);
+                    r = fma(-wr, vc[u][0], r);
+                    m = fma(-wi, vc[u][0], m);
+                    r = fma(-wi, vc[u][1], r);
+                    m = fma(wr, vc[u][1], m);
+                    ar[t] = r;
+                    ai[t] = m;
+                }
             }
         }
-        if (own_next) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t == jn / NW) {
-                    nxr = ar[t];
-                    nxi = ai[t];
-                }
-            if (lane < NR) sx[buf ^ 1][lane] = (d2){nxr, nxi};
-        }
+        if (own_next) publish(jn);
     }
-    wg_sync();
-    if (q == 0 && lane == n - 1) Dm[n - 1] = sx[(n - 1) & 1][lane][0];
-    if (q == 0 && lane == 0) Em[n - 1] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,7 +596,7 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
     return TBK_OK;
 }
 
-int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E) {
+int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E, bool beside_ql) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_QL, s);
@@ -571,7 +605,9 @@ int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, d
     hipLaunchKernelGGL(tridiag_ql_kernel<MPB>, dim3((unsigned)((nk + MPB - 1) / MPB)), dim3(64),             \
                        (size_t)2 * n * MPB * sizeof(double), s, d_de, d_de + (size_t)nk * n, n, nk, d_E,     \
                        m->ws_flag.as<int>())
-    if (n <= 64) {
+    if (n <= 64 && beside_ql && nk <= 8192) {
+        TBK_QL_LAUNCH(32);
+    } else if (n <= 64) {
         TBK_QL_LAUNCH(64);
     } else if (n <= 128) {
         TBK_QL_LAUNCH(32);

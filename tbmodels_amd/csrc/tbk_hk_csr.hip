@@ -127,11 +127,22 @@ hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr
 #pragma unroll
         for (int q = 0; q < KT; ++q) re[q] = im[q] = 0.0;
         const int64_t beg = cptr[e], end = cptr[e + 1];
+        // the record walk is a chain of dependent L2 loads: keep the next record in flight
+        int32_t packed_n = 0;
+        d2 val_n = {0.0, 0.0};
+        if (beg < end) {
+            packed_n = rec_r[beg];
+            val_n = *reinterpret_cast<const d2*>(rec_v + 2 * beg);
+        }
         for (int64_t t = beg; t < end; ++t) {
-            const int32_t packed = rec_r[t];
+            const int32_t packed = packed_n;
+            const double vr = val_n[0], vi = val_n[1];
+            if (t + 1 < end) {
+                packed_n = rec_r[t + 1];
+                val_n = *reinterpret_cast<const d2*>(rec_v + 2 * (t + 1));
+            }
             const int kind = packed >> 28;
             const int64_t r = packed & 0x0fffffff;
-            const double vr = rec_v[2 * t], vi = rec_v[2 * t + 1];
             const double sign_im = (kind == 1) ? -1.0 : ((kind == 2) ? 0.0 : 1.0);
             const double scale_re = (kind == 2) ? 2.0 : 1.0;
             const double ar = scale_re * vr, ai = scale_re * vi, br = sign_im * vi, bi = sign_im * vr;

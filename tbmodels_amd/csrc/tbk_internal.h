@@ -188,7 +188,9 @@ size_t tbk_eig_scratch_per_k(const tbk_model* m);
 // tbk_eig_small.hip
 bool tbk_eig_small_supported(int n);
 int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t nk, double* d_de);
-int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E);
+// `beside_ql`: this launch shares the chip with another QL launch (the tail of the chunk pipeline): use
+// half-size workgroups (32 KiB of LDS) that fit next to two resident 64 KiB ones.
+int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E, bool beside_ql = false);
 
 // tbk_peak.hip
 int tbk_run_mfma_f64_peak(double* tflops);
