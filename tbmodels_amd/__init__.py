@@ -10,7 +10,8 @@ binding a TBmodels maintainer would add.
 from ._model import Model
 from .kdotp import KdotpModel
 from . import synthetic
+from . import io
 
 __version__ = "0.1.0"
 
-__all__ = ("Model", "KdotpModel", "synthetic")
+__all__ = ("Model", "KdotpModel", "synthetic", "io")

@@ -19,6 +19,7 @@ and rebuilt lazily.
 import collections as co
 import ctypes
 import os
+import warnings
 import zlib
 
 import numpy as np
@@ -547,6 +548,80 @@ class Model:
             )
         )
         return KdotpModel(taylor_coefficients={p: coeffs[i] for i, p in enumerate(powers)})
+
+    # ------------------------------------------------------------------ HDF5 wire format
+    @classmethod
+    def from_hdf5_file(cls, hdf5_file, **kwargs):
+        """
+        Load a model stored by ``to_hdf5_file`` -- of this package or of the reference
+        (``_tb_model.py:984-1011``).  Explicit keyword arguments take precedence over the file's.
+        """
+        from . import hdf5_lite  # pylint: disable=import-outside-toplevel
+
+        tree = hdf5_lite.read(hdf5_file)
+        if "type_tag" not in tree:
+            warnings.warn(
+                "The loaded file '{}' is stored in an outdated format. Consider loading and storing the "
+                "file to update it.".format(hdf5_file),
+                DeprecationWarning,
+            )
+        return cls.from_hdf5(tree, **kwargs)
+
+    @classmethod
+    def from_hdf5(cls, tree, **kwargs):
+        """Build a model from the (nested dict) content of a model file (``_tb_model.py:1013-1036``)."""
+        group = tree.get("tb_model", tree)  # a development version wrote a top-level 'tb_model' group
+        new_kwargs = {"hop": {}}
+        for key in ("uc", "occ", "size", "dim", "pos", "sparse"):
+            if key in group:
+                value = group[key]
+                new_kwargs[key] = value.item() if isinstance(value, np.generic) else value
+        if "hop" not in kwargs:
+            sparse = bool(new_kwargs.get("sparse", False))
+            for entry in group.get("hop", {}).values():
+                r_vec = tuple(int(x) for x in entry["R"])
+                if sparse:
+                    new_kwargs["hop"][r_vec] = _csr(
+                        (entry["data"], entry["indices"], entry["indptr"]),
+                        shape=tuple(int(x) for x in entry["shape"]),
+                    )
+                else:
+                    new_kwargs["hop"][r_vec] = np.array(entry["mat"])
+            new_kwargs["contains_cc"] = False
+        new_kwargs.update(kwargs)
+        return cls(**new_kwargs)
+
+    def to_hdf5(self):
+        """The model as the nested dict ``hdf5_lite.write`` stores (``_tb_model.py:1038-1058``)."""
+        tree = {"type_tag": "tbmodels.model"}
+        if self.uc is not None:
+            tree["uc"] = np.asarray(self.uc, dtype=float)
+        if self.occ is not None:
+            tree["occ"] = np.int64(self.occ)
+        tree["size"] = np.int64(self.size)
+        tree["dim"] = np.int64(self.dim)
+        tree["pos"] = np.asarray(self.pos, dtype=float)
+        tree["sparse"] = bool(self._sparse)
+        hop = {}
+        for i, (r_vec, mat) in enumerate(self.hop.items()):
+            entry = {"R": np.array(r_vec, dtype=np.int64)}
+            if self._sparse:
+                mat = _csr(mat)
+                entry["data"] = np.asarray(mat.data, dtype=complex)
+                entry["indices"] = np.asarray(mat.indices, dtype=np.int32)
+                entry["indptr"] = np.asarray(mat.indptr, dtype=np.int32)
+                entry["shape"] = np.array(mat.shape, dtype=np.int64)
+            else:
+                entry["mat"] = np.asarray(mat, dtype=complex)
+            hop[str(i)] = entry
+        tree["hop"] = hop
+        return tree
+
+    def to_hdf5_file(self, hdf5_file):
+        """Save the model to an HDF5 file the reference's ``Model.from_hdf5_file`` / ``io.load`` read."""
+        from . import hdf5_lite  # pylint: disable=import-outside-toplevel
+
+        hdf5_lite.write(hdf5_file, self.to_hdf5())
 
     # ------------------------------------------------------------------ introspection
     def timing(self, reset=True):
