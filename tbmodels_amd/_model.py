@@ -50,6 +50,80 @@ def _hash_bytes(running, array):
     return zlib.adler32(data.view(np.uint8).reshape(-1).data, running)
 
 
+class _HopDict(co.defaultdict):
+    """
+    ``Model.hop``: a ``defaultdict`` (as in the reference, ``_tb_model.py:206``) that remembers whether a
+    matrix may have been handed to outside code.
+
+    The staged device copy has to follow in-place edits such as ``model.hop[R] += x``.  Hashing the hopping
+    bytes on every call finds them but costs a pass over the model (1.3 ms for 512 matrices of 64 x 64) --
+    more than a single-k ``hamilton`` call.  So: the model's own mutators (``add_hop``, ``add_on_site``,
+    ``set_sparse``) go through the raw ``dict`` methods and bump ``version``; ANY outside access that can
+    reach a matrix (``[]``, ``get``, ``values``, ``items``, ``pop``, ``update`` ...) sets ``exposed`` for good
+    -- a reference handed out once can be written through at any later time -- and ``Model._staged`` falls
+    back to the content hash from then on.  Untouched models (from files, from arrays) pay nothing.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.exposed = False
+        self.version = 0
+
+    def __reduce__(self):  # the defaultdict protocol iterates items(): keep that from marking the source
+        return (type(self), (self.default_factory,), None, None, iter(dict.items(self)))
+
+    def __getitem__(self, key):
+        self.exposed = True
+        return super().__getitem__(key)
+
+    def __setitem__(self, key, value):
+        self.exposed = True
+        super().__setitem__(key, value)
+
+    def __delitem__(self, key):
+        self.exposed = True
+        super().__delitem__(key)
+
+    def _exposing(name):  # pylint: disable=no-self-argument
+        def method(self, *args, **kwargs):
+            self.exposed = True
+            return getattr(co.defaultdict, name)(self, *args, **kwargs)
+
+        method.__name__ = name
+        return method
+
+    get = _exposing("get")
+    values = _exposing("values")
+    items = _exposing("items")
+    pop = _exposing("pop")
+    popitem = _exposing("popitem")
+    setdefault = _exposing("setdefault")
+    update = _exposing("update")
+    clear = _exposing("clear")
+    copy = _exposing("copy")
+    del _exposing
+
+    # --- the model's own access: raw dict methods, edits counted in `version` ---
+    def raw_items(self):
+        return dict.items(self)
+
+    def raw_values(self):
+        return dict.values(self)
+
+    def raw_get(self, key):
+        """``self[key]`` with the defaultdict insertion on a miss, without marking the dict exposed."""
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
+        value = self.default_factory()
+        dict.__setitem__(self, key, value)
+        self.version += 1
+        return value
+
+    def raw_set(self, key, value):
+        dict.__setitem__(self, key, value)
+        self.version += 1
+
+
 class Model:
     """
     Tight-binding model with GPU evaluation of ``hamilton`` / ``eigenval``.
@@ -134,10 +208,10 @@ class Model:
         else:
             blocks = self._fold_to_half_space(blocks)
 
-        self.hop = co.defaultdict(self._empty_matrix)
+        self.hop = _HopDict(self._empty_matrix)
         for key, mat in blocks.items():
             if np.any(mat):
-                self.hop[key] = self._matrix_type(mat)
+                self.hop.raw_set(key, self._matrix_type(mat))
         if on_site is not None:
             if len(on_site) != self.size:
                 raise ValueError(
@@ -145,9 +219,9 @@ class Model:
                         len(on_site), self.size
                     )
                 )
-            self.hop[self._zero_vec] += 0.5 * self._matrix_type(np.diag(np.array(on_site, dtype=complex)))
+            self._hop_add(self._zero_vec, 0.5 * self._matrix_type(np.diag(np.array(on_site, dtype=complex))))
 
-        for mat in self.hop.values():
+        for mat in self._hop_values():
             if mat.shape != (self.size, self.size):
                 raise ValueError(
                     "Hopping matrix of shape {0} found, should be ({1},{1}).".format(mat.shape, self.size)
@@ -338,7 +412,7 @@ class Model:
         else:
             R = tuple(-x for x in R)
             mat[orbital_2, orbital_1] += overlap.conjugate()
-        self.hop[R] += self._matrix_type(mat)
+        self._hop_add(R, self._matrix_type(mat))
 
     def add_on_site(self, on_site):
         """Add to the on-site energies (``_tb_model.py:1217-1234``)."""
@@ -352,6 +426,30 @@ class Model:
     def _empty_matrix(self):
         return self._matrix_type(np.zeros((self.size, self.size), dtype=complex))
 
+    # ``self.hop`` as the model itself reads and edits it (see ``_HopDict``); a plain dict assigned by the
+    # caller (``model.hop = {...}``) works too and is simply always content-hashed.
+    def _hop_items(self):
+        hop = self.hop
+        return hop.raw_items() if isinstance(hop, _HopDict) else hop.items()
+
+    def _hop_values(self):
+        hop = self.hop
+        return hop.raw_values() if isinstance(hop, _HopDict) else hop.values()
+
+    def _hop_set(self, key, value):
+        hop = self.hop
+        if isinstance(hop, _HopDict):
+            hop.raw_set(key, value)
+        else:
+            hop[key] = value
+
+    def _hop_add(self, key, mat):
+        hop = self.hop
+        if isinstance(hop, _HopDict):
+            hop.raw_set(key, hop.raw_get(key) + mat)
+        else:
+            hop[key] = hop[key] + mat if key in hop else self._empty_matrix() + mat
+
     def set_sparse(self, sparse=True):
         """Switch the storage of ``hop`` between dense arrays and CSR (``_tb_model.py:1294-1321``)."""
         if getattr(self, "_sparse", None) == sparse:
@@ -359,8 +457,8 @@ class Model:
         self._sparse = sparse
         self._matrix_type = _csr if sparse else np.array
         if hasattr(self, "hop"):
-            for key, mat in self.hop.items():
-                self.hop[key] = self._matrix_type(self._as_dense(mat) if sparse else np.array(mat))
+            for key, mat in list(self._hop_items()):
+                self._hop_set(key, self._matrix_type(self._as_dense(mat) if sparse else np.array(mat)))
 
     def _array_cast(self, mat):
         return np.array(mat) if self._sparse else mat
@@ -374,6 +472,9 @@ class Model:
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        if isinstance(self.hop, _HopDict):  # nobody outside holds references into a freshly unpickled model
+            self.hop.exposed = False
+            self.hop.version = 0
 
     def __del__(self):
         self._drop_staging()
@@ -396,10 +497,18 @@ class Model:
         """
         self._pinned = bool(pinned)
 
+    def _staging_key(self):
+        """What the staged copy is valid for: the edit counter while no matrix has left the model (exact, and
+        no pass over the bytes), the content fingerprint afterwards."""
+        hop = self.hop
+        if isinstance(hop, _HopDict) and not hop.exposed:
+            return ("version", hop.version, self.device, self.size, self.dim, bool(self._sparse))
+        return self._fingerprint()
+
     def _fingerprint(self):
         running = _xxhash.xxh3_64() if _xxhash is not None else 1
         meta = [self.device, self.size, self.dim, int(self._sparse), len(self.hop)]
-        for key, mat in self.hop.items():
+        for key, mat in self._hop_items():
             meta.extend(key)
             if self._sparse:
                 running = _hash_bytes(running, mat.indptr)
@@ -415,17 +524,18 @@ class Model:
         ``self.hop`` as the arrays the C ABI takes: ``R int32 (n_r, dim)`` plus either
         ``hop complex128 (n_r, N, N)`` (dense) or ``(r_ptr int64, row int32, col int32, val complex128)``.
         """
-        keys = list(self.hop.keys())
+        stored = list(self._hop_items())
+        keys = [key for key, _ in stored]
         r_vec = np.array(keys, dtype=np.int32).reshape(len(keys), self.dim)
         if not self._sparse:
             hop = np.empty((len(keys), self.size, self.size), dtype=np.complex128)
-            for idx, key in enumerate(keys):
-                hop[idx] = self.hop[key]
+            for idx, (_, mat) in enumerate(stored):
+                hop[idx] = mat
             return r_vec, hop
         r_ptr = [0]
         rows, cols, vals = [], [], []
-        for key in keys:
-            coo = self.hop[key].tocoo()
+        for _, mat in stored:
+            coo = mat.tocoo()
             rows.append(coo.row.astype(np.int32))
             cols.append(coo.col.astype(np.int32))
             vals.append(coo.data.astype(np.complex128))
@@ -437,7 +547,7 @@ class Model:
         """The ``tbk_model*`` for the current contents of ``self.hop`` (re-staged when they changed)."""
         if self._handle is not None and self._pinned:
             return self._handle
-        fingerprint = self._fingerprint()
+        fingerprint = self._staging_key()
         if self._handle is not None and fingerprint == self._staged_fingerprint:
             return self._handle
         self._drop_staging()
@@ -538,7 +648,7 @@ class Model:
         source = self
         if self._sparse:  # the derivative kernel reads the dense staged operand
             r_vec, _ = self.packed_hop()
-            dense = np.stack([np.array(m) for m in self.hop.values()]) if len(self.hop) else np.zeros((0, self.size, self.size))
+            dense = np.stack([np.array(m) for m in self._hop_values()]) if len(self.hop) else np.zeros((0, self.size, self.size))
             source = Model.from_packed(r_vec, dense, size=self.size, dim=self.dim)
             source.device = self.device
         coeffs = np.empty((len(powers), self.size, self.size), dtype=np.complex128)
@@ -603,7 +713,7 @@ class Model:
         tree["pos"] = np.asarray(self.pos, dtype=float)
         tree["sparse"] = bool(self._sparse)
         hop = {}
-        for i, (r_vec, mat) in enumerate(self.hop.items()):
+        for i, (r_vec, mat) in enumerate(self._hop_items()):
             entry = {"R": np.array(r_vec, dtype=np.int64)}
             if self._sparse:
                 mat = _csr(mat)

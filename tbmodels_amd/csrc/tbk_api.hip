@@ -395,9 +395,15 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
 // workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
 // tridiagonal stage on the QL stream: lane-per-matrix QL up to 64 orbitals, bisection above
+// Calls of at most this many k-points take the bisection kernel for every n: the lane-per-matrix QL is a
+// serial chain of ~n^2 rotations (2.7 ms at n = 64 however few matrices there are) that only pays when
+// tens of thousands of matrices share it; bisection spends a wave per matrix (~0.1 ms at n = 64).
+constexpr int64_t TBK_SMALL_CALL = 4096;
+constexpr int TBK_SMALL_CALL_MIN_N = 12;  // below this the QL chain (61 us at n = 8) is the shorter one
+
 static int launch_tridiag_eigenvalues(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E,
-                                      bool beside_ql = false) {
-    if (tbk_eig_small_supported(m->n_orb)) return tbk_launch_ql(m, s, d_de, nk, d_E, beside_ql);
+                                      bool beside_ql = false, bool small_call = false) {
+    if (tbk_eig_small_supported(m->n_orb) && !small_call) return tbk_launch_ql(m, s, d_de, nk, d_E, beside_ql);
     return tbk_launch_bisect(m, s, d_de, nk, d_E);
 }
 
@@ -434,6 +440,8 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const std::vector<int64_t> sched = chunk_schedule(m, nk, chunk);
     const int64_t n_chunks = (int64_t)sched.size();
     const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
+    // a property of the call, not of its chunking: TBK_OPT_K_CHUNK must not change the results
+    const bool small_call = nk <= TBK_SMALL_CALL && m->n_orb > TBK_SMALL_CALL_MIN_N;
     TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
@@ -466,7 +474,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         if (c >= 1) {  // QL of the previous chunk, alongside this chunk's reduction
             TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
             TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
-                                                 d_E + (size_t)prev_c0 * n));
+                                                 d_E + (size_t)prev_c0 * n, false, small_call));
             TBK_HIP(hipEventRecord(m->ev_ql[b ^ 1], m->stream_ql));
         }
         prev_c0 = c0;
@@ -476,7 +484,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     {  // QL of the last chunk: behind its own reduction on the eig stream, i.e. next to QL(last - 1)
         const int b = (int)((n_chunks - 1) & 1);
         TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_eig, debuf[b]->as<double>(), prev_nkc,
-                                             d_E + (size_t)prev_c0 * n, n_chunks > 1));
+                                             d_E + (size_t)prev_c0 * n, n_chunks > 1, small_call));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_eig));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues

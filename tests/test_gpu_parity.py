@@ -135,6 +135,21 @@ def test_restaging_after_mutation(toy):
     _close(clone.hamilton(KPT, convention=1), model.hamilton(KPT, convention=1), 0.0)
 
 
+def test_restaging_after_edit_through_a_handed_out_reference():
+    """No content hash while the model is untouched; an edit through a reference taken earlier is still seen."""
+    model = toy_model(0.2, -0.2)
+    assert model._staging_key()[0] == "version"
+    first = np.array(model.eigenval(KPT))
+    assert model._staging_key()[0] == "version"  # evaluating does not expose anything
+    on_site = model.hop[(0, 0, 0)]
+    model.eigenval(KPT)  # staged again under the content fingerprint
+    on_site += 0.25 * np.eye(2)  # no dict access: only the bytes changed
+    r_vec, hop = model.packed_hop()
+    got = np.array(model.eigenval(KPT))
+    _close(got, np.array(oracle.eigenval(r_vec, hop, KPT)))
+    _close(got, first + 0.5, 1e-12)  # hop[0] holds half of the on-site block
+
+
 @pytest.mark.parametrize("n_orb,n_r,n_k", [(64, 96, 300), (24, 17, 1000), (96, 40, 130), (3, 5, 4097)])
 def test_seeded_dense_vs_oracle(n_orb, n_r, n_k):
     """Sizes that cross tile boundaries (k tiles of 128, element tiles of 64, K stages of 8 R) and the XCD walk."""

@@ -152,6 +152,68 @@ def test_fingerprint_tracks_in_place_mutation():
     assert model._fingerprint() != before
 
 
+def test_staging_key_uses_edit_counter_until_a_matrix_leaves_the_model():
+    """`_HopDict`: the model's own mutators are counted; any outside access switches to content hashing for good."""
+    model = toy_model(0.1, 0.2)
+    key = model._staging_key()
+    assert key[0] == "version" and key == model._staging_key()
+    assert len(model.hop) > 0 and (0, 0, 0) in model.hop and list(model.hop)  # keys / len / in: not an exposure
+    repr(model), model.packed_hop(), model.to_hdf5()
+    assert model._staging_key() == key
+    model.add_hop(0.01, 0, 1, (3, 0, 0))
+    assert model._staging_key()[0] == "version" and model._staging_key() != key
+    key = model._staging_key()
+    model.add_on_site([0.1, 0.2])
+    assert model._staging_key()[0] == "version" and model._staging_key() != key
+    key = model._staging_key()
+    model.set_sparse(True)
+    assert model._staging_key()[0] == "version" and model._staging_key() != key
+    model.set_sparse(False)
+
+    handed_out = model.hop[(0, 0, 0)]  # from here on a reference is out there
+    key = model._staging_key()
+    assert key[0] != "version" and key == model._fingerprint()
+    assert model._staging_key() == key
+    handed_out[0, 0] += 1e-9  # written through the reference, no dict access at all
+    assert model._staging_key() != key
+
+    for expose in (
+        lambda m: m.hop.values(),
+        lambda m: m.hop.items(),
+        lambda m: m.hop.get((0, 0, 0)),
+        lambda m: m.hop.__setitem__((9, 0, 0), np.zeros((2, 2), dtype=complex)),
+        lambda m: m.hop.update({}),
+        lambda m: m.hop.setdefault((0, 0, 0)),
+        lambda m: m.hop.pop((0, 0, 0)),
+        lambda m: m.hop[(7, 7, 7)],  # the defaultdict insertion
+    ):
+        fresh = toy_model(0.1, 0.2)
+        assert fresh._staging_key()[0] == "version"
+        expose(fresh)
+        assert fresh._staging_key()[0] != "version"
+
+    replaced = toy_model(0.1, 0.2)
+    replaced.hop = {(0, 0, 0): np.eye(2, dtype=complex)}  # a plain dict: always content-hashed
+    assert replaced._staging_key() == replaced._fingerprint()
+    replaced.add_hop(0.5, 0, 1, (1, 0, 0))
+    assert (1, 0, 0) in replaced.hop and replaced.packed_hop()[0].shape == (2, 3)
+
+
+def test_pickle_and_copy_keep_the_source_unexposed():
+    import copy
+
+    model = toy_model(0.1, 0.2)
+    for clone in (pickle.loads(pickle.dumps(model)), copy.deepcopy(model)):
+        assert model._staging_key()[0] == "version"  # serialising did not expose the source
+        assert clone._staging_key()[0] == "version"  # nobody holds references into the clone
+        assert clone._fingerprint() == model._fingerprint()
+        clone.add_hop(0.1, 0, 1, (5, 0, 0))
+        assert clone._staging_key()[0] == "version" and (5, 0, 0) in clone.hop and (5, 0, 0) not in model.hop
+    model.hop[(0, 0, 0)]
+    clone = pickle.loads(pickle.dumps(model))
+    assert clone._staging_key()[0] == "version" and model._staging_key()[0] != "version"
+
+
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports exactly what include/tbk.h declares."""
     with open(os.path.join(ROOT, "include", "tbk.h")) as handle:

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-call latency of Model.hamilton / Model.eigenval for the small batches Z2Pack-style callers issue
+(one k-point, a line of 100, ...) on the silicon fixture (N=8, N_R=95) and a 64-orbital model."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tbmodels_amd  # noqa: E402
+from tbmodels_amd import synthetic as syn  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+with np.load(os.path.join(ROOT, "tests", "golden", "silicon.npz")) as g:
+    silicon = tbmodels_amd.Model.from_packed(g["R"], g["hop"], pos=g["pos"])
+r_vec, hop, pos = syn.dense_model_arrays(64, 512, syn.MODEL_SEED + 3)
+big = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+for name, model in (("silicon N=8 N_R=95", silicon), ("dense N=64 N_R=512", big)):
+    for pinned in (False, True):
+        model.pin_staging(pinned)
+        for nk in (1, 10, 100, 1000):
+            k = syn.random_kpoints(nk)
+            arg = k[0] if nk == 1 else k
+            t_h = timeit(lambda: model.hamilton(arg), 200)
+            t_h1 = timeit(lambda: model.hamilton(arg, convention=1), 200)
+            t_e = timeit(lambda: model.eigenval(arg), 200)
+            print("%-20s pinned=%d nk=%5d  hamilton %8.1f us  conv1 %8.1f us  eigenval %8.1f us" % (name, pinned, nk, t_h, t_h1, t_e))
