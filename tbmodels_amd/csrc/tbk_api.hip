@@ -481,10 +481,13 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         prev_nkc = nkc;
         c0 += nkc;
     }
-    {  // QL of the last chunk: behind its own reduction on the eig stream, i.e. next to QL(last - 1)
+    {  // Eigenvalues of the last chunk, behind its own reduction on the eig stream, i.e. next to QL(last - 1).
+       // Nothing is left to hide a 2.7 ms QL chain behind: the (short) last chunk takes the bisection kernel,
+       // a wave per matrix for ~0.1 ms (measured: 2.6 ms off the 100k step).
         const int b = (int)((n_chunks - 1) & 1);
         TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_eig, debuf[b]->as<double>(), prev_nkc,
-                                             d_E + (size_t)prev_c0 * n, n_chunks > 1, small_call));
+                                             d_E + (size_t)prev_c0 * n, n_chunks > 1,
+                                             small_call || (n_chunks > 1 && m->n_orb > TBK_SMALL_CALL_MIN_N)));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_eig));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues
