@@ -395,12 +395,10 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
 template <int NU, int NB>
 hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E) {
     const size_t lds = (size_t)(2 * NB + 2) * 64 * NU * sizeof(d2);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool raised[TBK_MAX_DEVICES] = {};
+    {
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB>), (int)lds, raised);
         if (e != hipSuccess) return e;
-        raised = true;
     }
     hipLaunchKernelGGL((herm_tridiag_stream_kernel<NU, NB>), dim3(nk), dim3(ST_THREADS), lds, s, d_H, n, d_D, d_E);
     return hipGetLastError();

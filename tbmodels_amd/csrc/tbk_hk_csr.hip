@@ -183,12 +183,10 @@ template <int MODE, int CONV, int KT>
 hipError_t launch_lds(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, const double* d_k,
                       const double* d_pos, double* d_H) {
     const size_t lds = (size_t)std::max<int64_t>(m->n_r, 1) * (KT * 2 + 2) * sizeof(double);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    static bool raised[TBK_MAX_DEVICES] = {};
+    {
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT>), (int)(80 * 1024), raised);
         if (e != hipSuccess) return e;
-        raised = true;
     }
     hipLaunchKernelGGL((hk_csr_lds_kernel<MODE, CONV, KT>), dim3((unsigned)((nk + KT - 1) / KT)), dim3(LDS_THREADS), lds,
                        m->stream, d_A, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_colmap, d_k, d_pos, m->dim, m->ncol,

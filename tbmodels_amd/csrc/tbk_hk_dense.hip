@@ -213,12 +213,10 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 template <int MODE, int CONV>
 hipError_t launch(const HkArgs& a, int grid, hipStream_t s) {
     const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool raised[TBK_MAX_DEVICES] = {};
+    {
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV>), (int)lds, raised);
         if (e != hipSuccess) return e;
-        raised = true;
     }
     hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();

@@ -60,6 +60,22 @@ void tbk_set_error(const char* fmt, ...);
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
+// dynamic LDS above the 64 KiB default: hipFuncSetAttribute acts on the CURRENT device's copy of the
+// kernel, so it is raised once per (kernel instantiation, device) -- `done` is that instantiation's flag row.
+// ------------------------------------------------------------------------------------------------
+constexpr int TBK_MAX_DEVICES = 64;
+
+inline hipError_t tbk_raise_lds_limit(const void* kernel, int bytes, bool (&done)[TBK_MAX_DEVICES]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < TBK_MAX_DEVICES && done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < TBK_MAX_DEVICES) done[dev] = true;
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a grow-only device buffer
 // ------------------------------------------------------------------------------------------------
 struct DevBuf {
