@@ -23,6 +23,8 @@
 // output is used as is), a wave owns whole rows (16 B per lane, coalesced), per-row scalars come from LDS,
 // summation order is fixed (no floating-point atomics): results are reproducible.
 
+#include <cstdlib>
+
 #include "tbk_internal.h"
 
 namespace {
@@ -32,8 +34,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -54,6 +56,53 @@ __device__ __forceinline__ double wave_sum(double v) {
         const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
         v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
     }
+    return v;
+}
+
+// Eight wave-wide sums at once: 64 lanes x 8 values -> lane l ends with the total of value (l >> 3).
+// Each stage halves the number of live values while it doubles the lanes summed (a transposing butterfly):
+// 34 VALU issues instead of 8 x 18 for eight separate wave_sum calls.  The summation tree of every value is
+// fixed, so results are reproducible.
+__device__ __forceinline__ void swap_add(double& x, double y, bool half32) {
+    // x <- [sum of x over the lane pair | sum of y over the lane pair] (lower | upper half, or even | odd rows)
+    unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+    unsigned yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+    if (half32) {
+        const auto rl = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+        x = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    } else {
+        const auto rl = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+        x = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+}
+
+// four values: lane l ends with the total of value (l >> 4)
+__device__ __forceinline__ double reduce4(double (&p)[4]) {
+    swap_add(p[0], p[2], true);   // lane bit 5 <- value bit 1
+    swap_add(p[1], p[3], true);
+    swap_add(p[0], p[1], false);  // lane bit 4 <- value bit 0
+    double v = p[0];
+    v += dpp_mov<0x128>(v);  // row_ror:8, 4, 2, 1: the sum over the row of 16 lanes
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    return v;
+}
+
+__device__ __forceinline__ double reduce8(double (&p)[8], int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) swap_add(p[k], p[k + 4], true);   // lane bit 5 <- value bit 2
+    swap_add(p[0], p[2], false);                                   // lane bit 4 <- value bit 1
+    swap_add(p[1], p[3], false);
+    const bool hi8 = (lane & 8) != 0;                              // lane bit 3 <- value bit 0
+    const double keep = hi8 ? p[1] : p[0];
+    const double send = hi8 ? p[0] : p[1];
+    double v = keep + dpp_mov<0x128>(send);  // row_ror:8
+    v += dpp_mov<0x141>(v);                  // row_half_mirror: i <-> 7 - i inside each group of 8
+    v += dpp_mov<0xB1>(v);                   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                   // quad_perm [2,3,0,1]
     return v;
 }
 
@@ -168,39 +217,74 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
         d2 colacc[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) colacc[u] = (d2){0.0, 0.0};
-        for (int r = j + 1 + wave; r < n; r += ST_WAVES) {
-            const d2 vr = sx[r];
-            const int u_first = r >> 6;
-            double* row = A + (size_t)r * n * 2;
-            d2 rowsum = (d2){0.0, 0.0};
+        // Row r of the stored triangle: columns r .. n-1, 16 B per lane, NU loads.  The loads are UNCONDITIONAL
+        // (lanes left of the diagonal or beyond n re-read the row's diagonal element; masked when used): with
+        // predicated loads hipcc waited for each one where it was issued, which serialised the pass on
+        // memory latency.  A wave takes RB of its rows at a time: 4 NU loads in flight, and the 2 RB row sums
+        // (re, im) share ONE transposed reduction -- the pass is VALU-issue bound, and two wave_sum calls per
+        // row were a third of its instructions.
+        constexpr int RB = (NU <= 2) ? 4 : 2;  // 16 NU RB bytes of row data per lane: keep two workgroups per CU
+        for (int r0 = j + 1 + wave; r0 < n; r0 += ST_WAVES * RB) {
+            d2 a[RB][NU];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int c = lane + 64 * u;
-                if (u >= u_first && c >= r && c < n) {
-                    d2 a = *reinterpret_cast<const d2*>(row + (size_t)c * 2);
-                    if (flush) {
+            for (int q = 0; q < RB; ++q) {
+                const int r = min(r0 + q * ST_WAVES, n - 1);
+                const double* row = A + (size_t)r * n * 2;
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const d2 t1 = cmulc(sV[b * NP + r], sW[b * NP + c]);
-                            const d2 t2 = cmulc(sW[b * NP + r], sV[b * NP + c]);
-                            a[0] -= t1[0] + t2[0];
-                            a[1] -= t1[1] + t2[1];
-                        }
-                        *reinterpret_cast<d2*>(row + (size_t)c * 2) = a;
-                    }
-                    const d2 t = cmul(a, nv[u]);
-                    rowsum[0] += t[0];
-                    rowsum[1] += t[1];
-                    if (c > r) {
-                        const d2 tc = cmulc(vr, a);  // conj(a) * v'_r
-                        colacc[u][0] += tc[0];
-                        colacc[u][1] += tc[1];
-                    }
+                for (int u = 0; u < NU; ++u) {
+                    const int c = min(max(lane + 64 * u, r), n - 1);
+                    a[q][u] = *reinterpret_cast<const d2*>(row + (size_t)c * 2);
                 }
             }
-            const double sr = wave_sum(rowsum[0]);
-            const double si = wave_sum(rowsum[1]);
-            if (lane == 0) su[r] = (d2){sr, si};  // one writer per row
+            double part[2 * RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int r = r0 + q * ST_WAVES;
+                d2 rowsum = (d2){0.0, 0.0};
+                if (r < n) {  // uniform
+                    const d2 vr = sx[r];
+                    double* row = A + (size_t)r * n * 2;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        if (64 * (u + 1) <= r) continue;  // uniform: the whole chunk lies left of the diagonal
+                        const int c = lane + 64 * u;
+                        const bool valid = c >= r && c < n;
+                        d2 av = a[q][u];
+                        if (flush) {
+                            const int cc = min(c, NP - 1);
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) {
+                                const d2 t1 = cmulc(sV[b * NP + r], sW[b * NP + cc]);
+                                const d2 t2 = cmulc(sW[b * NP + r], sV[b * NP + cc]);
+                                av[0] -= t1[0] + t2[0];
+                                av[1] -= t1[1] + t2[1];
+                            }
+                            if (valid) *reinterpret_cast<d2*>(row + (size_t)c * 2) = av;
+                        }
+                        av[0] = valid ? av[0] : 0.0;
+                        av[1] = valid ? av[1] : 0.0;
+                        const d2 t = cmul(av, nv[u]);
+                        rowsum[0] += t[0];
+                        rowsum[1] += t[1];
+                        if (c > r) {  // (av = 0 on invalid lanes)
+                            const d2 tc = cmulc(vr, av);  // conj(a) * v'_r
+                            colacc[u][0] += tc[0];
+                            colacc[u][1] += tc[1];
+                        }
+                    }
+                }
+                part[2 * q] = rowsum[0];
+                part[2 * q + 1] = rowsum[1];
+            }
+            if constexpr (RB == 4) {
+                const double total = reduce8(part, lane);  // lane l: value l >> 3 = (row slot l >> 4, re / im bit 3)
+                const int r_mine = r0 + (lane >> 4) * ST_WAVES;
+                if ((lane & 7) == 0 && r_mine < n) reinterpret_cast<double*>(su)[2 * r_mine + ((lane >> 3) & 1)] = total;
+            } else {
+                const double total = reduce4(part);  // lane l: value l >> 4 = (row slot l >> 5, re / im bit 4)
+                const int r_mine = r0 + (lane >> 5) * ST_WAVES;
+                if ((lane & 15) == 0 && r_mine < n) reinterpret_cast<double*>(su)[2 * r_mine + ((lane >> 4) & 1)] = total;
+            }
         }
         wg_sync();
         // column parts, one wave after the other: fixed summation order
