@@ -308,24 +308,26 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     double* Dm = D + mat * (size_t)n;
     double* Em = E + mat * (size_t)n;
 
+    // Lane i <- row i of the Hermitian matrix whose upper triangle is stored: element (i, c) comes from
+    // (min, max) of the pair, conjugated below the diagonal.  Unconditional loads from clamped addresses, all
+    // NT in flight (hipcc waits for a predicated load where it is issued), masked afterwards.
     dcol ar, ai;
+    {
+        d2 raw[NT];
+        const int li = min(lane, n - 1);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int c = NW * t + q;
-        double re = 0.0, im = 0.0;
-        if (lane < n && c < n) {
-            if (c >= lane) {
-                const d2 v = *reinterpret_cast<const d2*>(Hm + ((size_t)lane * n + c) * 2);
-                re = v[0];
-                im = v[1];
-            } else {
-                const d2 v = *reinterpret_cast<const d2*>(Hm + ((size_t)c * n + lane) * 2);
-                re = v[0];
-                im = -v[1];
-            }
+        for (int t = 0; t < NT; ++t) {
+            const int c = min(NW * t + q, n - 1);
+            const int lo = min(li, c), hi = max(li, c);
+            raw[t] = *reinterpret_cast<const d2*>(Hm + ((size_t)lo * n + hi) * 2);
         }
-        ar[t] = re;
-        ai[t] = im;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = NW * t + q;
+            const bool inside = lane < n && c < n;
+            ar[t] = inside ? raw[t][0] : 0.0;
+            ai[t] = inside ? (c >= lane ? raw[t][1] : -raw[t][1]) : 0.0;
+        }
     }
 
     // The owner of column jc publishes it (x, lane i = A[i][jc]) with the scalars of the reflector that
