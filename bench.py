@@ -328,6 +328,11 @@ def main():
                 "algorithmic_bytes_per_launch": (16.0 * n_orb * (n_orb + 1) / 2 + 8 * dim) * k_per_launch
                                                 + 16.0 * n_orb * n_orb * n_r,
                 "executed_tflops": round(f_exec * k_per_launch / (hk_ms_avg * 1e-3) / 1e12, 3) if hk_ms_avg > 0 else 0.0,
+                # `frac` prices SURVEY 8d's algorithmic 8 N^2 N_R flops per k-point against the peak; the kernel
+                # contracts only the packed upper triangle (half those flops), so the share of the matrix pipe it
+                # actually occupies is frac_executed
+                "frac_executed": round(f_exec * k_per_launch / (hk_ms_avg * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
+                if hk_ms_avg > 0 else 0.0,
                 "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
                 "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
             }

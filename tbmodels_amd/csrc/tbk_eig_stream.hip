@@ -405,8 +405,10 @@ __device__ __forceinline__ double wave_max(double v) {
 
 __global__ void __launch_bounds__(ST_MAXN)
 tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E, int n, double* __restrict__ out) {
-    __shared__ double sd[ST_MAXN];
-    __shared__ double se2[ST_MAXN];  // se2[i] = e_i^2 couples i and i+1
+    // 16 n bytes of LDS (dynamic): at n = 64 a block must fit beside the 64 KiB QL blocks of the previous chunk
+    extern __shared__ __attribute__((aligned(16))) double bs_smem[];
+    double* sd = bs_smem;
+    double* se2 = bs_smem + blockDim.x;  // se2[i] = e_i^2 couples i and i+1
     __shared__ double sred[2][ST_MAXN / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -514,8 +516,8 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_QL, s);
     const int threads = (n + 63) / 64 * 64;
-    hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)nk), dim3(threads), 0, s, d_de, d_de + (size_t)nk * n, n,
-                       d_E);
+    hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)nk), dim3(threads), 2 * threads * sizeof(double), s, d_de,
+                       d_de + (size_t)nk * n, n, d_E);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

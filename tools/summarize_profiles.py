@@ -8,6 +8,7 @@ Expects (any subset):  <dir>/trace/*_kernel_stats.csv      rocprofv3 --kernel-tr
                        <dir>/fetch/*_counter_collection.csv rocprofv3 --pmc FETCH_SIZE --kernel-trace -- ...
                        <dir>/write/*_counter_collection.csv rocprofv3 --pmc WRITE_SIZE --kernel-trace -- ...
                        <dir>/sq/*_counter_collection.csv    rocprofv3 --pmc SQ_* --kernel-trace -- ...
+                       <dir>/sq2/*_counter_collection.csv   (a second SQ group: the counters do not fit one pass)
 Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_summary.txt and profiles/<tag>_traffic.json
 (HBM bytes per launch of the H(k) kernel, the number bench.py reports as roofline.traffic).
 """
@@ -57,7 +58,7 @@ def main():
         "",
     ]
     traffic = {}
-    for group in ("fetch", "write", "sq"):
+    for group in ("fetch", "write", "sq", "sq2"):
         agg = load_counters(os.path.join(src, group))
         for kernel in KERNELS:
             for counter, vals in sorted(agg.get(kernel, {}).items()):
