@@ -437,16 +437,107 @@ def gen_wannier(tbmodels):
     np.savez_compressed(os.path.join(OUT, "wannier.npz"), **out)
 
 
+def gen_materials(tbmodels):
+    """
+    More of the reference's own sample data on the path (all data files of its test-suite, copied gzip'd next to
+    the expected outputs):
+
+    * bismuth Wannier90 files (tests/test_wannier.py:33-46, :64-230: hr + wsvec + xyz + win, both `pos_kind`s),
+      `wannier90_hr.dat` / `_v2` (empty lines, :247-255) and the two inconsistent files (:236-244), the two broken
+      wsvec files (:318-345) -- parser coverage beyond silicon;
+    * InAs models stored as HDF5 (tests/test_hdf5.py:48-78, tests/test_supercell.py): the 14-orbital primitive
+      model (140 R, dense) and its (1, 2, 3) supercell (84 orbitals, CSR, 56 R): the only real-material case above
+      64 orbitals, with the degenerate (folded) spectrum synthetic matrices do not have.
+    """
+    import gzip  # pylint: disable=import-outside-toplevel
+    import shutil  # pylint: disable=import-outside-toplevel
+
+    samples = os.path.join(REF, "tests", "samples")
+    path = lambda name: os.path.join(samples, name)  # noqa: E731
+
+    def copy(name, sub):
+        os.makedirs(os.path.join(OUT, sub), exist_ok=True)
+        with open(path(name), "rb") as src, gzip.GzipFile(os.path.join(OUT, sub, name + ".gz"), "wb", mtime=0) as dst:
+            shutil.copyfileobj(src, dst)
+
+    for name in (
+        "bi_hr.dat", "bi_wsvec.dat", "bi_centres.xyz", "bi.win", "bi_wsvec_blocks_missing.dat",
+        "bi_wsvec_blocks_incomplete.dat", "wannier90_hr.dat", "wannier90_hr_v2.dat", "wannier90_inconsistent.dat",
+        "wannier90_inconsistent_v2.dat",
+    ):
+        copy(name, "wannier")
+    for name in ("InAs_nosym.hdf5", "InAs_supercell_reference.hdf5"):
+        copy(name, "models")
+
+    out = {"kpt": np.array(KPT)}
+    # Gamma, X, L, W-like points and generic ones: degenerate bands at the symmetric points
+    kpath = np.array(
+        [(0.0, 0.0, 0.0), (0.5, 0.0, 0.5), (0.5, 0.5, 0.5), (0.5, 0.25, 0.75), (0.375, 0.375, 0.75), (0.1, 0.2, 0.7),
+         (-0.3, 0.5, 0.2), (1.1, -0.9, -0.7)]
+    )
+    out["kpath"] = kpath
+
+    def record(tag, model, k, with_hop=True):
+        if with_hop:
+            r_vec, hop = _pack_hop(model)
+            order = np.lexsort(r_vec.T[::-1])
+            out[tag + "_R"] = r_vec[order]
+            out[tag + "_hop"] = hop[order]
+        out[tag + "_pos"] = np.array(model.pos)
+        if model.uc is not None:
+            out[tag + "_uc"] = np.array(model.uc)
+        out[tag + "_h2"] = np.array(model.hamilton(k))
+        out[tag + "_h1"] = np.array(model.hamilton(k, convention=1))
+        out[tag + "_eig"] = _eig(model, k)
+
+    # --- bismuth
+    record("bi_hr_ws", tbmodels.Model.from_wannier_files(hr_file=path("bi_hr.dat"), wsvec_file=path("bi_wsvec.dat")), KPT)
+    stored = _regression("test_wannier", "test_wannier_hr_wsvec[bi_hr.dat-bi_wsvec.dat]")
+    assert np.abs(out["bi_hr_ws_h2"] - stored).max() < 1e-12
+    for kind in ("wannier", "nearest_atom"):
+        model = tbmodels.Model.from_wannier_files(
+            hr_file=path("bi_hr.dat"), wsvec_file=path("bi_wsvec.dat"), xyz_file=path("bi_centres.xyz"),
+            win_file=path("bi.win"), pos_kind=kind, distance_ratio_threshold=1.0,
+        )
+        record("bi_all_" + kind, model, KPT, with_hop=(kind == "wannier"))
+        out["bi_all_%s_reciprocal" % kind] = np.array(model.reciprocal_lattice)
+    # --- wannier90_hr (7 orbitals), with and without the stray empty lines
+    record("w90", tbmodels.Model.from_wannier_files(hr_file=path("wannier90_hr.dat"), occ=28), KPT)
+    stored = _regression("test_wannier", "test_wannier_hr_only[wannier90_hr.dat]")
+    assert np.abs(out["w90_h2"] - stored).max() < 1e-12
+    v2 = tbmodels.Model.from_wannier_files(hr_file=path("wannier90_hr_v2.dat"), occ=28)
+    assert np.abs(np.array(v2.hamilton(KPT)) - out["w90_h2"]).max() == 0.0
+    for name in ("wannier90_inconsistent.dat", "wannier90_inconsistent_v2.dat"):
+        try:
+            tbmodels.Model.from_wannier_files(hr_file=path(name))
+        except ValueError:
+            pass
+        else:
+            raise AssertionError(name + " did not raise in the reference")
+    # --- InAs, primitive and supercell
+    prim = tbmodels.Model.from_hdf5_file(path("InAs_nosym.hdf5"))
+    record("inas", prim, kpath)
+    sup = tbmodels.Model.from_hdf5_file(path("InAs_supercell_reference.hdf5"))
+    assert sup.size == 84
+    record("inas_sc", sup, kpath, with_hop=False)  # the matrices are in the (gzip'd) model file itself
+    out["inas_sc_nnz"] = np.array(sum(np.array(m).astype(bool).sum() for m in sup.hop.values()))
+    np.savez_compressed(os.path.join(OUT, "materials.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tbmodels = _import_reference()
     syn = _load_synthetic()
     print("reference tbmodels", tbmodels.__version__, "numpy", np.__version__)
+    if len(sys.argv) > 1 and sys.argv[1] == "materials":  # only the newest group (the others are unchanged)
+        gen_materials(tbmodels)
+        return
     gen_silicon(tbmodels, syn)
     gen_toy(tbmodels)
     gen_synthetic(tbmodels, syn)
     gen_kdotp(tbmodels, syn)
     gen_wannier(tbmodels)
+    gen_materials(tbmodels)
     for name in sorted(os.listdir(OUT)):
         print("%-16s %8d bytes" % (name, os.path.getsize(os.path.join(OUT, name))))
 
