@@ -25,7 +25,7 @@ from oracle import tbk_oracle as oracle
 from conftest import GOLDEN, KPT, load_golden
 
 WANNIER = [
-    "bi_hr.dat", "bi_wsvec.dat", "bi_centres.xyz", "bi.win", "bi_wsvec_blocks_missing.dat",
+    "bi_hr.dat", "bi_wsvec.dat", "bi_centres.xyz", "bi.win", "bi_equivalent.win", "bi_wsvec_blocks_missing.dat",
     "bi_wsvec_blocks_incomplete.dat", "wannier90_hr.dat", "wannier90_hr_v2.dat", "wannier90_inconsistent.dat",
     "wannier90_inconsistent_v2.dat",
 ]
@@ -98,6 +98,17 @@ def test_bismuth_all_files(files, gold):
             hr_file=files["bi_hr.dat"], wsvec_file=files["bi_wsvec.dat"], xyz_file=files["bi_centres.xyz"],
             distance_ratio_threshold=1.0,
         )
+
+
+def test_length_unit_modes(files):
+    """tests/test_wannier.py:355-373: the length unit given explicitly or inside the unit-cell block is equivalent."""
+    kwargs = dict(hr_file=files["bi_hr.dat"], xyz_file=files["bi_centres.xyz"], wsvec_file=files["bi_wsvec.dat"])
+    model1 = tbmodels_amd.Model.from_wannier_files(win_file=files["bi.win"], **kwargs)
+    model2 = tbmodels_amd.Model.from_wannier_files(win_file=files["bi_equivalent.win"], **kwargs)
+    assert np.allclose(model1.uc, model2.uc, rtol=0, atol=1e-10) and np.allclose(model1.pos, model2.pos, rtol=0, atol=1e-10)
+    assert set(model1.hop) == set(model2.hop)
+    for key in model1.hop:
+        assert np.array_equal(np.array(model1.hop[key]), np.array(model2.hop[key]))
 
 
 def test_wannier90_hr_with_and_without_empty_lines(files, gold):

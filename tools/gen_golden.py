@@ -461,7 +461,7 @@ def gen_materials(tbmodels):
             shutil.copyfileobj(src, dst)
 
     for name in (
-        "bi_hr.dat", "bi_wsvec.dat", "bi_centres.xyz", "bi.win", "bi_wsvec_blocks_missing.dat",
+        "bi_hr.dat", "bi_wsvec.dat", "bi_centres.xyz", "bi.win", "bi_equivalent.win", "bi_wsvec_blocks_missing.dat",
         "bi_wsvec_blocks_incomplete.dat", "wannier90_hr.dat", "wannier90_hr_v2.dat", "wannier90_inconsistent.dat",
         "wannier90_inconsistent_v2.dat",
     ):
