@@ -112,17 +112,19 @@ __device__ __forceinline__ void wg_sync() {
     __syncthreads();
 }
 
-constexpr int ST_THREADS = 512;
-constexpr int ST_WAVES = ST_THREADS / 64;
 constexpr int ST_MAXN = 512;
 
 __device__ __forceinline__ d2 cmul(d2 a, d2 b) { return (d2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
 // a * conj(b)
 __device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1] * b[1], a[1] * b[0] - a[0] * b[1]}; }
 
-template <int NU, int NB>  // 64-column chunks per row (n <= 64 NU); panel width
+// NU: 64-column chunks per row (n <= 64 NU); NB: panel width; ST_THREADS: workgroup size.  Up to 128 orbitals a
+// step is a chain of barriers and short phases (17 k cycles per step at n = 80 with eight waves, of which the
+// pass over the triangle needs ~2 k): four waves per matrix, twice as many matrices per CU.
+template <int NU, int NB, int ST_THREADS>
 __global__ void __launch_bounds__(ST_THREADS)
 herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
+    constexpr int ST_WAVES = ST_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) double st_smem[];
     constexpr int NP = 64 * NU;  // padded vector length
     d2* sV = reinterpret_cast<d2*>(st_smem);  // [NB][NP] pending v
@@ -301,13 +303,13 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
         }
         // panel not applied to memory: u -= V (W^H v') + W (V^H v');  wave b reduces pair b
         if (!flush && p > 0) {
-            if (wave < p) {
+            for (int b = wave; b < p; b += ST_WAVES) {
                 d2 g = (d2){0.0, 0.0}, h = (d2){0.0, 0.0};
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int i = lane + 64 * u;
-                    const d2 tg = cmulc(nv[u], sW[wave * NP + i]);  // conj(W) v'
-                    const d2 th = cmulc(nv[u], sV[wave * NP + i]);
+                    const d2 tg = cmulc(nv[u], sW[b * NP + i]);  // conj(W) v'
+                    const d2 th = cmulc(nv[u], sV[b * NP + i]);
                     g[0] += tg[0];
                     g[1] += tg[1];
                     h[0] += th[0];
@@ -318,8 +320,8 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 h[0] = wave_sum(h[0]);
                 h[1] = wave_sum(h[1]);
                 if (lane == 0) {
-                    sg[wave] = g;
-                    sh[wave] = h;
+                    sg[b] = g;
+                    sh[b] = h;
                 }
             }
             wg_sync();
@@ -478,15 +480,17 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     if (tid < n) out[mat * n + tid] = 0.5 * (lo + hi);
 }
 
-template <int NU, int NB>
+template <int NU, int NB, int ST_THREADS>
 hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E) {
     const size_t lds = (size_t)(2 * NB + 2) * 64 * NU * sizeof(d2);
     static bool raised[TBK_MAX_DEVICES] = {};
     {
-        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB>), (int)lds, raised);
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB, ST_THREADS>), (int)lds,
+                                           raised);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((herm_tridiag_stream_kernel<NU, NB>), dim3(nk), dim3(ST_THREADS), lds, s, d_H, n, d_D, d_E);
+    hipLaunchKernelGGL((herm_tridiag_stream_kernel<NU, NB, ST_THREADS>), dim3(nk), dim3(ST_THREADS), lds, s, d_H, n, d_D,
+                       d_E);
     return hipGetLastError();
 }
 
@@ -501,12 +505,14 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
     double* d_D = d_de;
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
+    // measured (tools/bench_sizes.py): four waves and a panel of 4 up to 128 orbitals (n = 80: 1.08 us per matrix
+    // against 1.42 with eight waves and a panel of 8); above that the variants are within 2 % of each other
     if (n <= 128)
-        TBK_HIP((launch_stream<2, 8>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<2, 4, 256>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     else if (n <= 256)
-        TBK_HIP((launch_stream<4, 8>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<4, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     else
-        TBK_HIP((launch_stream<8, 4>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<8, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     return TBK_OK;
 }
 
