@@ -55,10 +55,13 @@ typedef enum tbk_status {
 } tbk_status;
 
 /* eigensolver selection for tbk_model_set_option(TBK_OPT_EIGENSOLVER, ...):
- *   WAVE      hand-written wave-per-matrix Householder + QL (n_orb <= 64 only)
+ *   WAVE      hand-written register-resident Householder reduction (n_orb <= 64 only) + tridiagonal stage
  *   ROCSOLVER rocsolver_zheevd_strided_batched
- *   AUTO      WAVE when n_orb <= 64; the streaming Householder kernel + tridiagonal QL up to n_orb = 512;
- *             ROCSOLVER above */
+ *   AUTO      WAVE when n_orb <= 64; the streaming Householder kernel up to n_orb = 512; ROCSOLVER above.
+ * Tridiagonal stage of the two hand-written paths: lane-per-matrix QL for large batches of n_orb <= 64,
+ * bisection on Sturm counts otherwise (n_orb > 64, calls of <= max(4096, 256 n_orb) k-points, and the last
+ * chunk of a call).  Both are backward stable; they agree to rounding, so eigenvalues are reproducible run to
+ * run but depend on the batch size at the 1e-13 level. */
 enum { TBK_EIG_AUTO = 0, TBK_EIG_WAVE = 1, TBK_EIG_ROCSOLVER = 2 };
 enum {
     TBK_OPT_EIGENSOLVER = 1, /* one of TBK_EIG_*                                           */
@@ -128,7 +131,7 @@ int tbk_device_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* ---- timing: HIP events around every kernel of the path, on the stream it is launched on -------
  * stages: PHASE phase rows; HK the H(k) contraction; EIG reduction to tridiagonal form (or the whole
- * rocSOLVER call); QL tridiagonal QL + sort.  Stages of different k chunks may overlap in time. */
+ * rocSOLVER call); QL the tridiagonal stage (QL + sort, or bisection).  Stages of different k chunks may overlap. */
 enum { TBK_T_PHASE = 0, TBK_T_HK = 1, TBK_T_EIG = 2, TBK_T_QL = 3, TBK_T_COUNT = 4 };
 /* ms[i] = summed duration of stage i, launches[i] = number of timed launches; reset = 1 clears. */
 int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int reset);
