@@ -505,12 +505,17 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
     double* d_D = d_de;
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
-    // measured (tools/bench_sizes.py): four waves and a panel of 4 up to 128 orbitals (n = 80: 1.08 us per matrix
-    // against 1.42 with eight waves and a panel of 8); above that the variants are within 2 % of each other
+    // One instantiation per 64 columns of padded row length (work and LDS scale with the padding).  Measured
+    // (tools/bench_sizes.py): four waves and a panel of 4 up to 128 orbitals (n = 80: 1.08 us per matrix against
+    // 1.42 with eight waves and a panel of 8); above that panel / workgroup variants are within 2 % of each other
     if (n <= 128)
         TBK_HIP((launch_stream<2, 4, 256>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+    else if (n <= 192)
+        TBK_HIP((launch_stream<3, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     else if (n <= 256)
         TBK_HIP((launch_stream<4, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+    else if (n <= 384)  // (5 and 7 chunks were measured too: no better than 6 and 8)
+        TBK_HIP((launch_stream<6, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     else
         TBK_HIP((launch_stream<8, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
     return TBK_OK;
