@@ -114,6 +114,22 @@ __device__ __forceinline__ void wg_sync() {
 
 constexpr int ST_MAXN = 512;
 
+// Phase clock for tools/stream_phase_clock.hip (compiled out of the library): cycles per phase of a Householder
+// step, accumulated by thread 0 of workgroup 0.
+#ifdef TBK_PHASE_CLOCK
+__device__ unsigned long long tbk_phase_clock[16];
+#define TBK_CLK(k)                                                  \
+    do {                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                  \
+            const unsigned long long now_ = clock64();         \
+            tbk_phase_clock[k] += now_ - clk_prev_;                 \
+            clk_prev_ = now_;                                       \
+        }                                                           \
+    } while (0)
+#else
+#define TBK_CLK(k)
+#endif
+
 __device__ __forceinline__ d2 cmul(d2 a, d2 b) { return (d2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
 // a * conj(b)
 __device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1] * b[1], a[1] * b[0] - a[0] * b[1]}; }
@@ -129,8 +145,13 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
     constexpr int NP = 64 * NU;  // padded vector length
     d2* sV = reinterpret_cast<d2*>(st_smem);  // [NB][NP] pending v
     d2* sW = sV + NB * NP;                    // [NB][NP] pending w
-    d2* sx = sW + NB * NP;                    // [NP] column j, then the new reflector v'
+    d2* sx = sW + NB * NP;                    // [NP] column j
     d2* su = sx + NP;                         // [NP] u = A v'
+    d2* svn = su + NP;                        // [NP] the new reflector v' (its own buffer: no barrier between x and v')
+    // per-wave column sums, added up in fixed order after ONE barrier -- where the LDS budget allows it (two
+    // workgroups per CU must still fit at 3 and 4 chunks): otherwise the waves add one after the other
+    constexpr bool COLBUF = (NU >= 5);
+    d2* scol = svn + NP;                      // [ST_WAVES][NP] (COLBUF only)
     __shared__ d2 stau;
     __shared__ d2 sg[NB], sh[NB];             // W_b^H v', V_b^H v'
     const int tid = threadIdx.x;
@@ -141,9 +162,12 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
     double* Dm = D + mat * (size_t)n;
     double* Em = E + mat * (size_t)n;
 
-    for (int i = tid; i < (2 * NB + 2) * NP; i += ST_THREADS) sV[i] = (d2){0.0, 0.0};
+    for (int i = tid; i < (2 * NB + 3) * NP; i += ST_THREADS) sV[i] = (d2){0.0, 0.0};
     int p = 0;  // pending (v, w) pairs in the panel
     wg_sync();
+#ifdef TBK_PHASE_CLOCK
+    unsigned long long clk_prev_ = clock64();
+#endif
 
     for (int j = 0; j < n - 1; ++j) {
         // ---- 1. column j of the up-to-date matrix, from row j of the stored triangle ----
@@ -163,6 +187,7 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
             su[i] = (d2){0.0, 0.0};
         }
         wg_sync();
+        TBK_CLK(1);
 
         // ---- 2. reflector (every wave computes the scalars; everyone writes its share of v') ----
         {
@@ -193,7 +218,6 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 ej = beta;
             }
             const d2 dj = sx[j];
-            wg_sync();  // everyone has read x before it is overwritten by v'
             if (tid == 0) {
                 Dm[j] = dj[0];
                 Em[j] = ej;
@@ -206,13 +230,14 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 } else if (i == j + 1) {
                     v[0] = one;
                 }
-                sx[i] = v;  // a thread overwrites only the entries it read itself
+                svn[i] = v;
             }
         }
         wg_sync();
+        TBK_CLK(2);
         d2 nv[NU];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) nv[u] = sx[lane + 64 * u];
+        for (int u = 0; u < NU; ++u) nv[u] = svn[lane + 64 * u];
 
         // ---- 3. one pass over the stored triangle of the trailing matrix ----
         const bool flush = (p == NB);
@@ -225,9 +250,11 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
         // memory latency.  A wave takes RB of its rows at a time: 4 NU loads in flight, and the 2 RB row sums
         // (re, im) share ONE transposed reduction -- the pass is VALU-issue bound, and two wave_sum calls per
         // row were a third of its instructions.
-        constexpr int RB = (NU <= 2) ? 4 : 2;  // 16 NU RB bytes of row data per lane: keep two workgroups per CU
-        for (int r0 = j + 1 + wave; r0 < n; r0 += ST_WAVES * RB) {
-            d2 a[RB][NU];
+#ifndef TBK_STREAM_RB_SMALL
+#define TBK_STREAM_RB_SMALL 2
+#endif
+        constexpr int RB = (NU <= 2) ? TBK_STREAM_RB_SMALL : 2;  // 16 NU RB bytes of row data per lane: keep two workgroups per CU
+        auto load_group = [&](int r0, d2 (&a)[RB][NU]) {
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 const int r = min(r0 + q * ST_WAVES, n - 1);
@@ -238,13 +265,19 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                     a[q][u] = *reinterpret_cast<const d2*>(row + (size_t)c * 2);
                 }
             }
+        };
+        // (requesting the next group before this one is reduced was measured with tools/stream_phase_clock.hip:
+        // 5 % slower at n = 80 .. 128, neutral above)
+        for (int r0 = j + 1 + wave; r0 < n; r0 += ST_WAVES * RB) {
+            d2 a[RB][NU];
+            load_group(r0, a);
             double part[2 * RB];
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 const int r = r0 + q * ST_WAVES;
                 d2 rowsum = (d2){0.0, 0.0};
                 if (r < n) {  // uniform
-                    const d2 vr = sx[r];
+                    const d2 vr = svn[r];
                     double* row = A + (size_t)r * n * 2;
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
@@ -278,7 +311,18 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 part[2 * q] = rowsum[0];
                 part[2 * q + 1] = rowsum[1];
             }
-            if constexpr (RB == 4) {
+            if constexpr (RB == 8) {
+                double lo8[8], hi8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    lo8[k] = part[k];
+                    hi8[k] = part[8 + k];
+                }
+                const double t0 = reduce8(lo8, lane), t1 = reduce8(hi8, lane);
+                const int r_a = r0 + (lane >> 4) * ST_WAVES, r_b = r_a + 4 * ST_WAVES;
+                if ((lane & 7) == 0 && r_a < n) reinterpret_cast<double*>(su)[2 * r_a + ((lane >> 3) & 1)] = t0;
+                if ((lane & 7) == 0 && r_b < n) reinterpret_cast<double*>(su)[2 * r_b + ((lane >> 3) & 1)] = t1;
+            } else if constexpr (RB == 4) {
                 const double total = reduce8(part, lane);  // lane l: value l >> 3 = (row slot l >> 4, re / im bit 3)
                 const int r_mine = r0 + (lane >> 4) * ST_WAVES;
                 if ((lane & 7) == 0 && r_mine < n) reinterpret_cast<double*>(su)[2 * r_mine + ((lane >> 3) & 1)] = total;
@@ -288,18 +332,38 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 if ((lane & 15) == 0 && r_mine < n) reinterpret_cast<double*>(su)[2 * r_mine + ((lane >> 4) & 1)] = total;
             }
         }
-        wg_sync();
-        // column parts, one wave after the other: fixed summation order
-        for (int w = 0; w < ST_WAVES; ++w) {
-            if (wave == w) {
+        if constexpr (COLBUF) {
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int c = lane + 64 * u;
-                    const d2 t = su[c];
-                    su[c] = (d2){t[0] + colacc[u][0], t[1] + colacc[u][1]};
+            for (int u = 0; u < NU; ++u) scol[wave * NP + lane + 64 * u] = colacc[u];
+            wg_sync();
+        TBK_CLK(flush ? 7 : 3);
+            for (int i = tid; i < NP; i += ST_THREADS) {  // column parts of all waves, fixed summation order
+                d2 acc = su[i];
+#pragma unroll
+                for (int w = 0; w < ST_WAVES; ++w) {
+                    const d2 t = scol[w * NP + i];
+                    acc[0] += t[0];
+                    acc[1] += t[1];
                 }
+                su[i] = acc;
             }
             wg_sync();
+        TBK_CLK(4);
+        } else {
+            wg_sync();
+        TBK_CLK(flush ? 7 : 3);
+            // column parts, one wave after the other: fixed summation order
+            for (int w = 0; w < ST_WAVES; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int c = lane + 64 * u;
+                        const d2 t = su[c];
+                        su[c] = (d2){t[0] + colacc[u][0], t[1] + colacc[u][1]};
+                    }
+                }
+                wg_sync();
+            }
         }
         // panel not applied to memory: u -= V (W^H v') + W (V^H v');  wave b reduces pair b
         if (!flush && p > 0) {
@@ -336,6 +400,7 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 su[i] = acc;
             }
             wg_sync();
+        TBK_CLK(5);
         }
         if (flush) p = 0;
 
@@ -355,7 +420,7 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
             const d2 tau = stau;
             const double a2 = -0.5 * (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
             for (int i = tid; i < NP; i += ST_THREADS) {
-                const d2 v = sx[i];
+                const d2 v = svn[i];
                 d2 w = (d2){0.0, 0.0};
                 if (i > j && i < n) {
                     const d2 t = cmul(su[i], tau);
@@ -368,6 +433,7 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
             ++p;
         }
         wg_sync();
+        TBK_CLK(6);
     }
     // last diagonal element, with whatever is still pending in the panel
     if (tid == 0) {
@@ -482,7 +548,8 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
 
 template <int NU, int NB, int ST_THREADS>
 hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E) {
-    const size_t lds = (size_t)(2 * NB + 2) * 64 * NU * sizeof(d2);
+    const bool colbuf = (NU >= 5);  // see COLBUF in the kernel
+    const size_t lds = (size_t)(2 * NB + 3 + (colbuf ? ST_THREADS / 64 : 0)) * 64 * NU * sizeof(d2);
     static bool raised[TBK_MAX_DEVICES] = {};
     {
         hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB, ST_THREADS>), (int)lds,
