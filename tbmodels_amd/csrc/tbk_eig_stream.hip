@@ -289,22 +289,31 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                             const int cc = min(c, NP - 1);
 #pragma unroll
                             for (int b = 0; b < NB; ++b) {
-                                const d2 t1 = cmulc(sV[b * NP + r], sW[b * NP + cc]);
-                                const d2 t2 = cmulc(sW[b * NP + r], sV[b * NP + cc]);
-                                av[0] -= t1[0] + t2[0];
-                                av[1] -= t1[1] + t2[1];
+                                // av -= V_b[r] conj(W_b[c]) + W_b[r] conj(V_b[c]): eight FMAs straight into av
+                                const d2 vr_b = sV[b * NP + r], wr_b = sW[b * NP + r];
+                                const d2 vc_b = sV[b * NP + cc], wc_b = sW[b * NP + cc];
+                                av[0] = fma(-vr_b[0], wc_b[0], av[0]);
+                                av[1] = fma(-vr_b[1], wc_b[0], av[1]);
+                                av[0] = fma(-vr_b[1], wc_b[1], av[0]);
+                                av[1] = fma(vr_b[0], wc_b[1], av[1]);
+                                av[0] = fma(-wr_b[0], vc_b[0], av[0]);
+                                av[1] = fma(-wr_b[1], vc_b[0], av[1]);
+                                av[0] = fma(-wr_b[1], vc_b[1], av[0]);
+                                av[1] = fma(wr_b[0], vc_b[1], av[1]);
                             }
                             if (valid) *reinterpret_cast<d2*>(row + (size_t)c * 2) = av;
                         }
                         av[0] = valid ? av[0] : 0.0;
                         av[1] = valid ? av[1] : 0.0;
-                        const d2 t = cmul(av, nv[u]);
-                        rowsum[0] += t[0];
-                        rowsum[1] += t[1];
-                        if (c > r) {  // (av = 0 on invalid lanes)
-                            const d2 tc = cmulc(vr, av);  // conj(a) * v'_r
-                            colacc[u][0] += tc[0];
-                            colacc[u][1] += tc[1];
+                        rowsum[0] = fma(av[0], nv[u][0], rowsum[0]);  // a * v'_c
+                        rowsum[1] = fma(av[0], nv[u][1], rowsum[1]);
+                        rowsum[0] = fma(-av[1], nv[u][1], rowsum[0]);
+                        rowsum[1] = fma(av[1], nv[u][0], rowsum[1]);
+                        if (c > r) {  // conj(a) * v'_r  (av = 0 on invalid lanes)
+                            colacc[u][0] = fma(vr[0], av[0], colacc[u][0]);
+                            colacc[u][1] = fma(vr[1], av[0], colacc[u][1]);
+                            colacc[u][0] = fma(vr[1], av[1], colacc[u][0]);
+                            colacc[u][1] = fma(-vr[0], av[1], colacc[u][1]);
                         }
                     }
                 }
