@@ -59,9 +59,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Eight wave-wide sums at once: 64 lanes x 8 values -> lane l ends with the total of value (l >> 3).
+// Several wave-wide sums at once: 64 lanes x 4 values -> lane l ends with the total of value (l >> 4).
 // Each stage halves the number of live values while it doubles the lanes summed (a transposing butterfly):
-// 34 VALU issues instead of 8 x 18 for eight separate wave_sum calls.  The summation tree of every value is
+// 21 VALU issues instead of 4 x 18 for four separate wave_sum calls.  The summation tree of every value is
 // fixed, so results are reproducible.
 __device__ __forceinline__ void swap_add(double& x, double y, bool half32) {
     // x <- [sum of x over the lane pair | sum of y over the lane pair] (lower | upper half, or even | odd rows)
@@ -88,21 +88,6 @@ __device__ __forceinline__ double reduce4(double (&p)[4]) {
     v += dpp_mov<0x124>(v);
     v += dpp_mov<0x122>(v);
     v += dpp_mov<0x121>(v);
-    return v;
-}
-
-__device__ __forceinline__ double reduce8(double (&p)[8], int lane) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) swap_add(p[k], p[k + 4], true);   // lane bit 5 <- value bit 2
-    swap_add(p[0], p[2], false);                                   // lane bit 4 <- value bit 1
-    swap_add(p[1], p[3], false);
-    const bool hi8 = (lane & 8) != 0;                              // lane bit 3 <- value bit 0
-    const double keep = hi8 ? p[1] : p[0];
-    const double send = hi8 ? p[0] : p[1];
-    double v = keep + dpp_mov<0x128>(send);  // row_ror:8
-    v += dpp_mov<0x141>(v);                  // row_half_mirror: i <-> 7 - i inside each group of 8
-    v += dpp_mov<0xB1>(v);                   // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);                   // quad_perm [2,3,0,1]
     return v;
 }
 
@@ -247,13 +232,12 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
         // Row r of the stored triangle: columns r .. n-1, 16 B per lane, NU loads.  The loads are UNCONDITIONAL
         // (lanes left of the diagonal or beyond n re-read the row's diagonal element; masked when used): with
         // predicated loads hipcc waited for each one where it was issued, which serialised the pass on
-        // memory latency.  A wave takes RB of its rows at a time: 4 NU loads in flight, and the 2 RB row sums
+        // memory latency.  A wave takes RB of its rows at a time: RB NU loads in flight, and the 2 RB row sums
         // (re, im) share ONE transposed reduction -- the pass is VALU-issue bound, and two wave_sum calls per
         // row were a third of its instructions.
-#ifndef TBK_STREAM_RB_SMALL
-#define TBK_STREAM_RB_SMALL 2
-#endif
-        constexpr int RB = (NU <= 2) ? TBK_STREAM_RB_SMALL : 2;  // 16 NU RB bytes of row data per lane: keep two workgroups per CU
+        // rows per group: 2 everywhere (4 and 8 were measured for rows of <= 2 chunks: more registers, fewer
+        // workgroups per CU, no faster)
+        constexpr int RB = 2;
         auto load_group = [&](int r0, d2 (&a)[RB][NU]) {
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
@@ -320,22 +304,7 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
                 part[2 * q] = rowsum[0];
                 part[2 * q + 1] = rowsum[1];
             }
-            if constexpr (RB == 8) {
-                double lo8[8], hi8[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    lo8[k] = part[k];
-                    hi8[k] = part[8 + k];
-                }
-                const double t0 = reduce8(lo8, lane), t1 = reduce8(hi8, lane);
-                const int r_a = r0 + (lane >> 4) * ST_WAVES, r_b = r_a + 4 * ST_WAVES;
-                if ((lane & 7) == 0 && r_a < n) reinterpret_cast<double*>(su)[2 * r_a + ((lane >> 3) & 1)] = t0;
-                if ((lane & 7) == 0 && r_b < n) reinterpret_cast<double*>(su)[2 * r_b + ((lane >> 3) & 1)] = t1;
-            } else if constexpr (RB == 4) {
-                const double total = reduce8(part, lane);  // lane l: value l >> 3 = (row slot l >> 4, re / im bit 3)
-                const int r_mine = r0 + (lane >> 4) * ST_WAVES;
-                if ((lane & 7) == 0 && r_mine < n) reinterpret_cast<double*>(su)[2 * r_mine + ((lane >> 3) & 1)] = total;
-            } else {
+            {
                 const double total = reduce4(part);  // lane l: value l >> 4 = (row slot l >> 5, re / im bit 4)
                 const int r_mine = r0 + (lane >> 5) * ST_WAVES;
                 if ((lane & 15) == 0 && r_mine < n) reinterpret_cast<double*>(su)[2 * r_mine + ((lane >> 4) & 1)] = total;
