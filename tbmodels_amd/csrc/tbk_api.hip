@@ -285,7 +285,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_H2, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb, &m->ws_part};
     for (DevBuf* b : bufs) b->release();
     delete m;
 }

@@ -27,6 +27,8 @@
 // Roofline: 8 * ncol * n_r flops per k-point against (16 + 16) B of operand traffic per
 // (k-tile row + column) K step -- FP64-MFMA bound (78.6 TFLOP/s), not HBM bound; see DESIGN.md.
 
+#include <algorithm>
+
 #include "tbk_internal.h"
 
 namespace {
@@ -58,7 +60,29 @@ struct HkArgs {
     int mt_count;  // k tiles
     int nt_count;  // element tiles
     int xcd_rows;  // 0: plain order; > 0: k tiles per XCD super-row
+    // split-K (small k batches): blockIdx.y owns a contiguous range of K stages and stores its partial tile to
+    // P[split][k][e] (re, im) instead of scattering it; hk_finish_kernel adds the partials in fixed order
+    double* P;
+    int splits;
 };
+
+// One finished element of the packed tile -> H[k][i][j] (and H[k][j][i] conjugated in FULL mode), with the
+// convention-1 orbital phases if asked (_tb_model.py:1124-1128; the table e[k][p] = exp(2 pi i k.pos_p) is
+// filled once per chunk by tbk_launch_orbital_phases).
+template <int MODE, int CONV>
+__device__ __forceinline__ void store_element(const HkArgs& a, int64_t kq, int oi, int oj, double re, double im) {
+    if (CONV == 1) {
+        const d2 ei = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oi) * 2);
+        const d2 ej = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oj) * 2);
+        const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
+        const double t = re * cs - im * sn;
+        im = re * sn + im * cs;
+        re = t;
+    }
+    double* hk = a.H + (size_t)kq * a.n_orb * a.n_orb * 2;
+    *reinterpret_cast<d2*>(hk + ((size_t)oi * a.n_orb + oj) * 2) = (d2){re, im};
+    if (MODE == HK_FULL && oi != oj) *reinterpret_cast<d2*>(hk + ((size_t)oj * a.n_orb + oi) * 2) = (d2){re, -im};
+}
 
 __device__ __forceinline__ bool tile_of_block(const HkArgs& a, int b, int& mt, int& nt) {
     if (a.xcd_rows == 0) {
@@ -93,7 +117,7 @@ __device__ __forceinline__ bool tile_of_block(const HkArgs& a, int b, int& mt, i
     return true;
 }
 
-template <int MODE, int CONV>
+template <int MODE, int CONV, bool SPLIT>
 __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
@@ -125,7 +149,12 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) acc[i][j][p] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int n_stage = (int)(a.k2 / TBK_BK);
+    int s_begin = 0, n_stage = (int)(a.k2 / TBK_BK);
+    if (SPLIT) {
+        const int per = (n_stage + a.splits - 1) / a.splits;
+        s_begin = min((int)blockIdx.y * per, n_stage);
+        n_stage = min(s_begin + per, n_stage);
+    }
 
     // global -> LDS without a register round trip (global_load_lds_dwordx4): every wave-instruction
     // copies one 1 KiB K row; the LDS destination is the wave-uniform row base + 16 B per lane, which is
@@ -144,11 +173,11 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
         }
     };
 
-    if (n_stage > 0) issue_stage(0, 0);
+    if (n_stage > s_begin) issue_stage(s_begin, 0);
     __syncthreads();  // drains the LDS-DMA queue (vmcnt) before the barrier
 
-    for (int s = 0; s < n_stage; ++s) {
-        const int buf = s & 1;
+    for (int s = s_begin; s < n_stage; ++s) {
+        const int buf = (s - s_begin) & 1;
         if (s + 1 < n_stage) issue_stage(s + 1, buf ^ 1);  // lands during this stage's MFMAs
 
         const double* sA = smem + buf * STAGE_DOUBLES + wm * 64 + l15;
@@ -175,8 +204,7 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
         __syncthreads();  // next stage has landed (vmcnt(0)) and everyone is done reading this one
     }
 
-    // ---- epilogue: scatter the packed tile into H[k][i][j] (and H[k][j][i]) ----
-    const size_t nn = (size_t)a.n_orb * a.n_orb;
+    // ---- epilogue: scatter the packed tile into H[k][i][j] (and H[k][j][i]), or park the partial tile ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = (int)n0 + (wn * 2 + j) * 16 + l15;
@@ -189,36 +217,55 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t kq = m0 + wm * 64 + i * 16 + l4 + 4 * r;
                 if (kq >= a.nk) continue;
-                double re = acc[i][j][0][r];
-                double im = acc[i][j][1][r];
-                if (CONV == 1) {
-                    // H[i][j] *= conj(e_i) e_j,  e_p = exp(2 pi i k.pos_p)   (_tb_model.py:1124-1128);
-                    // the table e[k][p] is filled once per chunk by tbk_launch_orbital_phases
-                    const d2 ei = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oi) * 2);
-                    const d2 ej = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oj) * 2);
-                    const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
-                    const double t = re * cs - im * sn;
-                    im = re * sn + im * cs;
-                    re = t;
+                if (SPLIT) {
+                    double* part = a.P + (((size_t)blockIdx.y * a.nk_pad + kq) * a.ncol_pad + e) * 2;
+                    *reinterpret_cast<d2*>(part) = (d2){acc[i][j][0][r], acc[i][j][1][r]};
+                } else {
+                    store_element<MODE, CONV>(a, kq, oi, oj, acc[i][j][0][r], acc[i][j][1][r]);
                 }
-                double* hk = a.H + (size_t)kq * nn * 2;
-                *reinterpret_cast<d2*>(hk + ((size_t)oi * a.n_orb + oj) * 2) = (d2){re, im};
-                if (MODE == HK_FULL && oi != oj)
-                    *reinterpret_cast<d2*>(hk + ((size_t)oj * a.n_orb + oi) * 2) = (d2){re, -im};
             }
         }
     }
+}
+
+// split-K finish: one thread per (k-point, packed element) adds the partial tiles in split order and stores the
+// element like the epilogue above.
+template <int MODE, int CONV>
+__global__ void __launch_bounds__(256) hk_finish_kernel(const HkArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int e = (int)(idx % a.ncol_pad);
+    const int64_t kq = idx / a.ncol_pad;
+    if (kq >= a.nk) return;
+    const int32_t ij = a.colmap[e];
+    if (ij < 0) return;
+    double re = 0.0, im = 0.0;
+    for (int sp = 0; sp < a.splits; ++sp) {
+        const d2 v = *reinterpret_cast<const d2*>(a.P + (((size_t)sp * a.nk_pad + kq) * a.ncol_pad + e) * 2);
+        re += v[0];
+        im += v[1];
+    }
+    store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
 }
 
 template <int MODE, int CONV>
 hipError_t launch(const HkArgs& a, int grid, hipStream_t s) {
     const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
     static bool raised[TBK_MAX_DEVICES] = {};
-    {
-        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV>), (int)lds, raised);
+    static bool raised_split[TBK_MAX_DEVICES] = {};
+    if (a.splits > 1) {
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds,
+                                           raised_split);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(grid, a.splits), dim3(256), lds, s, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int64_t threads = a.nk * a.ncol_pad;
+        hipLaunchKernelGGL((hk_finish_kernel<MODE, CONV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV>), dim3(grid), dim3(256), lds, s, a);
+    hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, false>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -250,6 +297,24 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     } else {
         a.xcd_rows = 0;
         grid = a.mt_count * a.nt_count;
+    }
+    // Small k batches: a workgroup's K loop is a serial chain (1.06 ms at N_R = 4096 whatever the batch), and fewer
+    // than ~512 workgroups leave CUs idle or end on a ragged round -- split K across blockIdx.y so that the launch
+    // fills the chip (~1280 workgroups; measured at N_orb = 64, N_R = 4096: one k-point 1056 -> 163 us, 1000
+    // k-points 2137 -> 1340 us).  The operands are still read once.
+    a.P = nullptr;
+    a.splits = 1;
+    const int n_stage = (int)(m->k2 / TBK_BK);
+    const int tiles = a.mt_count * a.nt_count;
+    if (tiles < 768 && n_stage >= 16) {
+        int splits = std::min((1280 + tiles / 2) / tiles, n_stage / 4);
+        const size_t per_split = (size_t)nk_pad * a.ncol_pad * 2 * sizeof(double);
+        splits = (int)std::min<size_t>((size_t)splits, (size_t(256) << 20) / per_split);
+        if (splits > 1) {
+            TBK_CHECK(m->ws_part.reserve(per_split * splits));
+            a.P = m->ws_part.as<double>();
+            a.splits = splits;
+        }
     }
     StageTimer t(m, TBK_T_HK);
     if (mode == HK_TRI) {

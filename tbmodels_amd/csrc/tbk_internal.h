@@ -149,6 +149,7 @@ struct tbk_model {
     DevBuf ws_orb;    // convention 1: orbital phase table of the current chunk
     DevBuf ws_out;
     DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
+    DevBuf ws_part;   // split-K partial tiles of the dense H(k) kernel (small k batches)
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};

@@ -162,6 +162,22 @@ def test_seeded_dense_vs_oracle(n_orb, n_r, n_k):
     _close(model.hamilton(sub, convention=1), oracle.hamilton(r_vec, hop, sub, 1, pos=pos))
 
 
+@pytest.mark.parametrize("n_k", [1, 5, 130, 700, 3000])
+def test_split_k_batches_vs_oracle(n_k):
+    """Small k batches with many lattice vectors take the split-K launch of the dense kernel (partial tiles added in
+    fixed order by the finish kernel); 3000 k-points are past it.  All modes of the epilogue."""
+    r_vec, hop, pos = syn.dense_model_arrays(16, 300, syn.MODEL_SEED + 31)
+    k = syn.random_kpoints(n_k, seed=n_k) * 3 - 1.5
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    sub = slice(0, min(n_k, 40))
+    _close(model.hamilton(k)[sub], oracle.hamilton(r_vec, hop, k[sub]))
+    _close(model.hamilton(k, convention=1)[sub], oracle.hamilton(r_vec, hop, k[sub], 1, pos=pos))
+    _close(np.array(model.eigenval(k))[sub], np.array(oracle.eigenval(r_vec, hop, k[sub])))
+    again = model.hamilton(k)
+    assert np.array_equal(again, model.hamilton(k))  # fixed summation order: bit-identical run to run
+    assert np.array_equal(again, np.conj(np.swapaxes(again, 1, 2)))  # exactly Hermitian
+
+
 def test_seeded_csr_vs_oracle():
     """BASELINE config 3 shape at reduced size: N=128, N_R=64, 2 % fill."""
     r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(128, 64, syn.MODEL_SEED + 3)

@@ -25,8 +25,10 @@ with np.load(os.path.join(ROOT, "tests", "golden", "silicon.npz")) as g:
     silicon = tbmodels_amd.Model.from_packed(g["R"], g["hop"], pos=g["pos"])
 r_vec, hop, pos = syn.dense_model_arrays(64, 512, syn.MODEL_SEED + 3)
 big = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
-for name, model in (("silicon N=8 N_R=95", silicon), ("dense N=64 N_R=512", big)):
-    for pinned in (False, True):
+r_vec, hop, pos = syn.dense_model_arrays(64, 4096, syn.MODEL_SEED + 2)
+headline = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+for name, model in (("silicon N=8 N_R=95", silicon), ("dense N=64 N_R=512", big), ("dense N=64 N_R=4096", headline)):
+    for pinned in (False,):
         model.pin_staging(pinned)
         for nk in (1, 10, 100, 1000):
             k = syn.random_kpoints(nk)
