@@ -395,11 +395,11 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
 // workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
 // tridiagonal stage on the QL stream: lane-per-matrix QL up to 64 orbitals, bisection above
-// Calls of at most max(4096, 256 n) k-points take the bisection kernel for every chunk: the lane-per-matrix QL
+// Calls of at most max(4096, 640 n) k-points take the bisection kernel for every chunk: the lane-per-matrix QL
 // is a serial chain of ~n^2 rotations (2.7 ms at n = 64 however few matrices there are) that only pays when tens of
 // thousands of matrices share it and it can hide under the next chunk's reduction; bisection spends a wave per
-// matrix (VALU work ~ n per matrix).  Measured crossover at n = 64: ~20 000 k-points (8192: 11.2 vs 13.1 ms,
-// 16384: 22.0 vs 22.5, 32768: 41.5 vs 40.2).
+// matrix (VALU work ~ n per matrix).  Measured crossover at n = 64: ~49 000 k-points (24576: 30.4 vs 31.5 ms,
+// 32768: 39.7 vs 40.2, 49152: 59.6 vs 59.4, 65536: 78.3 vs 77.2).
 constexpr int64_t TBK_SMALL_CALL = 4096;
 constexpr int TBK_SMALL_CALL_MIN_N = 12;  // below this the QL chain (61 us at n = 8) is the shorter one
 
@@ -443,7 +443,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const int64_t n_chunks = (int64_t)sched.size();
     const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
     // a property of the call, not of its chunking: TBK_OPT_K_CHUNK must not change the results
-    const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, 256 * (int64_t)m->n_orb) && m->n_orb > TBK_SMALL_CALL_MIN_N;
+    const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, 640 * (int64_t)m->n_orb) && m->n_orb > TBK_SMALL_CALL_MIN_N;
     TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));

@@ -494,28 +494,45 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const int m = tid;  // this lane's eigenvalue index
     for (int it = 0; it < iters; ++it) {
         const double x = 0.5 * (lo + hi);
-        // Sturm count at x
+        // Sturm count at x: sign changes along p_0 = 1, p_1, ..., p_n, a zero taking the sign opposite to its
+        // predecessor.  Signs are carried as integer bits (11 VALU issues per step; the bool / select form compiled
+        // to 37 and made the single-k eigenval call 0.34 ms at n = 64).
         double pp = 1.0, p = sd[0] - x;
-        int cnt = (p < 0.0 || p == 0.0) ? 1 : 0;  // a zero takes the sign opposite to its predecessor (+1)
-        bool neg = cnt != 0;
-        for (int i0 = 1; i0 < n; i0 += 8) {
-            const int i1 = min(i0 + 8, n);
-            for (int i = i0; i < i1; ++i) {
-                const double pn = fma(sd[i] - x, p, -se2[i - 1] * pp);
-                pp = p;
-                p = pn;
-                const bool nneg = (p < 0.0) || (p == 0.0 && !neg);
-                cnt += (nneg != neg) ? 1 : 0;
-                neg = nneg;
-            }
-            // rescale (p, pp) by a common power of two: signs and the recurrence are unaffected
+        int sgn = (p <= 0.0) ? 1 : 0;  // p_1 against p_0 = 1 > 0
+        int cnt = sgn;
+        auto step = [&](double d_i, double e2_prev) {
+            const double pn = fma(d_i - x, p, -e2_prev * pp);
+            pp = p;
+            p = pn;
+            const int neg_bit = (int)((unsigned)__double2hiint(p) >> 31);
+            const int s_new = (p == 0.0) ? (sgn ^ 1) : neg_bit;
+            cnt += s_new ^ sgn;
+            sgn = s_new;
+        };
+        auto rescale = [&]() {  // (p, pp) by a common power of two: signs and the recurrence are unaffected
             const double big = fmax(fabs(p), fabs(pp));
             if (big > 0.0) {
                 const int ex = -ilogb(big);
                 p = ldexp(p, ex);
                 pp = ldexp(pp, ex);
             }
+        };
+        int i0 = 1;
+        for (; i0 + 8 <= n; i0 += 8) {
+            // the eight (d, e^2) pairs of the block are fetched together (uniform addresses: LDS broadcasts); read
+            // one by one inside the recurrence they put an LDS round trip into every step of the serial chain
+            double dv[8], ev[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                dv[t] = sd[i0 + t];
+                ev[t] = se2[i0 + t - 1];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) step(dv[t], ev[t]);
+            rescale();
         }
+        for (; i0 < n; ++i0) step(sd[i0], se2[i0 - 1]);  // ragged tail (< 8 steps)
+        rescale();
         if (cnt > m)
             hi = x;  // more than m eigenvalues below x: the m-th lies left of x
         else
