@@ -489,7 +489,14 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
         double* d = sd + lane;
         double* e = se + lane;
         bool failed = false;
-        for (int l = 0; l < n && !failed; ++l) {
+        // NaN / Inf anywhere in H(k) reaches (d, e): hand out NaN eigenvalues (the caller raises the ValueError of
+        // scipy's check_finite) instead of iterating to the non-convergence limit
+        bool finite = true;
+        for (int i = 0; i < n; ++i) finite = finite && isfinite(d[i * QL_LD]) && isfinite(e[i * QL_LD]);
+        if (!finite) {
+            for (int i = 0; i < n; ++i) d[i * QL_LD] = __builtin_nan("");
+        }
+        for (int l = 0; l < n && !failed && finite; ++l) {
             int iter = 0;
             while (true) {
                 // look for a negligible off-diagonal; |d[m]| is carried over from the previous step
@@ -552,7 +559,7 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
         }
         if (failed) atomicAdd(fail_count, 1);
         // ascending order, like eigvalsh: insertion sort of this lane's column
-        for (int a = 1; a < n; ++a) {
+        for (int a = 1; a < n && finite; ++a) {
             const double key = d[a * QL_LD];
             int b = a - 1;
             while (b >= 0 && d[b * QL_LD] > key) {

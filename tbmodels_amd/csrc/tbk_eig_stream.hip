@@ -461,6 +461,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const int nwave = blockDim.x >> 6;
     const size_t mat = blockIdx.x;
     double lo_g = 1e300, hi_g = -1e300;
+    int bad = 0;
     if (tid < n) {
         const double d = D[mat * n + tid];
         const double e = (tid < n - 1) ? E[mat * n + tid] : 0.0;
@@ -470,6 +471,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         const double rad = fabs(e) + fabs(em);  // Gershgorin disc
         lo_g = d - rad;
         hi_g = d + rad;
+        bad = !(isfinite(d) && isfinite(e));
     }
     lo_g = wave_min(lo_g);
     hi_g = wave_max(hi_g);
@@ -477,7 +479,12 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         sred[0][wave] = lo_g;
         sred[1][wave] = hi_g;
     }
-    __syncthreads();
+    // NaN / Inf anywhere in H(k) reaches (d, e); fmin / fmax and the sign tests below would quietly drop it.
+    // The caller maps non-finite eigenvalues to the ValueError of scipy's check_finite (_tb_model.py:1147-1150).
+    if (__syncthreads_or(bad)) {
+        if (tid < n) out[mat * n + tid] = __builtin_nan("");
+        return;
+    }
     double gl = sred[0][0], gu = sred[1][0];
     for (int w = 1; w < nwave; ++w) {
         gl = fmin(gl, sred[0][w]);

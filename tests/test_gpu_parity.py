@@ -222,6 +222,23 @@ def test_non_finite_k_is_value_error(silicon):
     assert np.isnan(model.hamilton([0.1, np.nan, 0.2])).any()
 
 
+@pytest.mark.parametrize("n_orb,n_k", [(8, 5), (8, 6000), (40, 3), (64, 50000), (100, 4), (300, 2)])
+def test_non_finite_hopping_is_value_error(n_orb, n_k):
+    """NaN / Inf in the model: every eigensolver path (1-wave and 4-wave reduction, QL and bisection, streaming
+    reduction) terminates and `eigenval` raises like scipy's check_finite (`_tb_model.py:1147-1150`)."""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 4, syn.MODEL_SEED + n_orb)
+    for bad in (np.nan, np.inf):
+        broken = hop.copy()
+        broken[1, 0, n_orb - 1] = bad
+        model = tbmodels_amd.Model.from_packed(r_vec, broken, pos=pos)
+        k = syn.random_kpoints(n_k)
+        with pytest.raises(ValueError):
+            model.eigenval(k)
+        assert not np.isfinite(model.hamilton(k[:2])).all()
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)  # the library is still usable afterwards
+    assert np.isfinite(np.array(model.eigenval(k[:3]))).all()
+
+
 def test_periodicity_and_linearity_properties():
     """Size-independent properties at the headline orbital count: H(k + G) = H(k); H is additive in hop."""
     r_vec, hop, pos = syn.dense_model_arrays(64, 256, syn.MODEL_SEED + 1)
