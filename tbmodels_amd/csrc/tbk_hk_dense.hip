@@ -64,6 +64,7 @@ struct HkArgs {
     // P[split][k][e] (re, im) instead of scattering it; hk_finish_kernel adds the partials in fixed order
     double* P;
     int splits;
+    int64_t p_rows;  // k rows per split in P
 };
 
 // One finished element of the packed tile -> H[k][i][j] (and H[k][j][i] conjugated in FULL mode), with the
@@ -218,13 +219,47 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                 const int64_t kq = m0 + wm * 64 + i * 16 + l4 + 4 * r;
                 if (kq >= a.nk) continue;
                 if (SPLIT) {
-                    double* part = a.P + (((size_t)blockIdx.y * a.nk_pad + kq) * a.ncol_pad + e) * 2;
+                    double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kq) * a.ncol_pad + e) * 2;
                     *reinterpret_cast<d2*>(part) = (d2){acc[i][j][0][r], acc[i][j][1][r]};
                 } else {
                     store_element<MODE, CONV>(a, kq, oi, oj, acc[i][j][0][r], acc[i][j][1][r]);
                 }
             }
         }
+    }
+}
+
+// Batches of at most 32 k-points (Z2Pack-style callers evaluate one k-point per call): the 128-row MFMA tile would
+// spend most of its work on padding (127/128 for one k-point), so this is a plain matrix-vector product on the vector
+// unit -- one thread per packed element, up to 32 accumulator pairs, K split over blockIdx.y like the split-K launch above and finished by
+// the same hk_finish_kernel.  Bound by reading Bt once (272 MB at N_orb = 64, N_R = 4096: ~55 us).
+template <int NKV>
+__global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_per_slice) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.ncol_pad) return;
+    const int64_t kk0 = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t kk1 = min(kk0 + rows_per_slice, a.k2);
+    const int64_t ldb = (int64_t)a.ncol_pad * 2;
+    const double* bre = a.Bt + (size_t)(e >> 4) * 32 + (e & 15);  // Bt[kk][tile][re | im][16]
+    double acc[NKV][2];
+#pragma unroll
+    for (int q = 0; q < NKV; ++q) acc[q][0] = acc[q][1] = 0.0;
+#pragma unroll 4
+    for (int64_t kk = kk0; kk < kk1; ++kk) {
+        const double br = bre[kk * ldb], bi = bre[kk * ldb + 16];
+        const double* arow = a.A + kk * a.nk_pad;  // uniform: phase row kk, k-points 0 .. NKV-1
+#pragma unroll
+        for (int q = 0; q < NKV; ++q) {
+            const double aq = arow[q];
+            acc[q][0] = fma(aq, br, acc[q][0]);
+            acc[q][1] = fma(aq, bi, acc[q][1]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NKV; ++q) {
+        if (q >= a.nk) break;
+        double* part = a.P + (((size_t)blockIdx.y * a.p_rows + q) * a.ncol_pad + e) * 2;
+        *reinterpret_cast<d2*>(part) = (d2){acc[q][0], acc[q][1]};
     }
 }
 
@@ -240,11 +275,33 @@ __global__ void __launch_bounds__(256) hk_finish_kernel(const HkArgs a) {
     if (ij < 0) return;
     double re = 0.0, im = 0.0;
     for (int sp = 0; sp < a.splits; ++sp) {
-        const d2 v = *reinterpret_cast<const d2*>(a.P + (((size_t)sp * a.nk_pad + kq) * a.ncol_pad + e) * 2);
+        const d2 v = *reinterpret_cast<const d2*>(a.P + (((size_t)sp * a.p_rows + kq) * a.ncol_pad + e) * 2);
         re += v[0];
         im += v[1];
     }
     store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
+}
+
+template <int MODE, int CONV>
+hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
+    const dim3 grid((unsigned)((a.ncol_pad + 255) / 256), (unsigned)a.splits);
+    if (a.nk <= 1)
+        hipLaunchKernelGGL(hk_gemv_kernel<1>, grid, dim3(256), 0, s, a, rows_per_slice);
+    else if (a.nk <= 2)
+        hipLaunchKernelGGL(hk_gemv_kernel<2>, grid, dim3(256), 0, s, a, rows_per_slice);
+    else if (a.nk <= 4)
+        hipLaunchKernelGGL(hk_gemv_kernel<4>, grid, dim3(256), 0, s, a, rows_per_slice);
+    else if (a.nk <= 8)
+        hipLaunchKernelGGL(hk_gemv_kernel<8>, grid, dim3(256), 0, s, a, rows_per_slice);
+    else if (a.nk <= 16)
+        hipLaunchKernelGGL(hk_gemv_kernel<16>, grid, dim3(256), 0, s, a, rows_per_slice);
+    else
+        hipLaunchKernelGGL(hk_gemv_kernel<32>, grid, dim3(256), 0, s, a, rows_per_slice);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t threads = a.nk * a.ncol_pad;
+    hipLaunchKernelGGL((hk_finish_kernel<MODE, CONV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 template <int MODE, int CONV>
@@ -298,12 +355,35 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
         a.xcd_rows = 0;
         grid = a.mt_count * a.nt_count;
     }
+    a.P = nullptr;
+    a.splits = 1;
+    a.p_rows = 0;
+    if (nk <= 32 && m->k2 > 0) {
+        // matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
+        const int col_blocks = (a.ncol_pad + 255) / 256;
+        const size_t per_split = (size_t)nk * a.ncol_pad * 2 * sizeof(double);
+        int slices = std::max(1, std::min(1024 / col_blocks, (int)(m->k2 / 32)));
+        slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices, (size_t(64) << 20) / per_split));
+        const int rows_per_slice = (int)((m->k2 + slices - 1) / slices);
+        slices = (int)((m->k2 + rows_per_slice - 1) / rows_per_slice);
+        TBK_CHECK(m->ws_part.reserve(per_split * slices));
+        a.P = m->ws_part.as<double>();
+        a.splits = slices;
+        a.p_rows = nk;
+        StageTimer t(m, TBK_T_HK);
+        if (mode == HK_TRI) {
+            TBK_HIP((launch_gemv<HK_TRI, 2>(a, rows_per_slice, m->stream)));
+        } else if (convention == 1) {
+            TBK_HIP((launch_gemv<HK_FULL, 1>(a, rows_per_slice, m->stream)));
+        } else {
+            TBK_HIP((launch_gemv<HK_FULL, 2>(a, rows_per_slice, m->stream)));
+        }
+        return TBK_OK;
+    }
     // Small k batches: a workgroup's K loop is a serial chain (1.06 ms at N_R = 4096 whatever the batch), and fewer
     // than ~512 workgroups leave CUs idle or end on a ragged round -- split K across blockIdx.y so that the launch
     // fills the chip (~1280 workgroups; measured at N_orb = 64, N_R = 4096: one k-point 1056 -> 163 us, 1000
     // k-points 2137 -> 1340 us).  The operands are still read once.
-    a.P = nullptr;
-    a.splits = 1;
     const int n_stage = (int)(m->k2 / TBK_BK);
     const int tiles = a.mt_count * a.nt_count;
     if (tiles < 768 && n_stage >= 16) {
@@ -314,6 +394,7 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
             TBK_CHECK(m->ws_part.reserve(per_split * splits));
             a.P = m->ws_part.as<double>();
             a.splits = splits;
+            a.p_rows = nk_pad;
         }
     }
     StageTimer t(m, TBK_T_HK);

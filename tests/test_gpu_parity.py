@@ -162,10 +162,11 @@ def test_seeded_dense_vs_oracle(n_orb, n_r, n_k):
     _close(model.hamilton(sub, convention=1), oracle.hamilton(r_vec, hop, sub, 1, pos=pos))
 
 
-@pytest.mark.parametrize("n_k", [1, 5, 130, 700, 3000])
-def test_split_k_batches_vs_oracle(n_k):
-    """Small k batches with many lattice vectors take the split-K launch of the dense kernel (partial tiles added in
-    fixed order by the finish kernel); 3000 k-points are past it.  All modes of the epilogue."""
+@pytest.mark.parametrize("n_k", [1, 2, 3, 5, 8, 9, 16, 17, 32, 33, 130, 700, 3000])
+def test_small_batches_vs_oracle(n_k):
+    """Up to 32 k-points take the matrix-vector kernel (one instantiation per 1 / 2 / 4 / 8 / 16 / 32 accumulator
+    pairs), larger small batches the split-K launch of the MFMA kernel; both park partial sums that the finish
+    kernel adds in fixed order.  3000 k-points are past both.  All modes of the epilogue."""
     r_vec, hop, pos = syn.dense_model_arrays(16, 300, syn.MODEL_SEED + 31)
     k = syn.random_kpoints(n_k, seed=n_k) * 3 - 1.5
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
