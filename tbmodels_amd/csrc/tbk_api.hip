@@ -448,6 +448,21 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
     double* d_H = m->ws_H.as<double>();
+    if (n_chunks == 1) {
+        // one chunk has nothing to overlap: everything in order on the main stream, no cross-stream events (they
+        // cost more than the kernels of a single-k call)
+        const int64_t nk_pad = phase_ld(nk);
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        double* d_A = m->ws_phase.as<double>();
+        double* d_de = debuf[0]->as<double>();
+        TBK_CHECK(fill_rows(m, d_k, nk, nk_pad, d_A));
+        TBK_CHECK(build_h(m, d_A, nk, nk_pad, HK_TRI, 2, d_k, nullptr, d_H));
+        if (tbk_eig_small_supported(m->n_orb))
+            TBK_CHECK(tbk_launch_tridiag(m, m->stream, d_H, nk, d_de));
+        else
+            TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream, d_H, nk, d_de));
+        return launch_tridiag_eigenvalues(m, m->stream, d_de, nk, d_E, false, small_call);
+    }
     int64_t prev_c0 = 0, prev_nkc = 0, c0 = 0;
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int b = (int)(c & 1);
