@@ -46,6 +46,9 @@ CONFIGS = {
     "cfg1": ("silicon", 8, 95, 1000, 1),
     "cfg2": ("dense", 64, 4096, 100_000, 2),
     "cfg3": ("csr", 256, 512, 50_000, 3),
+    # the cfg2 model on the 100 x 100 x 100 uniform mesh (meshgrid "ij" order); with N ranks every rank takes a
+    # contiguous slab of 1e6 / N mesh points (the one config whose total work is fixed: not the bench line)
+    "cfg4": ("dense", 64, 4096, 1_000_000, 2),
     "cfg5": ("dense", 512, 2048, 10_000, 5),
 }
 
@@ -160,6 +163,16 @@ def main():
     if args.config == "cfg1":
         k_all = synthetic.uniform_grid(10)
         k_slab = k_all[:nk_gpu]
+    elif args.config == "cfg4":
+        from tbmodels_amd.sharding import slab_bounds  # pylint: disable=import-outside-toplevel
+
+        if not args.nk:
+            lo, hi = slab_bounds(100 ** 3, world, rank)
+            nk_gpu = slab_bounds(100 ** 3, world, 0)[1]  # equal slabs for the all-gather (1e6 divides by 1, 2, 4, 8)
+            hi = lo + nk_gpu
+        else:
+            lo, hi = rank * nk_gpu, (rank + 1) * nk_gpu
+        k_slab = synthetic.grid_slab(100, lo, hi)
     else:
         rng = np.random.default_rng(synthetic.K_SEED)
         k_slab = None
@@ -348,7 +361,7 @@ def main():
 
         sample = args.cpu_sample
         if sample < 0:
-            sample = {"cfg1": 1000, "cfg2": 256, "cfg3": 48, "cfg5": 4}[args.config]
+            sample = {"cfg1": 1000, "cfg2": 256, "cfg3": 48, "cfg4": 256, "cfg5": 4}[args.config]
         cpu = None
         parity = None
         if sample > 0 and not args.construct_only:
@@ -371,14 +384,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.config == "cfg4" and not args.nk else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "%s: %s N_orb=%d N_R=%d, %d %s k-points per GPU, eigenval (H(k)+eig)"
                             % (args.config, arrays["kind"], n_orb, n_r, nk_gpu,
-                               "grid" if args.config == "cfg1" else "random"),
+                               "grid" if args.config in ("cfg1", "cfg4") else "random"),
                 "kpoints_per_gpu": nk_gpu,
                 "sharding": "contiguous k slabs, hoppings replicated, all-gather of eigenvalue slabs" if world > 1
                             else "single GPU",

@@ -66,7 +66,9 @@ enum { TBK_EIG_AUTO = 0, TBK_EIG_WAVE = 1, TBK_EIG_ROCSOLVER = 2 };
 enum {
     TBK_OPT_EIGENSOLVER = 1, /* one of TBK_EIG_*                                           */
     TBK_OPT_K_CHUNK = 2,     /* max k-points per internal chunk (0 = choose from free HBM) */
-    TBK_OPT_TIMING = 3       /* 1: bracket every kernel with HIP events (tbk_get_timing)   */
+    TBK_OPT_TIMING = 3,      /* 1: bracket every kernel with HIP events (tbk_get_timing)   */
+    TBK_OPT_FOLD = 4         /* 0: never fold k lists with long runs of one shared component (grids) into
+                              *    lower-dimensional models (default 1; dense models, eigenval only)          */
 };
 
 /* ---- library / device ------------------------------------------------------------------ */

@@ -23,7 +23,7 @@ TBK_ERR_NOT_FINITE = 4
 TBK_ERR_NO_CONVERGENCE = 5
 
 TBK_EIG_AUTO, TBK_EIG_WAVE, TBK_EIG_ROCSOLVER = 0, 1, 2
-TBK_OPT_EIGENSOLVER, TBK_OPT_K_CHUNK, TBK_OPT_TIMING = 1, 2, 3
+TBK_OPT_EIGENSOLVER, TBK_OPT_K_CHUNK, TBK_OPT_TIMING, TBK_OPT_FOLD = 1, 2, 3, 4
 TBK_T_PHASE, TBK_T_HK, TBK_T_EIG, TBK_T_QL, TBK_T_COUNT = 0, 1, 2, 3, 4
 STAGE_NAMES = ("phase", "hk", "eig", "ql")
 

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 
 #include "tbk_internal.h"
@@ -156,6 +157,7 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
                                   hipMemcpyHostToDevice)));
         m->staged_bytes += (int64_t)(colmap.size() * sizeof(int32_t));
     }
+    if (n_r > 0 && R != nullptr && k_rows_per_r == 2) m->h_R.assign(R, R + (size_t)n_r * dim);
     if (m->n_r_pad > 0 && R != nullptr) {
         std::vector<int32_t> r_pad((size_t)m->n_r_pad * dim, 0);
         std::memcpy(r_pad.data(), R, (size_t)n_r * dim * sizeof(int32_t));
@@ -285,8 +287,9 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_H2, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb, &m->ws_part};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold};
     for (DevBuf* b : bufs) b->release();
+    tbk_fold_release(m);
     delete m;
 }
 
@@ -303,6 +306,9 @@ extern "C" int tbk_model_set_option(tbk_model* m, int option, int64_t value) {
             return TBK_OK;
         case TBK_OPT_TIMING:
             m->timing = value != 0;
+            return TBK_OK;
+        case TBK_OPT_FOLD:
+            m->fold_enabled = value != 0;
             return TBK_OK;
         default:
             tbk_set_error("unknown option %d", option);
@@ -434,7 +440,19 @@ static std::vector<int64_t> chunk_schedule(tbk_model* m, int64_t nk, int64_t chu
     return out;
 }
 
-static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
+// Fills H for k-points [c0, c0 + nkc) of the call (phase rows + contraction on the main stream).
+using HBuilder = std::function<int(int64_t c0, int64_t nkc, double* d_H)>;
+
+static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, double* d_E, const HBuilder* builder = nullptr) {
+    const HBuilder direct = [&](int64_t c0, int64_t nkc, double* d_H) -> int {
+        const int64_t nk_pad = phase_ld(nkc);
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        double* d_A = m->ws_phase.as<double>();
+        const double* kc = d_k + c0 * m->dim;
+        TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
+        return build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H);
+    };
+    const HBuilder& build = builder ? *builder : direct;
     const int64_t chunk = choose_chunk(m, nk, true);
     const size_t n = (size_t)m->n_orb;
     const size_t nn2 = n * n * 2;
@@ -451,12 +469,8 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     if (n_chunks == 1) {
         // one chunk has nothing to overlap: everything in order on the main stream, no cross-stream events (they
         // cost more than the kernels of a single-k call)
-        const int64_t nk_pad = phase_ld(nk);
-        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
-        double* d_A = m->ws_phase.as<double>();
         double* d_de = debuf[0]->as<double>();
-        TBK_CHECK(fill_rows(m, d_k, nk, nk_pad, d_A));
-        TBK_CHECK(build_h(m, d_A, nk, nk_pad, HK_TRI, 2, d_k, nullptr, d_H));
+        TBK_CHECK(build(0, nk, d_H));
         if (tbk_eig_small_supported(m->n_orb))
             TBK_CHECK(tbk_launch_tridiag(m, m->stream, d_H, nk, d_de));
         else
@@ -467,18 +481,13 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int b = (int)(c & 1);
         const int64_t nkc = sched[c];
-        const int64_t nk_pad = phase_ld(nkc);
-        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * phase_ld(max_chunk) * sizeof(double)));
-        double* d_A = m->ws_phase.as<double>();
         double* d_de = debuf[b]->as<double>();
-        const double* kc = d_k + c0 * m->dim;
         if (c >= 1) {
             // H(c) overwrites the single H buffer and must not share the chip with the eigensolver
             TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b ^ 1], 0));
             if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
         }
-        TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
-        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H));
+        TBK_CHECK(build(c0, nkc, d_H));
         TBK_HIP(hipEventRecord(m->ev_hk[b], m->stream));
 
         TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_hk[b], 0));
@@ -513,7 +522,73 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     return TBK_OK;
 }
 
-extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
+// k lists with long runs of one shared component (grids in meshgrid order, stacks of planes): every run is
+// evaluated on the model folded along that component (tbk_fold.hip).  Returns TBK_OK with *done = false when the
+// list does not qualify.
+static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E, bool* done) {
+    *done = false;
+    if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 2048) return TBK_OK;
+    std::vector<double> host_copy;
+    if (h_k == nullptr) {
+        // device-resident k list: the run structure is read on the host (24 B per k-point) -- but only after its
+        // first 4096 points show a component with runs of >= 1024 (random lists stop here: 0.1 MB, not the list)
+        // The probe synchronises the stream, which would serialise back-to-back asynchronous calls: a (pointer,
+        // length) pair that did not qualify is remembered and not probed again (a miss only costs the shortcut).
+        if (d_k == m->fold_miss_ptr && nk == m->fold_miss_nk) return TBK_OK;
+        const int64_t probe = std::min<int64_t>(nk, 4096);
+        host_copy.resize((size_t)nk * m->dim);
+        TBK_HIP(hipMemcpyAsync(host_copy.data(), d_k, (size_t)probe * m->dim * sizeof(double), hipMemcpyDeviceToHost,
+                               m->stream));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+        bool plausible = false;
+        for (int d = 0; d < m->dim && !plausible; ++d) {
+            int64_t changes = 0;
+            for (int64_t i = 1; i < probe; ++i) changes += host_copy[(size_t)i * m->dim + d] != host_copy[(size_t)(i - 1) * m->dim + d];
+            plausible = changes * 1024 < probe;
+        }
+        if (!plausible) {
+            m->fold_miss_ptr = d_k;
+            m->fold_miss_nk = nk;
+            return TBK_OK;
+        }
+        TBK_HIP(hipMemcpyAsync(host_copy.data(), d_k, host_copy.size() * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+        h_k = host_copy.data();
+    }
+    std::vector<int64_t> runs;
+    const int f = tbk_fold_choose(m, h_k, nk, runs);
+    if (f < 0) return TBK_OK;
+    const int dim = m->dim;
+    TBK_CHECK(m->ws_kfold.reserve((size_t)nk * (dim - 1) * sizeof(double)));
+    double* d_k2 = m->ws_kfold.as<double>();
+    TBK_CHECK(tbk_fold_drop_component(m, d_k, dim, f, nk, d_k2));
+    const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
+    // the chunk pipeline (schedule, overlap of the tridiagonal stage) runs over the whole list; only the H(k) of a
+    // chunk is assembled run by run, each piece on the model folded for its run
+    const HBuilder folded = [&](int64_t c0, int64_t nkc, double* d_H) -> int {
+        size_t r = (size_t)(std::upper_bound(runs.begin(), runs.end(), c0) - runs.begin()) - 1;
+        for (int64_t lo = c0; lo < c0 + nkc; ++r) {
+            const int64_t hi = std::min(runs[r + 1], c0 + nkc);
+            tbk_fold_saved_t saved;
+            TBK_CHECK(tbk_fold_enter(m, f, h_k[runs[r] * dim + f], saved));
+            const int64_t len = hi - lo, nk_pad = phase_ld(len);
+            int rc = m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double));
+            if (rc == TBK_OK) rc = fill_rows(m, d_k2 + lo * (dim - 1), len, nk_pad, m->ws_phase.as<double>());
+            if (rc == TBK_OK)
+                rc = build_h(m, m->ws_phase.as<double>(), len, nk_pad, HK_TRI, 2, d_k2 + lo * (dim - 1), nullptr,
+                             d_H + (size_t)(lo - c0) * nn2);
+            tbk_fold_leave(m, saved);
+            TBK_CHECK(rc);
+            lo = hi;
+        }
+        return TBK_OK;
+    };
+    TBK_CHECK(eigenval_wave_pipeline(m, d_k, nk, d_E, &folded));
+    *done = true;
+    return TBK_OK;
+}
+
+static int eigenval_device_impl(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E) {
     TBK_ARG(m != nullptr, "model is NULL");
     TBK_ARG(nk >= 0, "nk < 0");
     if (nk == 0) return TBK_OK;
@@ -524,8 +599,12 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
         return TBK_ERR_ARGUMENT;
     }
     if (m->eigensolver != TBK_EIG_ROCSOLVER &&
-        (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb))))
+        (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb)))) {
+        bool done = false;
+        TBK_CHECK(eigenval_folded(m, d_k, h_k, nk, d_E, &done));
+        if (done) return TBK_OK;
         return eigenval_wave_pipeline(m, d_k, nk, d_E);
+    }
 
     const int64_t chunk = choose_chunk(m, nk, true);
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
@@ -543,6 +622,10 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
         TBK_CHECK(tbk_eig_batched(m, d_H, nkc, d_E + (size_t)c0 * m->n_orb));
     }
     return TBK_OK;
+}
+
+extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
+    return eigenval_device_impl(m, d_k, nullptr, nk, d_E);
 }
 
 extern "C" int tbk_synchronize(tbk_model* m) {
@@ -610,7 +693,7 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
     TBK_CHECK(m->ws_k.reserve((size_t)nk * m->dim * sizeof(double)));
     TBK_CHECK(m->ws_out.reserve((size_t)nk * m->n_orb * sizeof(double)));
     TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, k, (size_t)nk * m->dim * sizeof(double), hipMemcpyHostToDevice, m->stream));
-    TBK_CHECK(tbk_eigenval_device(m, m->ws_k.as<double>(), nk, m->ws_out.as<double>()));
+    TBK_CHECK(eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>()));
     TBK_HIP(hipMemcpyAsync(E_out, m->ws_out.ptr, (size_t)nk * m->n_orb * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
     return tbk_eigenval_check(m);  // synchronises

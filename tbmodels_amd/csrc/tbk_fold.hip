@@ -1,0 +1,204 @@
+// tbk_fold.hip -- k lists with long runs of a shared component (uniform grids, planes, lines): fold the model
+// along that component once per run and evaluate a model of lower dimension.
+//
+// The Fourier sum of /root/reference/src/tbmodels/_tb_model.py:1109-1122 costs 8 N^2 N_R flops per k-point
+// whatever the k list looks like.  On a grid -- BASELINE config 4 is the 100 x 100 x 100 mesh of
+// `np.meshgrid(..., indexing="ij")` -- 10^4 consecutive k-points share k_1, and for them
+//
+//     exp(2 pi i k.R) = exp(2 pi i k_1 R_1) * exp(2 pi i (k_2 R_2 + k_3 R_3))
+//
+// so the lattice vectors that differ only in R_1 can be summed ONCE per plane:
+//
+//     hop'[(R_2, R_3)] = sum_{R_1} exp(2 pi i k_1 R_1) hop[(R_1, R_2, R_3)]
+//
+// and the plane is a 2-D model with as many "lattice vectors" as there are distinct (R_2, R_3): 313 instead of
+// 4096 half-space vectors for the synthetic headline model (|R_i| <= 12) -- 13x less work for the H(k) contraction,
+// with every kernel of the path unchanged (phase rows, MFMA contraction, eigensolvers all run on the folded model).
+//
+// The fold acts on the STAGED operand Bt (two real rows P_r, Q_r per lattice vector: H = sum_r c_r P_r + s_r Q_r,
+// tbk_stage.hip).  With theta = alpha + sigma beta' (alpha = 2 pi k_f R_f, beta' the phase of the canonical
+// (dim-1)-vector rho', sigma = -1 where R's remaining components had to be negated to make them canonical):
+//
+//     P'_rho += cos(alpha) P_r + sin(alpha) Q_r          Q'_rho += sigma (-sin(alpha) P_r + cos(alpha) Q_r)
+//
+// One pass over Bt per run (272 MB at the headline shape: 55 us) against a contraction 13x shorter.
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "tbk_internal.h"
+
+namespace {
+
+// thread (column c of the flattened Bt row, folded vector rho): gathers the rows of its list
+__global__ void __launch_bounds__(256)
+fold_rows_kernel(const double* __restrict__ Bt, int64_t row_len, const int64_t* __restrict__ lptr,
+                 const int32_t* __restrict__ lrec, const int32_t* __restrict__ rcomp, double k_f,
+                 double* __restrict__ B2) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rho = blockIdx.y;
+    if (c >= row_len) return;
+    double accp = 0.0, accq = 0.0;
+    for (int64_t t = lptr[rho]; t < lptr[rho + 1]; ++t) {
+        const int32_t rec = lrec[t];
+        const int64_t r = rec & 0x7fffffff;
+        const double sigma = rec < 0 ? -1.0 : 1.0;
+        double sa, ca;
+        sincospi(2.0 * k_f * (double)rcomp[r], &sa, &ca);  // uniform per (rho, t): exact argument reduction
+        const double p = Bt[(2 * r) * row_len + c], q = Bt[(2 * r + 1) * row_len + c];
+        accp = fma(ca, p, fma(sa, q, accp));
+        accq = fma(sigma * ca, q, fma(-sigma * sa, p, accq));
+    }
+    B2[(2 * rho) * row_len + c] = accp;
+    B2[(2 * rho + 1) * row_len + c] = accq;
+}
+
+// k2[i][:] = k[i][all components but f]
+__global__ void drop_component_kernel(const double* __restrict__ k, int dim, int f, int64_t nk, double* __restrict__ k2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nk) return;
+    int o = 0;
+    for (int d = 0; d < dim; ++d)
+        if (d != f) k2[i * (dim - 1) + o++] = k[i * dim + d];
+}
+
+bool canonical_negate(std::vector<int32_t>& v) {
+    for (int32_t x : v) {
+        if (x > 0) return false;
+        if (x < 0) {
+            for (int32_t& y : v) y = -y;
+            return true;
+        }
+    }
+    return false;
+}
+
+}  // namespace
+
+// Builds (once per model and component) the folded lattice and the row lists.
+int tbk_fold_plan(tbk_model* m, int f) {
+    tbk_fold_plan_t& plan = m->fold[f];
+    if (plan.built) return TBK_OK;
+    const int dim = m->dim;
+    const int64_t n_r = m->n_r;
+    std::map<std::vector<int32_t>, int32_t> index;
+    std::vector<std::vector<int32_t>> lists;
+    std::vector<int32_t> rho_vec, rcomp((size_t)n_r);
+    for (int64_t r = 0; r < n_r; ++r) {
+        std::vector<int32_t> rho;
+        for (int d = 0; d < dim; ++d)
+            if (d != f) rho.push_back(m->h_R[(size_t)r * dim + d]);
+        rcomp[(size_t)r] = m->h_R[(size_t)r * dim + f];
+        const bool negated = canonical_negate(rho);
+        auto it = index.find(rho);
+        if (it == index.end()) {
+            it = index.emplace(rho, (int32_t)lists.size()).first;
+            lists.emplace_back();
+            rho_vec.insert(rho_vec.end(), rho.begin(), rho.end());
+        }
+        lists[(size_t)it->second].push_back((int32_t)r | (negated ? (int32_t)0x80000000 : 0));
+    }
+    plan.n_rho = (int64_t)lists.size();
+    plan.k2 = (plan.n_rho * 2 + TBK_BK - 1) / TBK_BK * TBK_BK;
+    plan.n_rho_pad = plan.k2 / 2;
+    std::vector<int64_t> lptr((size_t)plan.n_rho_pad + 1, 0);
+    std::vector<int32_t> lrec;
+    for (int64_t i = 0; i < plan.n_rho_pad; ++i) {
+        if (i < plan.n_rho) lrec.insert(lrec.end(), lists[(size_t)i].begin(), lists[(size_t)i].end());
+        lptr[(size_t)i + 1] = (int64_t)lrec.size();  // padding vectors keep empty lists: zero rows
+    }
+    std::vector<int32_t> r2((size_t)plan.n_rho_pad * (dim - 1), 0);
+    std::copy(rho_vec.begin(), rho_vec.end(), r2.begin());
+    const size_t row_len = (size_t)m->ncol_pad * 2;
+    TBK_HIP(hipMalloc((void**)&plan.d_R2, std::max<size_t>(r2.size(), 1) * sizeof(int32_t)));
+    TBK_HIP(hipMalloc((void**)&plan.d_lptr, lptr.size() * sizeof(int64_t)));
+    TBK_HIP(hipMalloc((void**)&plan.d_lrec, std::max<size_t>(lrec.size(), 1) * sizeof(int32_t)));
+    TBK_HIP(hipMalloc((void**)&plan.d_rcomp, std::max<size_t>(rcomp.size(), 1) * sizeof(int32_t)));
+    TBK_HIP(hipMalloc((void**)&plan.d_B2, (size_t)plan.k2 * row_len * sizeof(double)));
+    TBK_HIP(hipMemcpy(plan.d_R2, r2.data(), r2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    TBK_HIP(hipMemcpy(plan.d_lptr, lptr.data(), lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    TBK_HIP(hipMemcpy(plan.d_lrec, lrec.data(), lrec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    TBK_HIP(hipMemcpy(plan.d_rcomp, rcomp.data(), rcomp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    plan.built = true;
+    return TBK_OK;
+}
+
+void tbk_fold_release(tbk_model* m) {
+    for (tbk_fold_plan_t& plan : m->fold) {
+        void* ptrs[] = {plan.d_R2, plan.d_lptr, plan.d_lrec, plan.d_rcomp, plan.d_B2};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        plan = tbk_fold_plan_t();
+    }
+}
+
+// Which component (if any) is worth folding for this k list: the one with the fewest runs of equal consecutive
+// values, if its runs average >= 1024 k-points and the folded lattice is at least 3x smaller.  -1: none.
+int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int64_t>& run_starts) {
+    run_starts.clear();
+    if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 2048 || m->h_R.empty()) return -1;
+    int best = -1;
+    int64_t best_runs = nk;
+    for (int d = 0; d < m->dim; ++d) {
+        int64_t runs = 1;
+        for (int64_t i = 1; i < nk && runs * 1024 <= nk; ++i)
+            if (h_k[i * m->dim + d] != h_k[(i - 1) * m->dim + d]) ++runs;
+        if (runs * 1024 <= nk && runs < best_runs) {
+            best_runs = runs;
+            best = d;
+        }
+    }
+    if (best < 0) return -1;
+    if (tbk_fold_plan(m, best) != TBK_OK) return -1;
+    if (m->fold[best].n_rho * 3 > m->n_r) return -1;
+    run_starts.push_back(0);
+    for (int64_t i = 1; i < nk; ++i)
+        if (h_k[i * m->dim + best] != h_k[(i - 1) * m->dim + best]) run_starts.push_back(i);
+    run_starts.push_back(nk);
+    return best;
+}
+
+// Folds the staged operand for k_f (on the main stream) and turns `m` into the folded model; the caller evaluates
+// the run and calls tbk_fold_leave.
+int tbk_fold_enter(tbk_model* m, int f, double k_f, tbk_fold_saved_t& saved) {
+    tbk_fold_plan_t& plan = m->fold[f];
+    const int64_t row_len = (int64_t)m->ncol_pad * 2;
+    {
+        StageTimer t(m, TBK_T_PHASE);
+        dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad);
+        hipLaunchKernelGGL(fold_rows_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
+                           plan.d_rcomp, k_f, plan.d_B2);
+        TBK_HIP(hipGetLastError());
+    }
+    saved.dim = m->dim;
+    saved.n_r = m->n_r;
+    saved.n_r_pad = m->n_r_pad;
+    saved.k2 = m->k2;
+    saved.d_R = m->d_R;
+    saved.d_B = m->d_B;
+    m->dim = saved.dim - 1;
+    m->n_r = plan.n_rho;
+    m->n_r_pad = plan.n_rho_pad;
+    m->k2 = plan.k2;
+    m->d_R = plan.d_R2;
+    m->d_B = plan.d_B2;
+    return TBK_OK;
+}
+
+void tbk_fold_leave(tbk_model* m, const tbk_fold_saved_t& saved) {
+    m->dim = saved.dim;
+    m->n_r = saved.n_r;
+    m->n_r_pad = saved.n_r_pad;
+    m->k2 = saved.k2;
+    m->d_R = saved.d_R;
+    m->d_B = saved.d_B;
+}
+
+int tbk_fold_drop_component(tbk_model* m, const double* d_k, int dim, int f, int64_t nk, double* d_k2) {
+    hipLaunchKernelGGL(drop_component_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, m->stream, d_k, dim, f, nk,
+                       d_k2);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}

@@ -95,6 +95,26 @@ struct EventPair {
 };
 
 // ------------------------------------------------------------------------------------------------
+// folding along one k component (tbk_fold.hip)
+// ------------------------------------------------------------------------------------------------
+struct tbk_fold_plan_t {
+    bool built = false;
+    int64_t n_rho = 0, n_rho_pad = 0, k2 = 0;  // folded lattice vectors; K rows of the folded operand
+    int32_t* d_R2 = nullptr;     // [n_rho_pad][dim - 1]
+    int64_t* d_lptr = nullptr;   // [n_rho_pad + 1] lists of contributing lattice vectors
+    int32_t* d_lrec = nullptr;   // r | (negated ? 1 << 31 : 0)
+    int32_t* d_rcomp = nullptr;  // [n_r] the folded component of every lattice vector
+    double* d_B2 = nullptr;      // [k2][ncol_pad * 2] folded operand of the current run
+};
+
+struct tbk_fold_saved_t {
+    int dim;
+    int64_t n_r, n_r_pad, k2;
+    int32_t* d_R;
+    double* d_B;
+};
+
+// ------------------------------------------------------------------------------------------------
 // staged model
 // ------------------------------------------------------------------------------------------------
 struct tbk_model {
@@ -125,6 +145,13 @@ struct tbk_model {
 
     int64_t staged_bytes = 0;
 
+    // --- folding (k lists with long runs of one shared component) ---
+    std::vector<int32_t> h_R;  // host copy of the lattice vectors [n_r][dim]
+    tbk_fold_plan_t fold[TBK_MAX_DIM];
+    bool fold_enabled = true;
+    const double* fold_miss_ptr = nullptr;  // last device k list that did not qualify (not probed again)
+    int64_t fold_miss_nk = 0;
+
     // --- options ---
     int eigensolver = TBK_EIG_AUTO;
     int64_t k_chunk = 0;
@@ -150,6 +177,7 @@ struct tbk_model {
     DevBuf ws_out;
     DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
     DevBuf ws_part;   // split-K partial tiles of the dense H(k) kernel (small k batches)
+    DevBuf ws_kfold;  // k-points of a folded run without the folded component
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};
@@ -208,6 +236,13 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
 // `beside_ql`: this launch shares the chip with another QL launch (the tail of the chunk pipeline): use
 // half-size workgroups (32 KiB of LDS) that fit next to two resident 64 KiB ones.
 int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E, bool beside_ql = false);
+
+// tbk_fold.hip
+int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int64_t>& run_starts);
+int tbk_fold_enter(tbk_model* m, int f, double k_f, tbk_fold_saved_t& saved);
+void tbk_fold_leave(tbk_model* m, const tbk_fold_saved_t& saved);
+int tbk_fold_drop_component(tbk_model* m, const double* d_k, int dim, int f, int64_t nk, double* d_k2);
+void tbk_fold_release(tbk_model* m);
 
 // tbk_peak.hip
 int tbk_run_mfma_f64_peak(double* tflops);

@@ -179,6 +179,45 @@ def test_small_batches_vs_oracle(n_k):
     assert np.array_equal(again, np.conj(np.swapaxes(again, 1, 2)))  # exactly Hermitian
 
 
+def _grid(shape, offset=(0.0, 0.0, 0.0), order="ij"):
+    axes = [np.linspace(0, 1, n, endpoint=False) + o for n, o in zip(shape, offset)]
+    mesh = np.meshgrid(*axes, indexing=order)
+    return np.stack([m.reshape(-1) for m in mesh], axis=1)
+
+
+@pytest.mark.parametrize(
+    "dim,shape,offset,order",
+    [
+        (3, (3, 40, 40), (0.0, 0.0, 0.0), "ij"),       # planes of constant k_1
+        (3, (40, 3, 40), (0.13, -0.4, 2.5), "xy"),     # shifted mesh; component 1 is the slow one
+        (2, (5, 1100), (0.0, 0.25), "ij"),             # 2-D model: lines of constant k_1 fold to a 1-D model
+        (3, (2, 30, 50), (0.0, 0.0, 0.0), "ij"),
+    ],
+)
+def test_folded_grid_matches_direct_evaluation(dim, shape, offset, order):
+    """k lists with long runs of one shared component (uniform meshes) are evaluated on the model folded along that
+    component (tbk_fold.hip): same eigenvalues as the direct path (TBK_OPT_FOLD = 0) and as the oracle."""
+    from tbmodels_amd import _lib
+
+    n_orb, n_r = 12, 300 if dim == 3 else 160
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 50 + dim, dim=dim)
+    k = _grid(shape[:dim], offset[:dim], order)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    folded = np.array(model.eigenval(k))
+    model.set_option(_lib.TBK_OPT_FOLD, 0)
+    direct = np.array(model.eigenval(k))
+    model.set_option(_lib.TBK_OPT_FOLD, 1)
+    assert np.abs(folded - direct).max() < 1e-12
+    assert np.abs(folded - direct).max() > 0.0  # the folded path really ran (different summation order)
+    idx = np.random.default_rng(1).choice(len(k), 40, replace=False)
+    _close(folded[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
+    # a list without long runs takes the direct path: bit-identical with folding switched off
+    shuffled = k[np.random.default_rng(2).permutation(len(k))]
+    a = np.array(model.eigenval(shuffled))
+    model.set_option(_lib.TBK_OPT_FOLD, 0)
+    assert np.array_equal(a, np.array(model.eigenval(shuffled)))
+
+
 def test_seeded_csr_vs_oracle():
     """BASELINE config 3 shape at reduced size: N=128, N_R=64, 2 % fill."""
     r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(128, 64, syn.MODEL_SEED + 3)
