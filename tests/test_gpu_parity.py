@@ -211,6 +211,10 @@ def test_folded_grid_matches_direct_evaluation(dim, shape, offset, order):
     assert np.abs(folded - direct).max() > 0.0  # the folded path really ran (different summation order)
     idx = np.random.default_rng(1).choice(len(k), 40, replace=False)
     _close(folded[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
+    # a contiguous slab of the mesh (what one rank of a sharded run gets): ragged first and last runs
+    lo, hi = len(k) // 7, len(k) - len(k) // 5
+    model.set_option(_lib.TBK_OPT_FOLD, 1)
+    assert np.abs(np.array(model.eigenval(k[lo:hi])) - direct[lo:hi]).max() < 1e-12
     # a list without long runs takes the direct path: bit-identical with folding switched off
     shuffled = k[np.random.default_rng(2).permutation(len(k))]
     a = np.array(model.eigenval(shuffled))
