@@ -111,3 +111,19 @@ def test_config4_grid_slabs_match_whole():
     assert np.abs(np.concatenate(parts) - whole).max() < 1e-13
     again = [np.array(model.eigenval(syn.grid_slab(n, *slab_bounds(n ** 3, world, rank)))) for rank in range(world)]
     assert np.abs(np.concatenate(again).reshape(-1, 16) - np.concatenate(parts)).max() == 0.0  # and deterministic
+
+
+@pytest.mark.parametrize("n_orb,n_r,n_k,reps", [(64, 256, 100_000, 12), (40, 64, 70_000, 8), (128, 32, 12_288, 6), (256, 16, 4_096, 4)])
+def test_repeated_runs_are_bit_identical(n_orb, n_r, n_k, reps):
+    """Fixed summation orders everywhere (no floating-point atomics): the same call gives the same bits every time.
+    A race between the waves of a reduction workgroup or between the streams of the chunk pipeline shows up here
+    (the missing-waitcnt bug of the n <= 64 reduction changed ~50 rows per 100 000 only under LDS load)."""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + n_orb)
+    k = syn.random_kpoints(n_k, seed=n_orb)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    first = np.array(model.eigenval(k))
+    traces = np.einsum("rii->r", hop)
+    assert np.abs(first.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    for _ in range(reps):
+        again = np.array(model.eigenval(k))
+        assert np.array_equal(again, first)
