@@ -527,11 +527,11 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
 // list does not qualify.
 static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E, bool* done) {
     *done = false;
-    if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 2048) return TBK_OK;
+    if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 1024) return TBK_OK;
     std::vector<double> host_copy;
     if (h_k == nullptr) {
         // device-resident k list: the run structure is read on the host (24 B per k-point) -- but only after its
-        // first 4096 points show a component with runs of >= 1024 (random lists stop here: 0.1 MB, not the list)
+        // first 4096 points show a component with long runs (random lists stop here: 0.1 MB, not the list)
         // The probe synchronises the stream, which would serialise back-to-back asynchronous calls: a (pointer,
         // length) pair that did not qualify is remembered and not probed again (a miss only costs the shortcut).
         if (d_k == m->fold_miss_ptr && nk == m->fold_miss_nk) return TBK_OK;
@@ -544,7 +544,7 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
         for (int d = 0; d < m->dim && !plausible; ++d) {
             int64_t changes = 0;
             for (int64_t i = 1; i < probe; ++i) changes += host_copy[(size_t)i * m->dim + d] != host_copy[(size_t)(i - 1) * m->dim + d];
-            plausible = changes * 1024 < probe;
+            plausible = changes * tbk_fold_min_run() < probe;
         }
         if (!plausible) {
             m->fold_miss_ptr = d_k;

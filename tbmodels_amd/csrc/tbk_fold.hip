@@ -134,18 +134,23 @@ void tbk_fold_release(tbk_model* m) {
     }
 }
 
+// Average run length from which folding pays: a run costs one pass over Bt (60 us at the headline shape) plus
+// three small launches, the direct contraction ~1 us per k-point.  Measured on meshes of the headline model:
+// 14^3 (runs of 196) 4.4 -> 2.4 ms, 20^3 11.4 -> 5.0 ms, 30^3 38 -> 13.6 ms, 50^3 159 -> 49 ms.
+int64_t tbk_fold_min_run() { return 128; }
+
 // Which component (if any) is worth folding for this k list: the one with the fewest runs of equal consecutive
-// values, if its runs average >= 1024 k-points and the folded lattice is at least 3x smaller.  -1: none.
+// values, if its runs average >= tbk_fold_min_run() k-points and the folded lattice is at least 3x smaller.  -1: none.
 int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int64_t>& run_starts) {
     run_starts.clear();
-    if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 2048 || m->h_R.empty()) return -1;
+    if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 1024 || m->h_R.empty()) return -1;
     int best = -1;
     int64_t best_runs = nk;
     for (int d = 0; d < m->dim; ++d) {
         int64_t runs = 1;
-        for (int64_t i = 1; i < nk && runs * 1024 <= nk; ++i)
+        for (int64_t i = 1; i < nk && runs * tbk_fold_min_run() <= nk; ++i)
             if (h_k[i * m->dim + d] != h_k[(i - 1) * m->dim + d]) ++runs;
-        if (runs * 1024 <= nk && runs < best_runs) {
+        if (runs * tbk_fold_min_run() <= nk && runs < best_runs) {
             best_runs = runs;
             best = d;
         }

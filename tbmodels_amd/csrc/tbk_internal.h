@@ -243,6 +243,7 @@ int tbk_fold_enter(tbk_model* m, int f, double k_f, tbk_fold_saved_t& saved);
 void tbk_fold_leave(tbk_model* m, const tbk_fold_saved_t& saved);
 int tbk_fold_drop_component(tbk_model* m, const double* d_k, int dim, int f, int64_t nk, double* d_k2);
 void tbk_fold_release(tbk_model* m);
+int64_t tbk_fold_min_run();
 
 // tbk_peak.hip
 int tbk_run_mfma_f64_peak(double* tflops);
