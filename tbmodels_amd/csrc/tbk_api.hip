@@ -565,12 +565,24 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
     // the chunk pipeline (schedule, overlap of the tridiagonal stage) runs over the whole list; only the H(k) of a
     // chunk is assembled run by run, each piece on the model folded for its run
+    // runs are folded a group at a time (one pass over Bt for up to 16 of them); `group_lo` is the first run of the
+    // group whose operands are in the plan's buffer
+    const int64_t n_runs = (int64_t)runs.size() - 1;
+    const int group = tbk_fold_group_size();
+    int64_t group_lo = -1;
     const HBuilder folded = [&](int64_t c0, int64_t nkc, double* d_H) -> int {
         size_t r = (size_t)(std::upper_bound(runs.begin(), runs.end(), c0) - runs.begin()) - 1;
         for (int64_t lo = c0; lo < c0 + nkc; ++r) {
             const int64_t hi = std::min(runs[r + 1], c0 + nkc);
+            if (group_lo < 0 || (int64_t)r < group_lo || (int64_t)r >= group_lo + group) {
+                group_lo = (int64_t)r;
+                const int n_g = (int)std::min<int64_t>(group, n_runs - group_lo);
+                double kf[64];
+                for (int g = 0; g < n_g; ++g) kf[g] = h_k[runs[(size_t)(group_lo + g)] * dim + f];
+                TBK_CHECK(tbk_fold_group(m, f, kf, n_g));
+            }
             tbk_fold_saved_t saved;
-            TBK_CHECK(tbk_fold_enter(m, f, h_k[runs[r] * dim + f], saved));
+            TBK_CHECK(tbk_fold_enter(m, f, (int)((int64_t)r - group_lo), saved));
             const int64_t len = hi - lo, nk_pad = phase_ld(len);
             int rc = m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double));
             if (rc == TBK_OK) rc = fill_rows(m, d_k2 + lo * (dim - 1), len, nk_pad, m->ws_phase.as<double>());

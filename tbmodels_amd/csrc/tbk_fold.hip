@@ -55,6 +55,62 @@ fold_rows_kernel(const double* __restrict__ Bt, int64_t row_len, const int64_t* 
     B2[(2 * rho + 1) * row_len + c] = accq;
 }
 
+constexpr int FOLD_GROUP = 16;
+
+struct FoldValues {
+    double v[FOLD_GROUP];  // shared-component value of every run of the group (a kernel argument: no copy to wait for)
+};
+
+// (cos, sin)(2 pi k_f[g] R_f[r]) for the runs of a group
+__global__ void fold_table_kernel(const int32_t* __restrict__ rcomp, int64_t n_r, const FoldValues k_f, int n_g,
+                                  double* __restrict__ table) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_r * n_g) return;
+    const int64_t r = i / n_g;
+    const int g = (int)(i % n_g);
+    double sa, ca;
+    sincospi(2.0 * k_f.v[g] * (double)rcomp[r], &sa, &ca);  // exact argument reduction
+    table[2 * i] = ca;
+    table[2 * i + 1] = sa;
+}
+
+// The same fold for up to FOLD_GROUP runs in ONE pass over Bt: every (row pair, column) is loaded once and
+// accumulated into the operand of each run of the group (its phases come from the table above).
+
+__global__ void __launch_bounds__(256)
+fold_rows_group_kernel(const double* __restrict__ Bt, int64_t row_len, const int64_t* __restrict__ lptr,
+                       const int32_t* __restrict__ lrec, const double* __restrict__ table, int n_g, int64_t b2_stride,
+                       double* __restrict__ B2) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rho = blockIdx.y;
+    if (c >= row_len) return;
+    double accp[FOLD_GROUP], accq[FOLD_GROUP];
+#pragma unroll
+    for (int g = 0; g < FOLD_GROUP; ++g) accp[g] = accq[g] = 0.0;
+    for (int64_t t = lptr[rho]; t < lptr[rho + 1]; ++t) {
+        const int32_t rec = lrec[t];
+        const int64_t r = rec & 0x7fffffff;
+        const double sigma = rec < 0 ? -1.0 : 1.0;
+        const double p = Bt[(2 * r) * row_len + c], q = Bt[(2 * r + 1) * row_len + c];
+        const double* tab = table + 2 * r * n_g;  // uniform
+#pragma unroll
+        for (int g = 0; g < FOLD_GROUP; ++g) {
+            if (g < n_g) {
+                const double ca = tab[2 * g], sa = tab[2 * g + 1];
+                accp[g] = fma(ca, p, fma(sa, q, accp[g]));
+                accq[g] = fma(sigma * ca, q, fma(-sigma * sa, p, accq[g]));
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < FOLD_GROUP; ++g) {
+        if (g < n_g) {
+            B2[g * b2_stride + (2 * rho) * row_len + c] = accp[g];
+            B2[g * b2_stride + (2 * rho + 1) * row_len + c] = accq[g];
+        }
+    }
+}
+
 // k2[i][:] = k[i][all components but f]
 __global__ void drop_component_kernel(const double* __restrict__ k, int dim, int f, int64_t nk, double* __restrict__ k2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,7 +172,8 @@ int tbk_fold_plan(tbk_model* m, int f) {
     TBK_HIP(hipMalloc((void**)&plan.d_lptr, lptr.size() * sizeof(int64_t)));
     TBK_HIP(hipMalloc((void**)&plan.d_lrec, std::max<size_t>(lrec.size(), 1) * sizeof(int32_t)));
     TBK_HIP(hipMalloc((void**)&plan.d_rcomp, std::max<size_t>(rcomp.size(), 1) * sizeof(int32_t)));
-    TBK_HIP(hipMalloc((void**)&plan.d_B2, (size_t)plan.k2 * row_len * sizeof(double)));
+    TBK_HIP(hipMalloc((void**)&plan.d_B2, (size_t)FOLD_GROUP * plan.k2 * row_len * sizeof(double)));
+    TBK_HIP(hipMalloc((void**)&plan.d_table, std::max<size_t>((size_t)n_r * FOLD_GROUP * 2, 1) * sizeof(double)));
     TBK_HIP(hipMemcpy(plan.d_R2, r2.data(), r2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     TBK_HIP(hipMemcpy(plan.d_lptr, lptr.data(), lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     TBK_HIP(hipMemcpy(plan.d_lrec, lrec.data(), lrec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -127,7 +184,7 @@ int tbk_fold_plan(tbk_model* m, int f) {
 
 void tbk_fold_release(tbk_model* m) {
     for (tbk_fold_plan_t& plan : m->fold) {
-        void* ptrs[] = {plan.d_R2, plan.d_lptr, plan.d_lrec, plan.d_rcomp, plan.d_B2};
+        void* ptrs[] = {plan.d_R2, plan.d_lptr, plan.d_lrec, plan.d_rcomp, plan.d_B2, plan.d_table};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         plan = tbk_fold_plan_t();
@@ -165,18 +222,38 @@ int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int
     return best;
 }
 
-// Folds the staged operand for k_f (on the main stream) and turns `m` into the folded model; the caller evaluates
-// the run and calls tbk_fold_leave.
-int tbk_fold_enter(tbk_model* m, int f, double k_f, tbk_fold_saved_t& saved) {
+int tbk_fold_group_size() { return FOLD_GROUP; }
+
+// Folds the staged operand for the n_g (<= FOLD_GROUP) shared-component values h_kf[] in one pass (main stream).
+int tbk_fold_group(tbk_model* m, int f, const double* h_kf, int n_g) {
     tbk_fold_plan_t& plan = m->fold[f];
     const int64_t row_len = (int64_t)m->ncol_pad * 2;
-    {
-        StageTimer t(m, TBK_T_PHASE);
+    StageTimer t(m, TBK_T_PHASE);
+    if (n_g == 1) {
         dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad);
         hipLaunchKernelGGL(fold_rows_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
-                           plan.d_rcomp, k_f, plan.d_B2);
+                           plan.d_rcomp, h_kf[0], plan.d_B2);
         TBK_HIP(hipGetLastError());
+        return TBK_OK;
     }
+    FoldValues values;
+    for (int g = 0; g < FOLD_GROUP; ++g) values.v[g] = g < n_g ? h_kf[g] : 0.0;
+    const int64_t entries = m->n_r * n_g;
+    hipLaunchKernelGGL(fold_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, m->stream, plan.d_rcomp,
+                       m->n_r, values, n_g, plan.d_table);
+    TBK_HIP(hipGetLastError());
+    dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad);
+    hipLaunchKernelGGL(fold_rows_group_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
+                       plan.d_table, n_g, plan.k2 * row_len, plan.d_B2);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
+// Turns `m` into the model folded for slot `g` of the last tbk_fold_group call; the caller evaluates the run piece
+// and calls tbk_fold_leave.
+int tbk_fold_enter(tbk_model* m, int f, int g, tbk_fold_saved_t& saved) {
+    tbk_fold_plan_t& plan = m->fold[f];
+    const int64_t row_len = (int64_t)m->ncol_pad * 2;
     saved.dim = m->dim;
     saved.n_r = m->n_r;
     saved.n_r_pad = m->n_r_pad;
@@ -188,7 +265,7 @@ int tbk_fold_enter(tbk_model* m, int f, double k_f, tbk_fold_saved_t& saved) {
     m->n_r_pad = plan.n_rho_pad;
     m->k2 = plan.k2;
     m->d_R = plan.d_R2;
-    m->d_B = plan.d_B2;
+    m->d_B = plan.d_B2 + (size_t)g * plan.k2 * row_len;
     return TBK_OK;
 }
 

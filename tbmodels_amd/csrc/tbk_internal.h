@@ -104,7 +104,8 @@ struct tbk_fold_plan_t {
     int64_t* d_lptr = nullptr;   // [n_rho_pad + 1] lists of contributing lattice vectors
     int32_t* d_lrec = nullptr;   // r | (negated ? 1 << 31 : 0)
     int32_t* d_rcomp = nullptr;  // [n_r] the folded component of every lattice vector
-    double* d_B2 = nullptr;      // [k2][ncol_pad * 2] folded operand of the current run
+    double* d_B2 = nullptr;      // [group][k2][ncol_pad * 2] folded operands of the current group of runs
+    double* d_table = nullptr;   // [n_r][group][2] (cos, sin) of the shared-component phases
 };
 
 struct tbk_fold_saved_t {
@@ -239,7 +240,9 @@ int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, d
 
 // tbk_fold.hip
 int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int64_t>& run_starts);
-int tbk_fold_enter(tbk_model* m, int f, double k_f, tbk_fold_saved_t& saved);
+int tbk_fold_group_size();
+int tbk_fold_group(tbk_model* m, int f, const double* h_kf, int n_g);
+int tbk_fold_enter(tbk_model* m, int f, int g, tbk_fold_saved_t& saved);
 void tbk_fold_leave(tbk_model* m, const tbk_fold_saved_t& saved);
 int tbk_fold_drop_component(tbk_model* m, const double* d_k, int dim, int f, int64_t nk, double* d_k2);
 void tbk_fold_release(tbk_model* m);
