@@ -30,7 +30,7 @@ def _eigenvals(args):
         kpts = kpts.kpoints
     echo("Calculating energy eigenvalues ...")
     eigenvalues = io.EigenvalsData.from_eigenval_function(
-        kpoints=kpts, eigenval_function=model.eigenval, listable=True
+        kpoints=kpts, eigenval_function=model.eigenval_array, listable=True  # one batched call, no list of rows
     )
     echo("Writing kpoints and energy eigenvalues to file '{}' ...".format(args.output))
     io.save(eigenvalues, args.output)

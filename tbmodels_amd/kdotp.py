@@ -88,10 +88,15 @@ class KdotpModel:
 
     def eigenval(self, k):
         """Eigenvalues at one k-point or a list of k-points (``kdotp.py:84-100``)."""
+        out = self.eigenval_array(k)
+        return out if out.ndim == 1 else list(out)
+
+    def eigenval_array(self, k):
+        """``eigenval`` as one ``(NK, N)`` array instead of a list of rows (see ``Model.eigenval_array``)."""
         k_array, single = self._k_array(k)
         if not np.isfinite(k_array).all():
             raise ValueError("array must not contain infs or NaNs")
         _, size = self._shape()
         out = np.empty((k_array.shape[0], size), dtype=np.float64)
         _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
-        return out[0] if single else list(out)
+        return out[0] if single else out
