@@ -61,3 +61,10 @@ def test_model_file_roundtrip_on_device(tmp_path, silicon):
         again = io.load(path)
         assert again._sparse == sparse
         np.testing.assert_allclose(np.array(again.eigenval(silicon["known_kpoints"])), want, rtol=0, atol=1e-12)
+
+
+def test_example_script_runs():
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "bands_and_dos.py")], cwd=ROOT, capture_output=True,
+                         text=True, check=False)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "mesh points in" in run.stdout and "single-k calls" in run.stdout
