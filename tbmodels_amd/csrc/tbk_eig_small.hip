@@ -4,14 +4,14 @@
 // (/root/reference/src/tbmodels/_tb_model.py:1147-1150).  A vendor batched zheevd spends ~6 us per
 // 64x64 matrix here -- 5x the time of building H(k) -- so small matrices get their own path:
 //
-//   kernel 1  herm_tridiag<NR>   ONE WAVE PER MATRIX, the matrix lives in registers: lane i holds row i
-//             (NR complex = 2 NR VGPR pairs, statically indexed).  Householder reduction to a real
-//             symmetric tridiagonal (d, e), LAPACK zhetd2/zlarfg arithmetic, full (both-triangle)
-//             rank-2 updates so that every lane does the same straight-line work:
+//   kernel 1a herm_tridiag_packed<NRP>  n <= 32: 64 / NRP matrices per wave (NRP = 8, 16, 32 lanes per matrix), the
+//             matrices live in registers: a lane holds one row (NRP complex, statically indexed).  Householder
+//             reduction to a real symmetric tridiagonal (d, e), LAPACK zhetd2/zlarfg arithmetic, full
+//             (both-triangle) rank-2 updates so that every lane does the same straight-line work:
 //                 p = tau A v;  w = p - (tau/2)(p^H v) v;  A -= v w^H + w v^H
-//             v and w are broadcast through 2 KiB of LDS (uniform-address ds_read_b128), the next
-//             Householder column is captured out of the update pass (no dynamic register index), and
-//             the two dot products per step are 6-stage wave reductions.
+//             v and w are broadcast through LDS per segment, reductions stay inside the segment (DPP), the next
+//             Householder column is captured out of the update pass (no dynamic register index).
+//   kernel 1b herm_tridiag4<64>         32 < n <= 64: four waves per matrix (see below).
 //   kernel 2  tridiag_ql         ONE LANE PER MATRIX: implicit-shift QL on (d, e) held in LDS as
 //             [index][lane] (conflict-free), then an in-LDS insertion sort; ascending output like
 //             eigvalsh.  The serial chain is short (O(n^2) steps) and 64 matrices share a wave.
@@ -71,191 +71,173 @@ __device__ __forceinline__ void wg_sync() {
 
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
-template <int NR>
-__global__ void __launch_bounds__(64)
-herm_tridiag_kernel(const double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
-    constexpr int CG = 4;        // columns per uniform-branch group (= LDS prefetch granule)
-    constexpr int NG = NR / CG;
-    __shared__ d2 sv[NR];
-    __shared__ d2 sw[NR];
-    const int lane = threadIdx.x;
-    const size_t mat = blockIdx.x;
-    const double* Hm = H + mat * (size_t)n * n * 2;
-    double* Dm = D + mat * (size_t)n;
-    double* Em = E + mat * (size_t)n;
+// one wave writes and reads an LDS array: its LDS operations execute in order, the fence keeps the compiler from
+// moving them across each other
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-    // ---- load: lane i <- row i of the Hermitian matrix whose upper triangle (c >= i) is stored ----
-    double ar[NR], ai[NR];
-#pragma unroll
-    for (int c = 0; c < NR; ++c) {
-        double re = 0.0, im = 0.0;
-        if (lane < n && c < n) {
-            if (c >= lane) {
-                const d2 t = *reinterpret_cast<const d2*>(Hm + ((size_t)lane * n + c) * 2);
-                re = t[0];
-                im = t[1];
-            } else {
-                const d2 t = *reinterpret_cast<const d2*>(Hm + ((size_t)c * n + lane) * 2);
-                re = t[0];
-                im = -t[1];
-            }
-        }
-        ar[c] = re;
-        ai[c] = im;
+// ------------------------------------------------------------------------------------------------
+// kernel 1a: up to 32 orbitals -- SEVERAL matrices per wave.  With one matrix per wave an 8 x 8 matrix keeps 8 of 64
+// lanes busy; here lane l works on row (l % NRP) of matrix (l / NRP) of the block (NRP = 8, 16 or 32 lanes per
+// matrix).  Same arithmetic as above; what changes: reductions and broadcasts stay inside the NRP-lane segment, the
+// LDS copies of v and w are addressed per segment, and the "column already reduced" case (tau = 0) is handled with
+// selects instead of a wave-uniform branch, because the matrices of a wave need not agree on it.
+// ------------------------------------------------------------------------------------------------
+template <int SEG>
+__device__ __forceinline__ double seg_sum(double v) {
+    if (SEG == 8) {
+        v += dpp_mov<0x141>(v);  // row_half_mirror: i <-> 7 - i
+        v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+        return v;
     }
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    if (SEG == 32) {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return v;
+}
 
-    // x = current Householder column: lane i holds A[i][j]
+template <int NRP>
+__global__ void __launch_bounds__(64)
+herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, double* __restrict__ D,
+                           double* __restrict__ E) {
+    constexpr int G = 64 / NRP;  // matrices per wave
+    constexpr int CG = 4;        // columns per uniform-branch group
+    constexpr int NGR = NRP / CG;
+    __shared__ d2 sv[64];
+    __shared__ d2 sw[64];
+    const int lane = threadIdx.x;
+    const int row = lane % NRP;
+    const int base = lane - row;  // first lane of this matrix' segment
+    const int64_t mat = (int64_t)blockIdx.x * G + lane / NRP;
+    const bool live = mat < nk;
+    const int64_t mc = live ? mat : nk - 1;
+    const double* Hm = H + (size_t)mc * n * n * 2;
+    double* Dm = D + (size_t)mc * n;
+    double* Em = E + (size_t)mc * n;
+
+    // lane <- row `row` of the Hermitian matrix whose upper triangle is stored (unconditional clamped loads)
+    double ar[NRP], ai[NRP];
+    {
+        d2 raw[NRP];
+        const int li = min(row, n - 1);
+#pragma unroll
+        for (int c = 0; c < NRP; ++c) {
+            const int cc = min(c, n - 1);
+            const int lo = min(li, cc), hi = max(li, cc);
+            raw[c] = *reinterpret_cast<const d2*>(Hm + ((size_t)lo * n + hi) * 2);
+        }
+#pragma unroll
+        for (int c = 0; c < NRP; ++c) {
+            const bool inside = row < n && c < n;
+            ar[c] = inside ? raw[c][0] : 0.0;
+            ai[c] = inside ? (c >= row ? raw[c][1] : -raw[c][1]) : 0.0;
+        }
+    }
     double xr = ar[0], xi = ai[0];
 
     for (int j = 0; j < n - 1; ++j) {
-        if (lane == j) Dm[j] = xr;  // diagonal element A[j][j] is final
-        const double alr = bcast(xr, j + 1), ali = bcast(xi, j + 1);
-        const bool below = (lane > j + 1) && (lane < n);
-        const double sigma = wave_sum(below ? (xr * xr + xi * xi) : 0.0);
+        if (live && row == j) Dm[j] = xr;
+        const double alr = __shfl(xr, base + j + 1, 64), ali = __shfl(xi, base + j + 1, 64);
+        const bool below = (row > j + 1) && (row < n);
+        const double sigma = seg_sum<NRP>(below ? (xr * xr + xi * xi) : 0.0);
+        // zlarfg: tau = 0 (H = I) when the column is already reduced and its pivot real
+        const bool done = (sigma == 0.0) && (ali == 0.0);
+        const double beta = done ? alr : -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
+        const double rbeta = done ? 0.0 : 1.0 / beta;
+        const double tr = (beta - alr) * rbeta, ti = -ali * rbeta;
+        const double qr = alr - beta, qi = ali;
+        const double qn = done ? 0.0 : 1.0 / (qr * qr + qi * qi);
+        const double scr = qr * qn, sci = -qi * qn;
+        if (live && row == 0) Em[j] = beta;
 
-        double nxr = 0.0, nxi = 0.0;  // next column, captured in the update pass
-        if (sigma == 0.0 && ali == 0.0) {
-            // H = I (zlarfg: tau = 0): nothing to apply, the off-diagonal is already real
-            if (lane == 0) Em[j] = alr;
-#pragma unroll
-            for (int c = 0; c < NR; ++c)
-                if (c == j + 1) {
-                    nxr = ar[c];
-                    nxi = ai[c];
-                }
-        } else {
-            const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
-            const double tr = (beta - alr) / beta, ti = -ali / beta;  // tau
-            // scale = 1 / (alpha - beta)
-            const double qr = alr - beta, qi = ali;
-            const double qn = 1.0 / (qr * qr + qi * qi);
-            const double scr = qr * qn, sci = -qi * qn;
-            if (lane == 0) Em[j] = beta;
+        double vr = 0.0, vi = 0.0;
+        if (below) {
+            vr = xr * scr - xi * sci;
+            vi = xr * sci + xi * scr;
+        } else if (row == j + 1) {
+            vr = 1.0;
+        }
+        wave_lds_fence();
+        sv[lane] = (d2){vr, vi};
+        wave_lds_fence();
 
-            double vr = 0.0, vi = 0.0;
-            if (below) {
-                vr = xr * scr - xi * sci;
-                vi = xr * sci + xi * scr;
-            } else if (lane == j + 1) {
-                vr = 1.0;
-            }
-            __syncthreads();
-            if (lane < NR) sv[lane] = (d2){vr, vi};
-            __syncthreads();
-
-            // p = A v.  Columns are walked in groups of CG: one wave-uniform branch per group skips the
-            // finished part of the matrix, and the broadcast reads of v for group g+1 are issued
-            // (unconditionally) before the FMAs of group g so their LDS latency is covered -- this
-            // kernel runs one wave per SIMD, nothing else hides it.  v_c = w_c = 0 for c <= j makes a
-            // partly-finished group harmless.
-            double pr = 0.0, pi = 0.0;
-            {
-                d2 vb[2][CG];
-                double par[CG], pai[CG];
+        // p = A v over the columns of this lane's matrix
+        double pr = 0.0, pi = 0.0;
+        {
+            double par[CG], pai[CG];
 #pragma unroll
-                for (int cc = 0; cc < CG; ++cc) {
-                    vb[0][cc] = sv[cc];
-                    par[cc] = 0.0;
-                    pai[cc] = 0.0;
-                }
+            for (int cc = 0; cc < CG; ++cc) par[cc] = pai[cc] = 0.0;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + 1 < NG) {
+            for (int gr = 0; gr < NGR; ++gr) {
+                if (gr * CG + CG - 1 > j) {  // uniform (all matrices of the launch have n orbitals)
+                    d2 vb[CG];
 #pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) vb[(g + 1) & 1][cc] = sv[(g + 1) * CG + cc];
+                    for (int cc = 0; cc < CG; ++cc) vb[cc] = sv[base + gr * CG + cc];
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc) {
+                        par[cc] = fma(ar[gr * CG + cc], vb[cc][0], par[cc]);
+                        pai[cc] = fma(ar[gr * CG + cc], vb[cc][1], pai[cc]);
                     }
-                    if (g * CG + CG - 1 > j) {
-                        // the FMA levels are written column-interleaved: consecutive instructions are
-                        // independent, so the ~4x issue-interval latency of a dependent f64 FMA is covered
-                        // by the other 2 CG - 1 chains (one wave per SIMD: nothing else would cover it)
 #pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            par[cc] = fma(ar[g * CG + cc], vb[g & 1][cc][0], par[cc]);
-                            pai[cc] = fma(ar[g * CG + cc], vb[g & 1][cc][1], pai[cc]);
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            par[cc] = fma(-ai[g * CG + cc], vb[g & 1][cc][1], par[cc]);
-                            pai[cc] = fma(ai[g * CG + cc], vb[g & 1][cc][0], pai[cc]);
-                        }
+                    for (int cc = 0; cc < CG; ++cc) {
+                        par[cc] = fma(-ai[gr * CG + cc], vb[cc][1], par[cc]);
+                        pai[cc] = fma(ai[gr * CG + cc], vb[cc][0], pai[cc]);
                     }
                 }
+            }
 #pragma unroll
-                for (int cc = 0; cc < CG; ++cc) {
-                    pr += par[cc];
-                    pi += pai[cc];
-                }
+            for (int cc = 0; cc < CG; ++cc) {
+                pr += par[cc];
+                pi += pai[cc];
             }
-            const bool active = (lane > j) && (lane < n);
-            if (!active) {
-                pr = 0.0;
-                pi = 0.0;
-            }
-            // p *= tau
-            {
-                const double t = pr * tr - pi * ti;
-                pi = pr * ti + pi * tr;
-                pr = t;
-            }
-            // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
-            const double dr = wave_sum(pr * vr + pi * vi);
-            const double di = wave_sum(pr * vi - pi * vr);
-            const double a2r = -0.5 * (tr * dr - ti * di), a2i = -0.5 * (tr * di + ti * dr);
-            const double wr = pr + (a2r * vr - a2i * vi);
-            const double wi = pi + (a2r * vi + a2i * vr);
-            if (lane < NR) sw[lane] = (d2){wr, wi};
-            __syncthreads();
+        }
+        if (!((row > j) && (row < n))) pr = pi = 0.0;
+        {  // p *= tau
+            const double t = pr * tr - pi * ti;
+            pi = pr * ti + pi * tr;
+            pr = t;
+        }
+        // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
+        const double dr = seg_sum<NRP>(pr * vr + pi * vi);
+        const double di = seg_sum<NRP>(pr * vi - pi * vr);
+        const double a2r = -0.5 * (tr * dr - ti * di), a2i = -0.5 * (tr * di + ti * dr);
+        const double wr = pr + (a2r * vr - a2i * vi);
+        const double wi = pi + (a2r * vi + a2i * vr);
+        sw[lane] = (d2){wr, wi};
+        wave_lds_fence();
 
-            // A -= v w^H + w v^H  (rows and columns <= j see v = w = 0 and stay untouched)
-            {
-                d2 vb[2][CG], wb[2][CG];
+        // A -= v w^H + w v^H; the next Householder column is captured on the way
+        double nxr = 0.0, nxi = 0.0;
+#pragma unroll
+        for (int gr = 0; gr < NGR; ++gr) {
+            if (gr * CG + CG - 1 > j) {
+                d2 vb[CG], wb[CG];
 #pragma unroll
                 for (int cc = 0; cc < CG; ++cc) {
-                    vb[0][cc] = sv[cc];
-                    wb[0][cc] = sw[cc];
+                    vb[cc] = sv[base + gr * CG + cc];
+                    wb[cc] = sw[base + gr * CG + cc];
                 }
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + 1 < NG) {
-#pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            vb[(g + 1) & 1][cc] = sv[(g + 1) * CG + cc];
-                            wb[(g + 1) & 1][cc] = sw[(g + 1) * CG + cc];
-                        }
-                    }
-                    if (g * CG + CG - 1 > j) {
-                        // four FMA levels per component, column-interleaved (see the matvec above)
-#pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            ar[g * CG + cc] = fma(-vr, wb[g & 1][cc][0], ar[g * CG + cc]);
-                            ai[g * CG + cc] = fma(-vi, wb[g & 1][cc][0], ai[g * CG + cc]);
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            ar[g * CG + cc] = fma(-vi, wb[g & 1][cc][1], ar[g * CG + cc]);
-                            ai[g * CG + cc] = fma(vr, wb[g & 1][cc][1], ai[g * CG + cc]);
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            ar[g * CG + cc] = fma(-wr, vb[g & 1][cc][0], ar[g * CG + cc]);
-                            ai[g * CG + cc] = fma(-wi, vb[g & 1][cc][0], ai[g * CG + cc]);
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < CG; ++cc) {
-                            ar[g * CG + cc] = fma(-wi, vb[g & 1][cc][1], ar[g * CG + cc]);
-                            ai[g * CG + cc] = fma(wr, vb[g & 1][cc][1], ai[g * CG + cc]);
-                        }
-                        // capture the next Householder column A[:, j+1] from the group that holds it
-                        if ((j + 1) / CG == g) {
-#pragma unroll
-                            for (int cc = 0; cc < CG; ++cc) {
-                                const int c = g * CG + cc;
-                                if (c == j + 1) {
-                                    nxr = ar[c];
-                                    nxi = ai[c];
-                                }
-                            }
-                        }
+                for (int cc = 0; cc < CG; ++cc) {
+                    const int c = gr * CG + cc;
+                    ar[c] = fma(-vr, wb[cc][0], ar[c]);
+                    ai[c] = fma(-vi, wb[cc][0], ai[c]);
+                    ar[c] = fma(-vi, wb[cc][1], ar[c]);
+                    ai[c] = fma(vr, wb[cc][1], ai[c]);
+                    ar[c] = fma(-wr, vb[cc][0], ar[c]);
+                    ai[c] = fma(-wi, vb[cc][0], ai[c]);
+                    ar[c] = fma(-wi, vb[cc][1], ar[c]);
+                    ai[c] = fma(wr, vb[cc][1], ai[c]);
+                    if (c == j + 1) {  // uniform
+                        nxr = ar[c];
+                        nxi = ai[c];
                     }
                 }
             }
@@ -263,8 +245,8 @@ herm_tridiag_kernel(const double* __restrict__ H, int n, double* __restrict__ D,
         xr = nxr;
         xi = nxi;
     }
-    if (lane == n - 1) Dm[n - 1] = xr;
-    if (lane == 0) Em[n - 1] = 0.0;
+    if (live && row == n - 1) Dm[n - 1] = xr;
+    if (live && row == 0) Em[n - 1] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,13 +576,11 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
         return TBK_OK;
     }
     if (n <= 8)
-        hipLaunchKernelGGL(herm_tridiag_kernel<8>, grid, block, 0, s, d_H, n, d_D, d_Eo);
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<8>, dim3((unsigned)((nk + 7) / 8)), block, 0, s, d_H, n, nk, d_D, d_Eo);
     else if (n <= 16)
-        hipLaunchKernelGGL(herm_tridiag_kernel<16>, grid, block, 0, s, d_H, n, d_D, d_Eo);
-    else if (n <= 32)
-        hipLaunchKernelGGL(herm_tridiag_kernel<32>, grid, block, 0, s, d_H, n, d_D, d_Eo);
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<16>, dim3((unsigned)((nk + 3) / 4)), block, 0, s, d_H, n, nk, d_D, d_Eo);
     else
-        hipLaunchKernelGGL(herm_tridiag_kernel<64>, grid, block, 0, s, d_H, n, d_D, d_Eo);
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<32>, dim3((unsigned)((nk + 1) / 2)), block, 0, s, d_H, n, nk, d_D, d_Eo);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
