@@ -319,7 +319,7 @@ def _onsite_model(mat):
 
 @pytest.mark.parametrize("solver", ["auto", "rocsolver"])
 @pytest.mark.parametrize(
-    "n", [1, 2, 3, 8, 9, 12, 13, 16, 17, 32, 33, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 200, 256, 257, 300, 384, 385, 512, 520]
+    "n", [1, 2, 3, 8, 9, 12, 13, 16, 17, 32, 33, 40, 48, 49, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 200, 256, 257, 300, 384, 385, 512, 520]
 )
 def test_eigensolver_structured_matrices(solver, n):
     """
