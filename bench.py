@@ -349,6 +349,11 @@ def main():
                 "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
                 "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
             }
+            if args.config == "cfg4":
+                # mesh planes are evaluated on the folded model (csrc/tbk_fold.hip): the contraction executes ~13x
+                # fewer flops than the direct sum these figures price, so `frac` says how much faster than the
+                # direct path's roofline the run is, not how busy the matrix pipe was
+                roofline["note"] = "folded evaluation: frac and executed_tflops refer to the UNFOLDED flop count"
         else:
             out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not args.construct_only else n_orb * n_orb)
             b_k = out_bytes + 8 * dim
