@@ -287,7 +287,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_H2, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);
     delete m;
@@ -564,12 +564,94 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
     TBK_CHECK(tbk_fold_drop_component(m, d_k, dim, f, nk, d_k2));
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
     // the chunk pipeline (schedule, overlap of the tridiagonal stage) runs over the whole list; only the H(k) of a
-    // chunk is assembled run by run, each piece on the model folded for its run
-    // runs are folded a group at a time (one pass over Bt for up to 16 of them); `group_lo` is the first run of the
-    // group whose operands are in the plan's buffer
+    // chunk is assembled run by run, each piece on the model folded for its run.
+    // Runs are folded a group at a time (one pass over Bt for up to 16 of them); `group_lo` is the first run of the
+    // group whose operands are in the plan's buffer.
     const int64_t n_runs = (int64_t)runs.size() - 1;
     const int group = tbk_fold_group_size();
     int64_t group_lo = -1;
+    tbk_fold_plan_t& plan1 = m->fold[f];
+    std::vector<int> reduced;  // original component of every reduced one
+    for (int d = 0; d < dim; ++d)
+        if (d != f) reduced.push_back(d);
+
+    // [lo, hi) of one run, `m` folded for that run: phase rows + contraction of the (dim - 1)-dimensional model
+    auto piece_plane = [&](int64_t lo, int64_t hi, double* d_Hp) -> int {
+        const int64_t len = hi - lo, nk_pad = phase_ld(len);
+        TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
+        TBK_CHECK(fill_rows(m, d_k2 + lo * (dim - 1), len, nk_pad, m->ws_phase.as<double>()));
+        return build_h(m, m->ws_phase.as<double>(), len, nk_pad, HK_TRI, 2, d_k2 + lo * (dim - 1), nullptr, d_Hp);
+    };
+
+    // Second level (meshes): inside a plane the k-points come in LINES -- equal-length sub-runs of one more shared
+    // component whose remaining coordinates repeat from line to line.  Every line is a (dim - 2)-dimensional model
+    // (13 instead of 313 lattice vectors at the headline shape); all lines of the piece go through ONE launch with
+    // per-line operands and shared phase rows (tbk_launch_hk_dense_lines).  Ragged ends of the piece, and anything
+    // that does not have this structure, take piece_plane.
+    auto piece = [&](int64_t lo, int64_t hi, double* d_Hp) -> int {
+        const int dim1 = dim - 1;
+        if (dim1 < 2 || hi - lo < 512) return piece_plane(lo, hi, d_Hp);
+        // the reduced component with the longest sub-runs
+        int e2 = -1;
+        int64_t best_changes = hi - lo;
+        for (int e = 0; e < dim1; ++e) {
+            int64_t changes = 0;
+            for (int64_t i = lo + 1; i < hi; ++i) changes += h_k[i * dim + reduced[e]] != h_k[(i - 1) * dim + reduced[e]];
+            if (changes < best_changes) {
+                best_changes = changes;
+                e2 = e;
+            }
+        }
+        if (e2 < 0 || best_changes < 4) return piece_plane(lo, hi, d_Hp);
+        const int c2 = reduced[e2];
+        std::vector<int64_t> sb(1, lo);  // sub-run starts
+        for (int64_t i = lo + 1; i < hi; ++i)
+            if (h_k[i * dim + c2] != h_k[(i - 1) * dim + c2]) sb.push_back(i);
+        sb.push_back(hi);
+        const size_t n_sub = sb.size() - 1;
+        if (n_sub < 6) return piece_plane(lo, hi, d_Hp);
+        const int64_t L = sb[2] - sb[1];  // an interior line
+        if (L < 8 || L > TBK_BM) return piece_plane(lo, hi, d_Hp);
+        auto same_line = [&](int64_t a0, int64_t b0) {  // equal remaining coordinates along two lines of length L
+            for (int64_t t = 0; t < L; ++t)
+                for (int e = 0; e < dim1; ++e)
+                    if (e != e2 && h_k[(a0 + t) * dim + reduced[e]] != h_k[(b0 + t) * dim + reduced[e]]) return false;
+            return true;
+        };
+        // body: the longest prefix of interior sub-runs (from the second one) that are lines like the first of them
+        size_t first = (sb[1] - sb[0] == L && same_line(sb[0], sb[1])) ? 0 : 1, last = first;
+        while (last < n_sub && sb[last + 1] - sb[last] == L && same_line(sb[first], sb[last])) ++last;
+        const int64_t n_lines = (int64_t)(last - first);
+        if (n_lines < 4) return piece_plane(lo, hi, d_Hp);
+        tbk_fold_plan_t* plan2 = nullptr;
+        const int cap = 256;  // lines per batch (operands: cap x k2'' x row)
+        TBK_CHECK(tbk_fold_subplan(m, plan1, e2, cap, &plan2));
+        if (!plan2 || plan2->n_rho * 3 > plan1.n_rho) return piece_plane(lo, hi, d_Hp);
+
+        if (sb[first] > lo) TBK_CHECK(piece_plane(lo, sb[first], d_Hp));  // ragged head
+        const int64_t row_len = (int64_t)m->ncol_pad * 2;
+        for (int64_t l0 = 0; l0 < n_lines; l0 += cap) {
+            const int64_t nl = std::min<int64_t>(cap, n_lines - l0);
+            const int64_t a0 = sb[first] + l0 * L;
+            // (the lines' shared-component values are read on the device: first point of every line)
+            TBK_CHECK(tbk_fold_lines(m, *plan2, d_k2 + a0 * dim1 + e2, L * dim1, (int)nl));
+            tbk_fold_saved_t saved2;
+            TBK_CHECK(tbk_fold_enter(m, *plan2, 0, saved2));
+            int rc = m->ws_kline.reserve((size_t)L * std::max(dim1 - 1, 1) * sizeof(double));
+            if (rc == TBK_OK) rc = tbk_fold_drop_component(m, d_k2 + a0 * dim1, dim1, e2, L, m->ws_kline.as<double>());
+            if (rc == TBK_OK) rc = m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * TBK_BM * sizeof(double));
+            if (rc == TBK_OK) rc = fill_rows(m, m->ws_kline.as<double>(), L, TBK_BM, m->ws_phase.as<double>());
+            if (rc == TBK_OK)
+                rc = tbk_launch_hk_dense_lines(m, m->ws_phase.as<double>(), nl, (int)L, plan2->k2 * row_len,
+                                               d_Hp + (size_t)(a0 - lo) * nn2);
+            tbk_fold_leave(m, saved2);
+            TBK_CHECK(rc);
+        }
+        const int64_t body_end = sb[first] + n_lines * L;
+        if (body_end < hi) TBK_CHECK(piece_plane(body_end, hi, d_Hp + (size_t)(body_end - lo) * nn2));  // ragged tail
+        return TBK_OK;
+    };
+
     const HBuilder folded = [&](int64_t c0, int64_t nkc, double* d_H) -> int {
         size_t r = (size_t)(std::upper_bound(runs.begin(), runs.end(), c0) - runs.begin()) - 1;
         for (int64_t lo = c0; lo < c0 + nkc; ++r) {
@@ -579,16 +661,11 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
                 const int n_g = (int)std::min<int64_t>(group, n_runs - group_lo);
                 double kf[64];
                 for (int g = 0; g < n_g; ++g) kf[g] = h_k[runs[(size_t)(group_lo + g)] * dim + f];
-                TBK_CHECK(tbk_fold_group(m, f, kf, n_g));
+                TBK_CHECK(tbk_fold_group(m, plan1, kf, n_g, 0));
             }
             tbk_fold_saved_t saved;
-            TBK_CHECK(tbk_fold_enter(m, f, (int)((int64_t)r - group_lo), saved));
-            const int64_t len = hi - lo, nk_pad = phase_ld(len);
-            int rc = m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double));
-            if (rc == TBK_OK) rc = fill_rows(m, d_k2 + lo * (dim - 1), len, nk_pad, m->ws_phase.as<double>());
-            if (rc == TBK_OK)
-                rc = build_h(m, m->ws_phase.as<double>(), len, nk_pad, HK_TRI, 2, d_k2 + lo * (dim - 1), nullptr,
-                             d_H + (size_t)(lo - c0) * nn2);
+            TBK_CHECK(tbk_fold_enter(m, plan1, (int)((int64_t)r - group_lo), saved));
+            const int rc = piece(lo, hi, d_H + (size_t)(lo - c0) * nn2);
             tbk_fold_leave(m, saved);
             TBK_CHECK(rc);
             lo = hi;

@@ -74,16 +74,34 @@ __global__ void fold_table_kernel(const int32_t* __restrict__ rcomp, int64_t n_r
     table[2 * i + 1] = sa;
 }
 
+// the same table for n_g lines whose shared-component values sit in device memory at k_f[g * stride]
+__global__ void fold_table_dev_kernel(const int32_t* __restrict__ rcomp, int64_t n_r, const double* __restrict__ k_f,
+                                      int64_t stride, int n_g, double* __restrict__ table) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_r * n_g) return;
+    const int64_t r = i / n_g;
+    const int g = (int)(i % n_g);
+    double sa, ca;
+    sincospi(2.0 * k_f[(int64_t)g * stride] * (double)rcomp[r], &sa, &ca);
+    table[2 * i] = ca;
+    table[2 * i + 1] = sa;
+}
+
 // The same fold for up to FOLD_GROUP runs in ONE pass over Bt: every (row pair, column) is loaded once and
 // accumulated into the operand of each run of the group (its phases come from the table above).
 
 __global__ void __launch_bounds__(256)
 fold_rows_group_kernel(const double* __restrict__ Bt, int64_t row_len, const int64_t* __restrict__ lptr,
-                       const int32_t* __restrict__ lrec, const double* __restrict__ table, int n_g, int64_t b2_stride,
-                       double* __restrict__ B2) {
+                       const int32_t* __restrict__ lrec, const double* __restrict__ table_all, int n_total,
+                       int64_t b2_stride, double* __restrict__ B2_all) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t rho = blockIdx.y;
     if (c >= row_len) return;
+    // blockIdx.z: which FOLD_GROUP slots of the n_total this block folds
+    const int g_base = blockIdx.z * FOLD_GROUP;
+    const int n_g = min(FOLD_GROUP, n_total - g_base);
+    const double* table = table_all + 2 * g_base;
+    double* B2 = B2_all + (size_t)g_base * b2_stride;
     double accp[FOLD_GROUP], accq[FOLD_GROUP];
 #pragma unroll
     for (int g = 0; g < FOLD_GROUP; ++g) accp[g] = accq[g] = 0.0;
@@ -92,7 +110,7 @@ fold_rows_group_kernel(const double* __restrict__ Bt, int64_t row_len, const int
         const int64_t r = rec & 0x7fffffff;
         const double sigma = rec < 0 ? -1.0 : 1.0;
         const double p = Bt[(2 * r) * row_len + c], q = Bt[(2 * r + 1) * row_len + c];
-        const double* tab = table + 2 * r * n_g;  // uniform
+        const double* tab = table + 2 * r * n_total;  // uniform
 #pragma unroll
         for (int g = 0; g < FOLD_GROUP; ++g) {
             if (g < n_g) {
@@ -133,47 +151,49 @@ bool canonical_negate(std::vector<int32_t>& v) {
 
 }  // namespace
 
-// Builds (once per model and component) the folded lattice and the row lists.
-int tbk_fold_plan(tbk_model* m, int f) {
-    tbk_fold_plan_t& plan = m->fold[f];
+// Builds the folded lattice and the row lists for folding the lattice R[n_r][dim] along component f.
+static int build_plan(tbk_fold_plan_t& plan, const int32_t* R, int64_t n_r, int dim, int f, int ncol_pad, int capacity) {
     if (plan.built) return TBK_OK;
-    const int dim = m->dim;
-    const int64_t n_r = m->n_r;
     std::map<std::vector<int32_t>, int32_t> index;
     std::vector<std::vector<int32_t>> lists;
-    std::vector<int32_t> rho_vec, rcomp((size_t)n_r);
+    std::vector<int32_t> rcomp((size_t)n_r);
+    plan.h_R2.clear();
     for (int64_t r = 0; r < n_r; ++r) {
         std::vector<int32_t> rho;
         for (int d = 0; d < dim; ++d)
-            if (d != f) rho.push_back(m->h_R[(size_t)r * dim + d]);
-        rcomp[(size_t)r] = m->h_R[(size_t)r * dim + f];
+            if (d != f) rho.push_back(R[(size_t)r * dim + d]);
+        rcomp[(size_t)r] = R[(size_t)r * dim + f];
         const bool negated = canonical_negate(rho);
         auto it = index.find(rho);
         if (it == index.end()) {
             it = index.emplace(rho, (int32_t)lists.size()).first;
             lists.emplace_back();
-            rho_vec.insert(rho_vec.end(), rho.begin(), rho.end());
+            plan.h_R2.insert(plan.h_R2.end(), rho.begin(), rho.end());
         }
         lists[(size_t)it->second].push_back((int32_t)r | (negated ? (int32_t)0x80000000 : 0));
     }
+    plan.dim = dim;
+    plan.n_r = n_r;
     plan.n_rho = (int64_t)lists.size();
     plan.k2 = (plan.n_rho * 2 + TBK_BK - 1) / TBK_BK * TBK_BK;
     plan.n_rho_pad = plan.k2 / 2;
+    plan.capacity = capacity;
     std::vector<int64_t> lptr((size_t)plan.n_rho_pad + 1, 0);
     std::vector<int32_t> lrec;
     for (int64_t i = 0; i < plan.n_rho_pad; ++i) {
         if (i < plan.n_rho) lrec.insert(lrec.end(), lists[(size_t)i].begin(), lists[(size_t)i].end());
         lptr[(size_t)i + 1] = (int64_t)lrec.size();  // padding vectors keep empty lists: zero rows
     }
-    std::vector<int32_t> r2((size_t)plan.n_rho_pad * (dim - 1), 0);
-    std::copy(rho_vec.begin(), rho_vec.end(), r2.begin());
-    const size_t row_len = (size_t)m->ncol_pad * 2;
+    std::vector<int32_t> r2((size_t)plan.n_rho_pad * std::max(dim - 1, 1), 0);
+    std::copy(plan.h_R2.begin(), plan.h_R2.end(), r2.begin());
+    const size_t row_len = (size_t)ncol_pad * 2;
     TBK_HIP(hipMalloc((void**)&plan.d_R2, std::max<size_t>(r2.size(), 1) * sizeof(int32_t)));
     TBK_HIP(hipMalloc((void**)&plan.d_lptr, lptr.size() * sizeof(int64_t)));
     TBK_HIP(hipMalloc((void**)&plan.d_lrec, std::max<size_t>(lrec.size(), 1) * sizeof(int32_t)));
     TBK_HIP(hipMalloc((void**)&plan.d_rcomp, std::max<size_t>(rcomp.size(), 1) * sizeof(int32_t)));
-    TBK_HIP(hipMalloc((void**)&plan.d_B2, (size_t)FOLD_GROUP * plan.k2 * row_len * sizeof(double)));
-    TBK_HIP(hipMalloc((void**)&plan.d_table, std::max<size_t>((size_t)n_r * FOLD_GROUP * 2, 1) * sizeof(double)));
+    TBK_HIP(hipMalloc((void**)&plan.d_B2, (size_t)capacity * plan.k2 * row_len * sizeof(double)));
+    plan.table_entries = n_r * FOLD_GROUP;
+    TBK_HIP(hipMalloc((void**)&plan.d_table, std::max<size_t>((size_t)plan.table_entries * 2, 1) * sizeof(double)));
     TBK_HIP(hipMemcpy(plan.d_R2, r2.data(), r2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     TBK_HIP(hipMemcpy(plan.d_lptr, lptr.data(), lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     TBK_HIP(hipMemcpy(plan.d_lrec, lrec.data(), lrec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -182,13 +202,42 @@ int tbk_fold_plan(tbk_model* m, int f) {
     return TBK_OK;
 }
 
-void tbk_fold_release(tbk_model* m) {
-    for (tbk_fold_plan_t& plan : m->fold) {
+int tbk_fold_plan(tbk_model* m, int f) {
+    return build_plan(m->fold[f], m->h_R.data(), m->n_r, m->dim, f, m->ncol_pad, FOLD_GROUP);
+}
+
+// Second-level plan: folds the lattice `parent` produced along its component f2 (mesh lines inside a mesh plane);
+// room for `capacity` operands (one per line of a plane piece).
+int tbk_fold_subplan(tbk_model* m, tbk_fold_plan_t& parent, int f2, int capacity, tbk_fold_plan_t** out) {
+    *out = nullptr;
+    const int dim2 = parent.dim - 1;
+    if (dim2 < 2 || f2 < 0 || f2 >= dim2) return TBK_OK;
+    if (!parent.sub) parent.sub = new tbk_fold_plan_t[TBK_MAX_DIM];
+    tbk_fold_plan_t& plan = parent.sub[f2];
+    if (plan.built && plan.capacity < capacity) {  // a longer piece than any before: rebuild with more room
         void* ptrs[] = {plan.d_R2, plan.d_lptr, plan.d_lrec, plan.d_rcomp, plan.d_B2, plan.d_table};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         plan = tbk_fold_plan_t();
     }
+    TBK_CHECK(build_plan(plan, parent.h_R2.data(), parent.n_rho, dim2, f2, m->ncol_pad, capacity));
+    *out = &plan;
+    return TBK_OK;
+}
+
+static void release_plan(tbk_fold_plan_t& plan) {
+    if (plan.sub) {
+        for (int i = 0; i < TBK_MAX_DIM; ++i) release_plan(plan.sub[i]);
+        delete[] plan.sub;
+    }
+    void* ptrs[] = {plan.d_R2, plan.d_lptr, plan.d_lrec, plan.d_rcomp, plan.d_B2, plan.d_table};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    plan = tbk_fold_plan_t();
+}
+
+void tbk_fold_release(tbk_model* m) {
+    for (tbk_fold_plan_t& plan : m->fold) release_plan(plan);
 }
 
 // Average run length from which folding pays: a run costs one pass over Bt (60 us at the headline shape) plus
@@ -224,35 +273,57 @@ int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int
 
 int tbk_fold_group_size() { return FOLD_GROUP; }
 
-// Folds the staged operand for the n_g (<= FOLD_GROUP) shared-component values h_kf[] in one pass (main stream).
-int tbk_fold_group(tbk_model* m, int f, const double* h_kf, int n_g) {
-    tbk_fold_plan_t& plan = m->fold[f];
+// Folds the CURRENT operand of `m` (m->d_B: the staged one, or a first-level folded one) for the n_g (<= FOLD_GROUP)
+// shared-component values h_kf[] in one pass, into slots slot0 .. slot0 + n_g - 1 of the plan's buffer (main stream).
+int tbk_fold_group(tbk_model* m, tbk_fold_plan_t& plan, const double* h_kf, int n_g, int slot0) {
     const int64_t row_len = (int64_t)m->ncol_pad * 2;
+    double* out = plan.d_B2 + (size_t)slot0 * plan.k2 * row_len;
     StageTimer t(m, TBK_T_PHASE);
     if (n_g == 1) {
         dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad);
         hipLaunchKernelGGL(fold_rows_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
-                           plan.d_rcomp, h_kf[0], plan.d_B2);
+                           plan.d_rcomp, h_kf[0], out);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
     FoldValues values;
     for (int g = 0; g < FOLD_GROUP; ++g) values.v[g] = g < n_g ? h_kf[g] : 0.0;
-    const int64_t entries = m->n_r * n_g;
+    const int64_t entries = plan.n_r * n_g;
     hipLaunchKernelGGL(fold_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, m->stream, plan.d_rcomp,
-                       m->n_r, values, n_g, plan.d_table);
+                       plan.n_r, values, n_g, plan.d_table);
     TBK_HIP(hipGetLastError());
     dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad);
     hipLaunchKernelGGL(fold_rows_group_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
-                       plan.d_table, n_g, plan.k2 * row_len, plan.d_B2);
+                       plan.d_table, n_g, plan.k2 * row_len, out);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
 
-// Turns `m` into the model folded for slot `g` of the last tbk_fold_group call; the caller evaluates the run piece
-// and calls tbk_fold_leave.
-int tbk_fold_enter(tbk_model* m, int f, int g, tbk_fold_saved_t& saved) {
-    tbk_fold_plan_t& plan = m->fold[f];
+// All n_lines (<= plan.capacity) lines of a mesh plane piece in one go: their shared-component values are read on
+// the device (d_kf[line * stride]); slots 0 .. n_lines - 1.
+int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int64_t stride, int n_lines) {
+    const int64_t row_len = (int64_t)m->ncol_pad * 2;
+    StageTimer t(m, TBK_T_PHASE);
+    if ((size_t)plan.table_entries < (size_t)plan.n_r * n_lines) {
+        if (plan.d_table) TBK_HIP(hipFree(plan.d_table));
+        plan.d_table = nullptr;
+        plan.table_entries = plan.n_r * (int64_t)std::max(n_lines, plan.capacity);
+        TBK_HIP(hipMalloc((void**)&plan.d_table, std::max<size_t>((size_t)plan.table_entries * 2, 1) * sizeof(double)));
+    }
+    const int64_t entries = plan.n_r * n_lines;
+    hipLaunchKernelGGL(fold_table_dev_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, m->stream,
+                       plan.d_rcomp, plan.n_r, d_kf, stride, n_lines, plan.d_table);
+    TBK_HIP(hipGetLastError());
+    dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad, (unsigned)((n_lines + FOLD_GROUP - 1) / FOLD_GROUP));
+    hipLaunchKernelGGL(fold_rows_group_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
+                       plan.d_table, n_lines, plan.k2 * row_len, plan.d_B2);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
+// Turns `m` into the model folded by `plan`, with the operand in `slot` of the plan's buffer; the caller evaluates and
+// calls tbk_fold_leave.  Nests (a second-level plan on top of a first-level one).
+int tbk_fold_enter(tbk_model* m, tbk_fold_plan_t& plan, int slot, tbk_fold_saved_t& saved) {
     const int64_t row_len = (int64_t)m->ncol_pad * 2;
     saved.dim = m->dim;
     saved.n_r = m->n_r;
@@ -265,7 +336,7 @@ int tbk_fold_enter(tbk_model* m, int f, int g, tbk_fold_saved_t& saved) {
     m->n_r_pad = plan.n_rho_pad;
     m->k2 = plan.k2;
     m->d_R = plan.d_R2;
-    m->d_B = plan.d_B2 + (size_t)g * plan.k2 * row_len;
+    m->d_B = plan.d_B2 + (size_t)slot * plan.k2 * row_len;
     return TBK_OK;
 }
 

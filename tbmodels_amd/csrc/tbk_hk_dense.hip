@@ -65,6 +65,11 @@ struct HkArgs {
     double* P;
     int splits;
     int64_t p_rows;  // k rows per split in P
+    // "lines" launches (second-level fold, tbk_fold.hip): k tile t is one mesh line -- its own operand at
+    // Bt + t * b_tile_stride, the SAME phase rows for every line (a_tile_stride = 0), rows_per_tile k-points of output
+    int64_t a_tile_stride;  // TBK_BM in ordinary launches
+    int64_t b_tile_stride;  // 0 in ordinary launches
+    int rows_per_tile;      // TBK_BM in ordinary launches
 };
 
 // One finished element of the packed tile -> H[k][i][j] (and H[k][j][i] conjugated in FULL mode), with the
@@ -133,12 +138,12 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
     const int l15 = lane & 15;
     const int l4 = lane >> 4;
 
-    const int64_t m0 = (int64_t)mt_idx * TBK_BM;
+    const int64_t m0 = (int64_t)mt_idx * a.rows_per_tile;  // first k-point of the tile's output rows
     const int64_t n0 = (int64_t)nt_idx * TBK_BNP;
 
     // staging: wave w copies K rows w, w+4, w+8, w+12 of both operands, 16 B per lane
-    const double* gA = a.A + m0 + lane * 2;
-    const double* gB = a.Bt + n0 * 2 + lane * 2;
+    const double* gA = a.A + (int64_t)mt_idx * a.a_tile_stride + lane * 2;
+    const double* gB = a.Bt + (int64_t)mt_idx * a.b_tile_stride + n0 * 2 + lane * 2;
     const int64_t ldgA = a.nk_pad;
     const int64_t ldgB = (int64_t)a.ncol_pad * 2;
 
@@ -216,8 +221,9 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t kq = m0 + wm * 64 + i * 16 + l4 + 4 * r;
-                if (kq >= a.nk) continue;
+                const int local = wm * 64 + i * 16 + l4 + 4 * r;
+                const int64_t kq = m0 + local;
+                if (local >= a.rows_per_tile || kq >= a.nk) continue;
                 if (SPLIT) {
                     double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kq) * a.ncol_pad + e) * 2;
                     *reinterpret_cast<d2*>(part) = (d2){acc[i][j][0][r], acc[i][j][1][r]};
@@ -358,6 +364,9 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.P = nullptr;
     a.splits = 1;
     a.p_rows = 0;
+    a.a_tile_stride = TBK_BM;
+    a.b_tile_stride = 0;
+    a.rows_per_tile = TBK_BM;
     if (nk <= 32 && m->k2 > 0) {
         // matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
         const int col_blocks = (a.ncol_pad + 255) / 256;
@@ -405,5 +414,47 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     } else {
         TBK_HIP((launch<HK_FULL, 2>(a, grid, m->stream)));
     }
+    return TBK_OK;
+}
+
+// H(k) of n_lines mesh lines of line_len (<= 128) k-points each in ONE launch: line t uses the operand at
+// m->d_B + t * b_stride (a second-level folded model per line) and all lines share the phase rows d_A[K][128]
+// (the k-points of a line differ only in the remaining component, which is the same sequence on every line).
+// TRI mode, convention 2 (the eigenvalue path).
+int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, int line_len, int64_t b_stride,
+                              double* d_H) {
+    if (n_lines == 0) return TBK_OK;
+    TBK_ARG(line_len >= 1 && line_len <= TBK_BM, "a mesh line must fit one k tile");
+    HkArgs a;
+    a.A = d_A;
+    a.Bt = m->d_B;
+    a.colmap = m->d_colmap;
+    a.kpts = nullptr;
+    a.pos = nullptr;
+    a.H = d_H;
+    a.k2 = m->k2;
+    a.nk = n_lines * line_len;
+    a.nk_pad = TBK_BM;
+    a.ncol_pad = m->ncol_pad;
+    a.n_orb = m->n_orb;
+    a.dim = m->dim;
+    a.mt_count = (int)n_lines;
+    a.nt_count = m->ncol_pad / TBK_BNP;
+    a.P = nullptr;
+    a.splits = 1;
+    a.p_rows = 0;
+    a.a_tile_stride = 0;
+    a.b_tile_stride = b_stride;
+    a.rows_per_tile = line_len;
+    int grid;
+    if (a.mt_count >= 32) {
+        a.xcd_rows = 4;
+        grid = ((a.mt_count + 7) / 8) * a.nt_count * 8;
+    } else {
+        a.xcd_rows = 0;
+        grid = a.mt_count * a.nt_count;
+    }
+    StageTimer t(m, TBK_T_HK);
+    TBK_HIP((launch<HK_TRI, 2>(a, grid, m->stream)));
     return TBK_OK;
 }

@@ -99,13 +99,19 @@ struct EventPair {
 // ------------------------------------------------------------------------------------------------
 struct tbk_fold_plan_t {
     bool built = false;
+    int dim = 0;                 // dimension of the lattice this plan folds (the folded one has dim - 1)
+    int64_t n_r = 0;             // its lattice vectors
     int64_t n_rho = 0, n_rho_pad = 0, k2 = 0;  // folded lattice vectors; K rows of the folded operand
+    int capacity = 0;            // folded operands that fit d_B2
+    std::vector<int32_t> h_R2;   // host copy of the folded lattice [n_rho][dim - 1] (second-level plans are built on it)
     int32_t* d_R2 = nullptr;     // [n_rho_pad][dim - 1]
     int64_t* d_lptr = nullptr;   // [n_rho_pad + 1] lists of contributing lattice vectors
     int32_t* d_lrec = nullptr;   // r | (negated ? 1 << 31 : 0)
     int32_t* d_rcomp = nullptr;  // [n_r] the folded component of every lattice vector
-    double* d_B2 = nullptr;      // [group][k2][ncol_pad * 2] folded operands of the current group of runs
-    double* d_table = nullptr;   // [n_r][group][2] (cos, sin) of the shared-component phases
+    double* d_B2 = nullptr;      // [capacity][k2][ncol_pad * 2] folded operands
+    double* d_table = nullptr;   // [n_r][slots][2] (cos, sin) of the shared-component phases
+    int64_t table_entries = 0;   // its capacity in (r, slot) pairs
+    tbk_fold_plan_t* sub = nullptr;  // [dim - 1] second-level plans (mesh lines inside a mesh plane), built on demand
 };
 
 struct tbk_fold_saved_t {
@@ -179,6 +185,7 @@ struct tbk_model {
     DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
     DevBuf ws_part;   // split-K partial tiles of the dense H(k) kernel (small k batches)
     DevBuf ws_kfold;  // k-points of a folded run without the folded component
+    DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};
@@ -218,6 +225,8 @@ int tbk_stage_kdotp(tbk_model* m, const double* d_coeff_raw);
 int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
                         int convention, const double* d_k, const double* d_pos, double* d_H);
 
+int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, int line_len, int64_t b_stride, double* d_H);
+
 // tbk_hk_csr.hip
 int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
                       int convention, const double* d_k, const double* d_pos, double* d_H);
@@ -241,10 +250,12 @@ int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, d
 // tbk_fold.hip
 int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int64_t>& run_starts);
 int tbk_fold_group_size();
-int tbk_fold_group(tbk_model* m, int f, const double* h_kf, int n_g);
-int tbk_fold_enter(tbk_model* m, int f, int g, tbk_fold_saved_t& saved);
+int tbk_fold_group(tbk_model* m, tbk_fold_plan_t& plan, const double* h_kf, int n_g, int slot0);
+int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int64_t stride, int n_lines);
+int tbk_fold_enter(tbk_model* m, tbk_fold_plan_t& plan, int slot, tbk_fold_saved_t& saved);
 void tbk_fold_leave(tbk_model* m, const tbk_fold_saved_t& saved);
 int tbk_fold_drop_component(tbk_model* m, const double* d_k, int dim, int f, int64_t nk, double* d_k2);
+int tbk_fold_subplan(tbk_model* m, tbk_fold_plan_t& parent, int f2, int capacity, tbk_fold_plan_t** out);
 void tbk_fold_release(tbk_model* m);
 int64_t tbk_fold_min_run();
 
