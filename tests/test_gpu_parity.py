@@ -192,6 +192,8 @@ def _grid(shape, offset=(0.0, 0.0, 0.0), order="ij"):
         (3, (40, 3, 40), (0.13, -0.4, 2.5), "xy"),     # shifted mesh; component 1 is the slow one
         (2, (5, 1100), (0.0, 0.25), "ij"),             # 2-D model: lines of constant k_1 fold to a 1-D model
         (3, (2, 30, 50), (0.0, 0.0, 0.0), "ij"),
+        (3, (2, 12, 200), (0.0, 0.1, 0.0), "ij"),      # lines longer than a k tile: planes only
+        (4, (2, 40, 6, 6), (0.0, 0.0, 0.5, 0.0), "ij"),  # 4-D: lines are 2-D models
     ],
 )
 def test_folded_grid_matches_direct_evaluation(dim, shape, offset, order):
@@ -199,7 +201,7 @@ def test_folded_grid_matches_direct_evaluation(dim, shape, offset, order):
     component (tbk_fold.hip): same eigenvalues as the direct path (TBK_OPT_FOLD = 0) and as the oracle."""
     from tbmodels_amd import _lib
 
-    n_orb, n_r = 12, 300 if dim == 3 else 160
+    n_orb, n_r = 12, {2: 160, 3: 300, 4: 600}[dim]
     r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 50 + dim, dim=dim)
     k = _grid(shape[:dim], offset[:dim], order)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
