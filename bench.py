@@ -366,7 +366,8 @@ def main():
 
         sample = args.cpu_sample
         if sample < 0:
-            sample = {"cfg1": 1000, "cfg2": 256, "cfg3": 48, "cfg4": 256, "cfg5": 4}[args.config]
+            # ~10-15 s of single-core work each (17-19 ms per k-point at the headline shape)
+            sample = {"cfg1": 1000, "cfg2": 640, "cfg3": 48, "cfg4": 640, "cfg5": 4}[args.config]
         cpu = None
         parity = None
         if sample > 0 and not args.construct_only:
