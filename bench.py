@@ -132,6 +132,75 @@ def cpu_baseline(arrays, kpts, sample):
     return len(k) / dt, dt, np.array(eig)
 
 
+_CPU_SHARED = {}
+
+
+def _cpu_chunk(bounds):
+    from oracle import tbk_oracle as oracle  # checker / baseline only
+
+    lo, hi = bounds
+    if hi > lo:
+        oracle.eigenval(_CPU_SHARED["R"], _CPU_SHARED["hop"], _CPU_SHARED["k"][lo:hi])
+    return hi - lo
+
+
+def _cpu_worker_init():
+    try:  # the oracle's ufunc passes are single-threaded; keep LAPACK from spawning a pool per process
+        import threadpoolctl  # pylint: disable=import-outside-toplevel
+
+        _CPU_SHARED["limit"] = threadpoolctl.threadpool_limits(1)
+    except ImportError:
+        pass
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU boxes show
+    256 CPUs under a 16-CPU quota; 256 busy processes there ran slower than 16)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
+def cpu_baseline_all_cores(arrays, kpts, per_proc):
+    """The same oracle in one process per host core, each on its own contiguous k chunk (what a
+    user of the reference does with its pickle support).  Forks, so it runs BEFORE this process touches the GPU."""
+    import multiprocessing as mp  # pylint: disable=import-outside-toplevel
+
+    procs = usable_cores()
+    if arrays["kind"] == "dense":
+        hop = arrays["hop"]
+    else:
+        hop = synthetic.csr_to_dense(arrays["n_orb"], arrays["r_ptr"], arrays["row"], arrays["col"], arrays["val"])
+    total = min(len(kpts), procs * per_proc)
+    edges = [total * i // procs for i in range(procs + 1)]
+    _CPU_SHARED.update(R=arrays["R"], hop=hop, k=kpts)
+    with mp.get_context("fork").Pool(procs, initializer=_cpu_worker_init) as pool:
+        pool.map(_cpu_chunk, [(0, 0)] * procs, chunksize=1)  # every worker up and imported before the clock starts
+        t0 = time.perf_counter()
+        done = sum(pool.map(_cpu_chunk, list(zip(edges[:-1], edges[1:])), chunksize=1))
+        dt = time.perf_counter() - t0
+    _CPU_SHARED.clear()
+    return {
+        "value": round(done / dt, 2), "unit": "k-points/s", "cores": procs, "kind": "port", "host_cpus": os.cpu_count(),
+        "sample": "%d k-points of this workload in %d processes (one contiguous chunk each), same oracle, %.1f s"
+                  % (done, procs, dt),
+    }
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,13 +211,6 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-
-    lib = _lib.lib()
-    if _lib.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: libtbk has no CPU path")
-    device = local_rank % _lib.device_count()
-
-    group = group_from_env() if world > 1 else None
 
     kind, n_orb, n_r, nk_gpu, cfg_idx = CONFIGS[args.config]
     if args.nk:
@@ -180,6 +242,16 @@ def main():
             k_slab = rng.random((nk_gpu, dim))
     k_slab = np.ascontiguousarray(k_slab)
 
+    cpu_all = None
+    if rank == 0 and world == 1 and args.cpu_sample != 0 and not args.construct_only:
+        per_proc = {"cfg1": 64, "cfg2": 256, "cfg3": 24, "cfg4": 256, "cfg5": 2}[args.config]  # ~5-10 s
+        cpu_all = cpu_baseline_all_cores(arrays, k_slab, per_proc)
+
+    lib = _lib.lib()
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libtbk has no CPU path")
+    device = local_rank % _lib.device_count()
+    group = group_from_env() if world > 1 else None
     model = stage(lib, device, arrays)
     solver = {"auto": _lib.TBK_EIG_AUTO, "wave": _lib.TBK_EIG_WAVE, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[args.eigensolver]
     _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, solver))
@@ -406,6 +478,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "max_abs_err_vs_oracle": parity,
             "max_trace_identity_err_4096_rows": trace_err,
