@@ -71,14 +71,16 @@ def _worker(rank, world, port, n_k, out_dir, backend="gloo"):
         sharded.group.close()
 
 
-@pytest.mark.parametrize("backend,n_k", [("gloo", 11), ("gloo", 64), ("gloo", 1), ("file", 11), ("file", 2)])
-def test_world_size_2_allgather(tmp_path, backend, n_k):
+@pytest.mark.parametrize(
+    "backend,n_k,world",
+    [("gloo", 11, 2), ("gloo", 64, 2), ("gloo", 1, 2), ("file", 11, 2), ("file", 2, 2), ("file", 37, 8), ("file", 5, 8)],
+)
+def test_world_size_n_allgather(tmp_path, backend, n_k, world):
     import multiprocessing as mp
 
     from tbmodels_amd import synthetic as syn
     from oracle import tbk_oracle as oracle
 
-    world = 2
     port = _free_port()
     # fresh interpreters: torch (gloo) is imported only inside the workers -- never in this process,
     # which may already hold libtbk and its system ROCm runtime (see tbmodels_amd/rendezvous.py)
