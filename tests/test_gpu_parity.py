@@ -422,3 +422,49 @@ def test_csr_kernel_variants(n_r):
     _close(model.hamilton(k), oracle.hamilton(r_vec, hop, k))
     _close(model.hamilton(k, convention=1), oracle.hamilton(r_vec, hop, k, 1, pos=pos))
     _close(np.array(model.eigenval(k)), np.array(oracle.eigenval(r_vec, hop, k)))
+
+
+@pytest.mark.parametrize("n,n_r", [(10, 4), (70, 9)])
+def test_csr_duplicates_unsorted_and_explicit_zeros(n, n_r):
+    """Straight through the C ABI (the Python model canonicalises its matrices): duplicate (row, col) entries are
+    summed like scipy's toarray(), entries come in any order inside an R block, stored zeros are harmless
+    (include/tbk.h, tbk_model_create_csr)."""
+    import ctypes
+
+    from tbmodels_amd import _lib
+
+    rng = np.random.default_rng(99 + n)
+    r_vec = np.ascontiguousarray(syn.half_space_vectors(n_r), dtype=np.int32)  # R = 0 first
+    assert not r_vec[0].any()
+    dense = np.zeros((n_r, n, n), dtype=complex)
+    r_ptr, rows, cols, vals = [0], [], [], []
+    for idx in range(n_r):
+        nnz = 4 * n  # with replacement: duplicates are certain
+        row = rng.integers(0, n, nnz).astype(np.int32)  # not even grouped by row
+        col = rng.integers(0, n, nnz).astype(np.int32)
+        val = rng.normal(size=nnz) + 1j * rng.normal(size=nnz)
+        val[::7] = 0.0
+        if idx == 0:  # the stored R = 0 block is half of a Hermitian block (a8): add every entry's mirror image
+            row, col, val = np.concatenate([row, col]), np.concatenate([col, row]), np.concatenate([val, val.conj()]) / 2
+        np.add.at(dense[idx], (row, col), val)
+        rows.append(row)
+        cols.append(col)
+        vals.append(val)
+        r_ptr.append(r_ptr[-1] + len(row))
+    r_ptr = np.array(r_ptr, dtype=np.int64)
+    rows, cols = np.ascontiguousarray(np.concatenate(rows)), np.ascontiguousarray(np.concatenate(cols))
+    vals = np.ascontiguousarray(np.concatenate(vals), dtype=np.complex128)
+    lib = _lib.lib()
+    handle = ctypes.c_void_p()
+    _lib.check(lib.tbk_model_create_csr(0, 3, n, n_r, _lib.ptr(r_vec), _lib.ptr(r_ptr), _lib.ptr(rows), _lib.ptr(cols),
+                                        _lib.ptr(vals), ctypes.byref(handle)))
+    try:
+        k = syn.random_kpoints(50, seed=5)
+        ham = np.empty((len(k), n, n), dtype=np.complex128)
+        eig = np.empty((len(k), n))
+        _lib.check(lib.tbk_hamilton(handle, _lib.ptr(k), len(k), 2, None, _lib.ptr(ham)))
+        _lib.check(lib.tbk_eigenval(handle, _lib.ptr(k), len(k), _lib.ptr(eig)))
+    finally:
+        lib.tbk_model_destroy(handle)
+    _close(ham, oracle.hamilton(r_vec, dense, k))
+    _close(eig, np.array(oracle.eigenval(r_vec, dense, k)))
