@@ -176,6 +176,8 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
 // ------------------------------------------------------------------------------------------------
 extern "C" int tbk_model_create_dense(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
                                       const double* hop, tbk_model** out) {
+    TBK_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
     TBK_ARG(n_r == 0 || hop != nullptr, "hop is NULL");
     tbk_model* m = nullptr;
     TBK_CHECK(create_common(device, dim, n_orb, n_r, R, 2, &m));
@@ -204,8 +206,12 @@ extern "C" int tbk_model_create_dense(int device, int dim, int n_orb, int64_t n_
 extern "C" int tbk_model_create_csr(int device, int dim, int n_orb, int64_t n_r, const int32_t* R,
                                     const int64_t* r_ptr, const int32_t* row, const int32_t* col,
                                     const double* val, tbk_model** out) {
+    TBK_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    TBK_ARG(n_r >= 0, "n_r out of range");
     TBK_ARG(n_r == 0 || r_ptr != nullptr, "r_ptr is NULL");
     const int64_t nnz = n_r > 0 ? r_ptr[n_r] : 0;
+    TBK_ARG(n_r == 0 || r_ptr[0] == 0, "r_ptr[0] must be 0");
     TBK_ARG(nnz >= 0, "negative nnz");
     TBK_ARG(nnz == 0 || (row && col && val), "row/col/val is NULL");
     for (int64_t r = 0; r < n_r; ++r) TBK_ARG(r_ptr[r] <= r_ptr[r + 1], "r_ptr not monotone");

@@ -246,3 +246,61 @@ def test_product_package_does_not_import_oracle():
                 with open(os.path.join(dirpath, name)) as handle:
                     text = handle.read()
                 assert "import oracle" not in text and "from oracle" not in text, name
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_a_device():
+    """Argument validation of the create calls comes first (no GPU needed): status TBK_ERR_ARGUMENT and a message in
+    tbk_last_error(); the Python wrapper turns that status into ValueError."""
+    lib = _lib.lib()
+    handle = ctypes.c_void_p()
+    r_vec = np.zeros((1, 3), dtype=np.int32)
+    hop = np.zeros((1, 2, 2), dtype=np.complex128)
+
+    def last():
+        return lib.tbk_last_error().decode()
+
+    create_dense = lib.tbk_model_create_dense
+    assert create_dense(0, 0, 2, 1, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert "dim" in last()
+    assert create_dense(0, 3, 0, 1, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert "n_orb" in last()
+    assert create_dense(0, 3, 2, -1, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert create_dense(0, 3, 2, 1, _lib.ptr(r_vec), None, ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert "hop" in last()
+    assert create_dense(0, 3, 2, 1, None, _lib.ptr(hop), ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert create_dense(0, 3, 2, 1, _lib.ptr(r_vec), _lib.ptr(hop), None) == _lib.TBK_ERR_ARGUMENT
+
+    create_csr = lib.tbk_model_create_csr
+    r_ptr = np.array([0, 2], dtype=np.int64)
+    row = np.array([0, 1], dtype=np.int32)
+    col = np.array([1, 5], dtype=np.int32)  # 5 is outside a 2 x 2 block
+    val = np.ones(2, dtype=np.complex128)
+    args = (0, 3, 2, 1, _lib.ptr(r_vec))
+    assert create_csr(*args, _lib.ptr(r_ptr), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+                      ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert "out of range" in last()
+    assert create_csr(*args, None, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+                      ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    bad_ptr = np.array([2, 0], dtype=np.int64)
+    assert create_csr(*args, _lib.ptr(bad_ptr), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+                      ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    col[1] = 1
+    assert create_csr(*args, _lib.ptr(r_ptr), _lib.ptr(row), _lib.ptr(col), None,
+                      ctypes.byref(handle)) == _lib.TBK_ERR_ARGUMENT
+    assert handle.value is None
+    with pytest.raises(ValueError):
+        _lib.check(create_dense(0, 0, 2, 1, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)))
+    # calls on a missing handle, and a communicator with an impossible rank
+    k = np.zeros((1, 3))
+    out = np.zeros((1, 2, 2), dtype=np.complex128)
+    assert lib.tbk_hamilton(None, _lib.ptr(k), 1, 2, None, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    assert lib.tbk_eigenval(None, _lib.ptr(k), 1, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    assert lib.tbk_model_set_option(None, _lib.TBK_OPT_TIMING, 1) == _lib.TBK_ERR_ARGUMENT
+    comm = ctypes.c_void_p()
+    uid = np.zeros(128, dtype=np.uint8)
+    assert lib.tbk_comm_create(0, 2, 2, _lib.ptr(uid), ctypes.byref(comm)) == _lib.TBK_ERR_ARGUMENT
+    assert lib.tbk_comm_create(0, 2, 0, None, ctypes.byref(comm)) == _lib.TBK_ERR_ARGUMENT
+    lib.tbk_model_destroy(None)  # a no-op, like free(NULL)
+    if _lib.device_count() == 0:  # valid arguments, no device: the loud failure, not a host computation
+        assert create_dense(0, 3, 2, 1, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)) == _lib.TBK_ERR_DEVICE
+        assert "no CPU path" in last()
