@@ -26,8 +26,9 @@
  *   - "host" entry points take caller-owned host memory and return when the result is in it;
  *     "device" entry points take device pointers on the model's device, enqueue on the model's
  *     stream and return without synchronising (tbk_synchronize waits);
- *   - a handle is immutable after creation (re-create it when model.hop changes); calls on one
- *     handle must not overlap in time; different handles are independent.
+ *   - a handle's staged model is immutable after creation (re-create it when model.hop changes);
+ *     host threads calling into ONE handle are serialised by a lock inside it (they share its
+ *     workspaces and streams); different handles are independent and run concurrently.
  *
  * There is no CPU implementation behind this interface: without a gfx950 device every compute
  * entry point fails with TBK_ERR_DEVICE.

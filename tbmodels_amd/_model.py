@@ -19,6 +19,7 @@ and rebuilt lazily.
 import collections as co
 import ctypes
 import os
+import threading
 import warnings
 import zlib
 
@@ -151,6 +152,7 @@ class Model:
         self._handle = None
         self._staged_fingerprint = None
         self._pinned = False
+        self._call_lock = threading.RLock()
         self.device = int(os.environ.get("TBK_DEVICE", "0"))
 
         self.set_sparse(sparse)
@@ -468,10 +470,12 @@ class Model:
         state = dict(self.__dict__)
         state["_handle"] = None
         state["_staged_fingerprint"] = None
+        state.pop("_call_lock", None)
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self._call_lock = threading.RLock()
         if isinstance(self.hop, _HopDict):  # nobody outside holds references into a freshly unpickled model
             self.hop.exposed = False
             self.hop.version = 0
@@ -571,7 +575,8 @@ class Model:
 
     def set_option(self, option, value):
         """Forward a ``TBK_OPT_*`` option to the staged model (see ``include/tbk.h``)."""
-        _lib.check(_lib.lib().tbk_model_set_option(self._staged(), option, int(value)))
+        with self._call_lock:
+            _lib.check(_lib.lib().tbk_model_set_option(self._staged(), option, int(value)))
 
     # ------------------------------------------------------------------ the hot path
     def _k_array(self, k):
@@ -604,9 +609,10 @@ class Model:
         n_k = k_array.shape[0]
         out = np.empty((n_k, self.size, self.size), dtype=np.complex128)
         pos = np.ascontiguousarray(self.pos, dtype=np.float64) if convention == 1 else None
-        _lib.check(
-            _lib.lib().tbk_hamilton(self._staged(), _lib.ptr(k_array), n_k, int(convention), _lib.ptr(pos), _lib.ptr(out))
-        )
+        with self._call_lock:  # (re)staging and the call are one step for other threads (ctypes drops the GIL)
+            _lib.check(
+                _lib.lib().tbk_hamilton(self._staged(), _lib.ptr(k_array), n_k, int(convention), _lib.ptr(pos), _lib.ptr(out))
+            )
         return out[0] if single else out
 
     def eigenval(self, k):
@@ -629,7 +635,8 @@ class Model:
             raise ValueError("array must not contain infs or NaNs")
         n_k = k_array.shape[0]
         out = np.empty((n_k, self.size), dtype=np.float64)
-        _lib.check(_lib.lib().tbk_eigenval(self._staged(), _lib.ptr(k_array), n_k, _lib.ptr(out)))
+        with self._call_lock:
+            _lib.check(_lib.lib().tbk_eigenval(self._staged(), _lib.ptr(k_array), n_k, _lib.ptr(out)))
         if not np.isfinite(out).all():
             raise ValueError("array must not contain infs or NaNs")
         return out[0] if single else out
@@ -661,11 +668,12 @@ class Model:
             source = Model.from_packed(r_vec, dense, size=self.size, dim=self.dim)
             source.device = self.device
         coeffs = np.empty((len(powers), self.size, self.size), dtype=np.complex128)
-        _lib.check(
-            _lib.lib().tbk_kdotp_coefficients(
-                source._staged(), _lib.ptr(k0), len(powers), _lib.ptr(pw), _lib.ptr(pref), _lib.ptr(coeffs)
+        with source._call_lock:
+            _lib.check(
+                _lib.lib().tbk_kdotp_coefficients(
+                    source._staged(), _lib.ptr(k0), len(powers), _lib.ptr(pw), _lib.ptr(pref), _lib.ptr(coeffs)
+                )
             )
-        )
         return KdotpModel(taylor_coefficients={p: coeffs[i] for i, p in enumerate(powers)})
 
     # ------------------------------------------------------------------ HDF5 wire format

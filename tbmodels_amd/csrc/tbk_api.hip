@@ -301,6 +301,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
 
 extern "C" int tbk_model_set_option(tbk_model* m, int option, int64_t value) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     switch (option) {
         case TBK_OPT_EIGENSOLVER:
             TBK_ARG(value >= TBK_EIG_AUTO && value <= TBK_EIG_ROCSOLVER, "unknown eigensolver");
@@ -370,6 +371,7 @@ static int build_h(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, 
 extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, int convention,
                                    const double* d_pos, double* d_H) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_ARG(convention == 1 || convention == 2, "convention must be 1 or 2");
     TBK_ARG(nk >= 0, "nk < 0");
     if (nk == 0) return TBK_OK;
@@ -685,6 +687,7 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
 
 static int eigenval_device_impl(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_ARG(nk >= 0, "nk < 0");
     if (nk == 0) return TBK_OK;
     TBK_ARG(d_k && d_E, "k / E is NULL");
@@ -725,6 +728,7 @@ extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, 
 
 extern "C" int tbk_synchronize(tbk_model* m) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_HIP(hipSetDevice(m->device));
     TBK_HIP(hipStreamSynchronize(m->stream));
     return TBK_OK;
@@ -732,6 +736,7 @@ extern "C" int tbk_synchronize(tbk_model* m) {
 
 extern "C" int tbk_eigenval_check(tbk_model* m) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_HIP(hipSetDevice(m->device));
     int flag[2] = {0, 0};
     TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost, m->stream));
@@ -748,6 +753,7 @@ extern "C" int tbk_eigenval_check(tbk_model* m) {
 extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int convention,
                             const double* pos, double* H_out) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_ARG(convention == 1 || convention == 2, "convention must be 1 or 2");
     TBK_ARG(nk >= 0, "nk < 0");
     if (nk == 0) return TBK_OK;
@@ -781,6 +787,7 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
 
 extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E_out) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_ARG(nk >= 0, "nk < 0");
     if (nk == 0) return TBK_OK;
     TBK_ARG(k && E_out, "k / E is NULL");
@@ -899,6 +906,7 @@ extern "C" int tbk_device_mem_info(int device, int64_t* free_bytes, int64_t* tot
 // ------------------------------------------------------------------------------------------------
 extern "C" int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int reset) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_HIP(hipSetDevice(m->device));
     TBK_HIP(hipStreamSynchronize(m->stream));
     TBK_HIP(hipStreamSynchronize(m->stream_eig));

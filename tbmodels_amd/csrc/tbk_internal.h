@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,8 @@ void tbk_set_error(const char* fmt, ...);
         int r_ = (expr);                                                                          \
         if (r_ != TBK_OK) return r_;                                                              \
     } while (0)
+
+#define TBK_LOCK(m) std::lock_guard<std::recursive_mutex> tbk_lock_((m)->mu)
 
 #define TBK_ARG(cond, msg)                                                                        \
     do {                                                                                          \
@@ -125,6 +128,9 @@ struct tbk_fold_saved_t {
 // staged model
 // ------------------------------------------------------------------------------------------------
 struct tbk_model {
+    // One host thread at a time per handle: the entry points share workspaces, the fold cache and the stage timers
+    // (ctypes drops the GIL for the duration of a call).  Recursive: the host-buffer calls go through the device ones.
+    std::recursive_mutex mu;
     int device = 0;
     int dim = 0;
     int n_orb = 0;

@@ -82,6 +82,7 @@ kdotp_coeff_kernel(const double* __restrict__ Bt, const int32_t* __restrict__ co
 extern "C" int tbk_kdotp_coefficients(tbk_model* m, const double* k0, int64_t n_p, const int32_t* powers,
                                       const double* prefactor, double* coeffs_out) {
     TBK_ARG(m != nullptr, "model is NULL");
+    TBK_LOCK(m);
     TBK_ARG(!m->sparse && !m->kdotp, "construct_kdotp needs a dense tight-binding model handle");
     TBK_ARG(n_p >= 0 && n_p <= 65535, "n_p out of range");
     if (n_p == 0) return TBK_OK;

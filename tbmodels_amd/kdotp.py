@@ -8,6 +8,7 @@ eigensolver (``tbk_kdotp_*`` in ``include/tbk.h``).
 """
 
 import ctypes
+import threading
 
 import numpy as np
 
@@ -30,12 +31,18 @@ class KdotpModel:
             tuple(key): np.array(mat, dtype=complex) for key, mat in taylor_coefficients.items()
         }
         self._handle = None
+        self._call_lock = threading.RLock()
         self.device = 0
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_handle"] = None
+        state.pop("_call_lock", None)
         return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._call_lock = threading.RLock()
 
     def __del__(self):
         handle = getattr(self, "_handle", None)
@@ -53,6 +60,10 @@ class KdotpModel:
         return len(key), mat.shape[0]
 
     def _staged(self):
+        with self._call_lock:
+            return self._staged_locked()
+
+    def _staged_locked(self):
         if self._handle is None:
             dim, size = self._shape()
             keys = list(self.taylor_coefficients.keys())

@@ -468,3 +468,37 @@ def test_csr_duplicates_unsorted_and_explicit_zeros(n, n_r):
         lib.tbk_model_destroy(handle)
     _close(ham, oracle.hamilton(r_vec, dense, k))
     _close(eig, np.array(oracle.eigenval(r_vec, dense, k)))
+
+
+def test_threads_sharing_one_model_and_threads_with_their_own():
+    """ctypes drops the GIL during a call: concurrent host threads on ONE handle are serialised by the library (they
+    share its workspaces), threads with their own models just run; both give the single-threaded results."""
+    import threading
+
+    r_vec, hop, pos = syn.dense_model_arrays(20, 30, syn.MODEL_SEED + 77)
+    shared = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    batches = [syn.random_kpoints(n_k, seed=100 + i) for i, n_k in enumerate((1, 37, 5000, 300, 9000, 2, 700, 4097))]
+    expected_e = [shared.eigenval_array(k) for k in batches]
+    expected_h = [shared.hamilton(k[:50], convention=1) for k in batches]
+    results = {}
+    errors = []
+
+    def work(tag, model, idx):
+        try:
+            for _ in range(3):
+                results[(tag, idx, "e")] = model.eigenval_array(batches[idx])
+                results[(tag, idx, "h")] = model.hamilton(batches[idx][:50], convention=1)
+        except Exception as exc:  # pylint: disable=broad-except
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=("shared", shared, i)) for i in range(len(batches))]
+    own = [tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos) for _ in range(4)]
+    threads += [threading.Thread(target=work, args=("own", own[i], i)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for (tag, idx, what), got in results.items():
+        ref = expected_e[idx] if what == "e" else expected_h[idx]
+        _close(got, ref, 1e-13)
