@@ -112,6 +112,10 @@ class ShardedEigenval:
         return np.concatenate(pieces, axis=0)[:n_k].copy()
 
     def _device_gather(self, k, start, stop, per, n_k, n_orb):
+        with self.model._call_lock:  # pylint: disable=protected-access  # staged handle stays valid for the whole exchange
+            return self._device_gather_locked(k, start, stop, per, n_k, n_orb)
+
+    def _device_gather_locked(self, k, start, stop, per, n_k, n_orb):
         lib = _lib.lib()
         handle = self.model._staged()  # pylint: disable=protected-access
         comm = self._communicator()
