@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""
+Random shapes against the oracle (GPU box): orbital counts around every kernel boundary, odd batch sizes, 1-4 lattice
+dimensions, dense / sparse storage, both conventions, mesh and random k-points, host and list / array returns.
+
+    python tools/fuzz_parity.py [seconds] [seed]
+
+Prints one line per case that exceeds 1e-10 and a summary; exit status 1 if any case failed.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tbmodels_amd  # noqa: E402
+from tbmodels_amd import synthetic as syn  # noqa: E402
+from oracle import tbk_oracle as oracle  # noqa: E402  (checker)
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+
+N_EDGES = [1, 2, 3, 4, 7, 8, 9, 12, 13, 15, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 66, 80, 96, 127, 128, 129, 150,
+           191, 192, 193, 200, 255, 256, 257, 300, 383, 384, 385]
+NK_EDGES = [1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 500, 1000, 4095, 4096, 4097, 5000, 8193, 12289]
+
+
+def pick_case():
+    n = int(rng.choice(N_EDGES))
+    dim = int(rng.choice([1, 2, 3, 3, 3, 4]))
+    box = {1: 12, 2: 12, 3: 12, 4: 3}[dim]
+    max_r = {1: 13, 2: 313, 3: 3000, 4: 1000}[dim]
+    n_r = int(min(max_r, rng.choice([0, 1, 2, 5, 7, 8, 9, 16, 33, 64, 100, 257, 600])))
+    n_r = int(min(n_r, max(1, 3e7 // (n * n))))  # <= ~0.5 GB of hoppings
+    # keep the oracle's scratch (NK x n x n complex, twice) under ~1.5 GB and its time in seconds
+    nk_cap = max(1, int(1.5e7 / (n * n)))
+    nk = int(min(nk_cap, rng.choice(NK_EDGES)))
+    if n * n * max(n_r, 1) * nk > 1e9:
+        nk = max(1, int(1e9 / (n * n * max(n_r, 1))))
+    sparse = bool(rng.integers(0, 2))
+    mesh = bool(rng.integers(0, 4) == 0) and dim >= 2
+    return dict(n=n, dim=dim, box=box, n_r=n_r, nk=nk, sparse=sparse, mesh=mesh)
+
+
+def build(case):
+    n, dim, n_r = case["n"], case["dim"], case["n_r"]
+    r_vec = syn.half_space_vectors(n_r, dim=dim, box=case["box"]) if n_r else np.zeros((0, dim), dtype=np.int32)
+    scale = float(rng.choice([1e-6, 1.0, 1.0, 1.0, 1e3]))
+    hop = scale * (rng.standard_normal((n_r, n, n)) + 1j * rng.standard_normal((n_r, n, n))) / np.sqrt(max(n_r, 1) * n)
+    if case["sparse"]:
+        hop *= rng.random((n_r, n, n)) < rng.choice([0.02, 0.2, 0.6])
+    if n_r:
+        hop[0] = (hop[0] + hop[0].conj().T) / 4.0
+    pos = rng.random((n, dim))
+    if case["mesh"]:
+        per = max(2, int(round(case["nk"] ** (1.0 / dim))))
+        axes = [np.linspace(0, 1, per, endpoint=False) + rng.random() for _ in range(dim)]
+        k = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, dim)
+    else:
+        k = (rng.random((case["nk"], dim)) - 0.5) * float(rng.choice([1.0, 4.0]))
+    return r_vec, hop, pos, np.ascontiguousarray(k), scale
+
+
+def main():
+    t_end = time.time() + budget
+    n_cases = 0
+    worst = 0.0
+    failures = []
+    while time.time() < t_end:
+        case = pick_case()
+        r_vec, hop, pos, k, scale = build(case)
+        model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=case["sparse"], size=case["n"], dim=case["dim"])
+        tol = 1e-10 * max(1.0, scale)
+        try:
+            e_gpu = np.array(model.eigenval(k)).reshape(len(k), case["n"])
+            e_ref = np.array(oracle.eigenval(r_vec, hop, k, n_orb=case["n"])).reshape(len(k), case["n"])
+            err_e = float(np.abs(e_gpu - e_ref).max())
+            n_h = min(len(k), max(1, int(2e6 / (case["n"] ** 2))))
+            conv = int(rng.choice([1, 2]))
+            h_gpu = model.hamilton(k[:n_h], convention=conv)
+            h_ref = oracle.hamilton(r_vec, hop, k[:n_h], conv, pos=pos, n_orb=case["n"])
+            err_h = float(np.abs(h_gpu - h_ref).max())
+            single = np.abs(model.eigenval(k[0]) - e_ref[0]).max()
+        except Exception as exc:  # pylint: disable=broad-except
+            failures.append((case, repr(exc)))
+            print("EXCEPTION", case, repr(exc), flush=True)
+            continue
+        n_cases += 1
+        rel = max(err_e, err_h, single) / max(1.0, scale)
+        worst = max(worst, rel)
+        if max(err_e, err_h, single) > tol:
+            failures.append((case, err_e, err_h, single))
+            print("FAIL", case, "scale", scale, "eig", err_e, "ham", err_h, "single", single, flush=True)
+    print("cases %d  worst scaled error %.3g  failures %d" % (n_cases, worst, len(failures)))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
