@@ -110,6 +110,10 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
         return TBK_ERR_MEMORY;
     }
     m->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->n_cu = cus;
+    }
     m->dim = dim;
     m->n_orb = n_orb;
     m->n_r = n_r;

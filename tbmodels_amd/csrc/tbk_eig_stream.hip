@@ -462,12 +462,11 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const size_t mat = blockIdx.x;
     double lo_g = 1e300, hi_g = -1e300;
     int bad = 0;
+    double d = 0.0, e = 0.0;
     if (tid < n) {
-        const double d = D[mat * n + tid];
-        const double e = (tid < n - 1) ? E[mat * n + tid] : 0.0;
+        d = D[mat * n + tid];
+        e = (tid < n - 1) ? E[mat * n + tid] : 0.0;
         const double em = (tid > 0) ? E[mat * n + tid - 1] : 0.0;
-        sd[tid] = d;
-        se2[tid] = e * e;
         const double rad = fabs(e) + fabs(em);  // Gershgorin disc
         lo_g = d - rad;
         hi_g = d + rad;
@@ -490,7 +489,22 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         gl = fmin(gl, sred[0][w]);
         gu = fmax(gu, sred[1][w]);
     }
-    const double scale = fmax(fabs(gl), fabs(gu));
+    // Work in units of the spectrum's scale (an exact power of two, undone at the end), with the coupling e_i^2 kept
+    // above 1e-60: a block-diagonal (d, e) -- sparse on-site blocks, decoupled orbitals -- has e_i = 0 exactly, and
+    // at a midpoint that IS an eigenvalue of a leading block (x = 0 for any spectrum symmetric about 0) two
+    // consecutive zeros p_{i-1} = p_i = 0 would zero the whole rest of the recurrence.  With e_i^2 > 0 a zero is
+    // followed by -e_i^2 p_{i-1} != 0; the perturbation of the spectrum is below 1e-30 of its scale.
+    const double scale_raw = fmax(fabs(gl), fabs(gu));
+    const int sc_exp = (scale_raw > 0.0) ? -ilogb(scale_raw) : 0;
+    if (tid < n) {
+        const double es = ldexp(e, sc_exp);
+        sd[tid] = ldexp(d, sc_exp);
+        se2[tid] = fmax(es * es, 1e-60);
+    }
+    __syncthreads();
+    gl = ldexp(gl, sc_exp);
+    gu = ldexp(gu, sc_exp);
+    const double scale = fmax(fabs(gl), fabs(gu));  // in [1, 2), or 0 for the zero matrix
     const double slack = 4.0 * 2.220446049250313e-16 * scale * n + 1e-300;
     double lo = gl - slack, hi = gu + slack;
     const double tol = 2.0 * 2.220446049250313e-16 * scale + 1e-300;
@@ -545,7 +559,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         else
             lo = x;
     }
-    if (tid < n) out[mat * n + tid] = 0.5 * (lo + hi);
+    if (tid < n) out[mat * n + tid] = ldexp(0.5 * (lo + hi), -sc_exp);
 }
 
 template <int NU, int NB, int ST_THREADS>

@@ -28,6 +28,7 @@
 // (k-tile row + column) K step -- FP64-MFMA bound (78.6 TFLOP/s), not HBM bound; see DESIGN.md.
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "tbk_internal.h"
 
@@ -70,6 +71,11 @@ struct HkArgs {
     int64_t a_tile_stride;  // TBK_BM in ordinary launches
     int64_t b_tile_stride;  // 0 in ordinary launches
     int rows_per_tile;      // TBK_BM in ordinary launches
+    // "tail" launches: the tiles of the last, partly filled round of a launch are K-split on their own (launch()
+    // below): this launch covers blocks block_offset + blockIdx.x of the walk, and in a split launch with
+    // p_tiles > 0 the partial tile of block b goes to the compact P[split][b - block_offset][128][64] (re, im)
+    int block_offset;
+    int p_tiles;
 };
 
 // One finished element of the packed tile -> H[k][i][j] (and H[k][j][i] conjugated in FULL mode), with the
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     int mt_idx, nt_idx;
-    if (!tile_of_block(a, blockIdx.x, mt_idx, nt_idx)) return;
+    if (!tile_of_block(a, (int)blockIdx.x + a.block_offset, mt_idx, nt_idx)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -225,7 +231,11 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                 const int64_t kq = m0 + local;
                 if (local >= a.rows_per_tile || kq >= a.nk) continue;
                 if (SPLIT) {
-                    double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kq) * a.ncol_pad + e) * 2;
+                    double* part =
+                        a.p_tiles > 0
+                            ? a.P + ((((size_t)blockIdx.y * a.p_tiles + blockIdx.x) * TBK_BM + local) * TBK_BNP +
+                                     (wn * 2 + j) * 16 + l15) * 2
+                            : a.P + (((size_t)blockIdx.y * a.p_rows + kq) * a.ncol_pad + e) * 2;
                     *reinterpret_cast<d2*>(part) = (d2){acc[i][j][0][r], acc[i][j][1][r]};
                 } else {
                     store_element<MODE, CONV>(a, kq, oi, oj, acc[i][j][0][r], acc[i][j][1][r]);
@@ -288,6 +298,29 @@ __global__ void __launch_bounds__(256) hk_finish_kernel(const HkArgs a) {
     store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
 }
 
+// The same for a tail launch: one workgroup per tail tile, partial tiles in the compact layout.
+template <int MODE, int CONV>
+__global__ void __launch_bounds__(256) hk_finish_tiles_kernel(const HkArgs a) {
+    int mt_idx, nt_idx;
+    if (!tile_of_block(a, (int)blockIdx.x + a.block_offset, mt_idx, nt_idx)) return;
+    const int el = threadIdx.x & (TBK_BNP - 1);
+    const int e = nt_idx * TBK_BNP + el;
+    const int32_t ij = a.colmap[e];
+    if (ij < 0) return;
+    for (int local = threadIdx.x / TBK_BNP; local < a.rows_per_tile; local += 256 / TBK_BNP) {
+        const int64_t kq = (int64_t)mt_idx * a.rows_per_tile + local;
+        if (kq >= a.nk) break;
+        double re = 0.0, im = 0.0;
+        for (int sp = 0; sp < a.splits; ++sp) {
+            const d2 v = *reinterpret_cast<const d2*>(
+                a.P + ((((size_t)sp * a.p_tiles + blockIdx.x) * TBK_BM + local) * TBK_BNP + el) * 2);
+            re += v[0];
+            im += v[1];
+        }
+        store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
+    }
+}
+
 template <int MODE, int CONV>
 hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
     const dim3 grid((unsigned)((a.ncol_pad + 255) / 256), (unsigned)a.splits);
@@ -310,9 +343,73 @@ hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Launches of a few rounds end on a ragged one (4096 k-points at N_orb = 64: 1056 tiles = 2.06 rounds of 512
+// workgroup slots take the time of 3; measured 1.26 us per k-point against 0.99 for long launches).  The blocks of
+// the last, partly filled round are therefore K-split among all slots: whole rounds in one ordinary launch, the
+// tail as a split launch over (tail blocks) x (slots / tail blocks) and a per-tile finish in fixed split order.
+// Above TAIL_MAX_ROUNDS the ragged round stops mattering (no difference measured at 16.5 vs 15.98 rounds).
+constexpr int TAIL_MAX_ROUNDS = 12;
+
 template <int MODE, int CONV>
-hipError_t launch(const HkArgs& a, int grid, hipStream_t s) {
+hipError_t launch_plain(const HkArgs& a, int grid, hipStream_t s);
+
+static int tail_split_rounds() {
+    static const int rounds = [] {
+        const char* v = getenv("TBK_HK_TAIL_SPLIT");  // measurements only: "0" switches it off, N sets the limit
+        return v ? atoi(v) : TAIL_MAX_ROUNDS;
+    }();
+    return rounds;
+}
+
+template <int MODE, int CONV>
+int launch(tbk_model* m, const HkArgs& a, int grid) {
+    hipStream_t s = m->stream;
     const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
+    static bool raised[TBK_MAX_DEVICES] = {};
+    static bool raised_split[TBK_MAX_DEVICES] = {};
+    const int slots = 2 * m->n_cu;  // __launch_bounds__(256, 2) and 72 KiB of LDS: two workgroups per CU
+    const int n_stage = (int)(a.k2 / TBK_BK);
+    const int full = grid / slots * slots, tail = grid - full;
+    if (a.splits == 1 && full > 0 && grid < tail_split_rounds() * slots && tail > 0 && n_stage >= 16) {
+        // Time of u equal workgroups in units of a full round of two per CU: one alone on its CU runs at 1.06 ms per
+        // tile against 1.97 ms for each of two sharing it, so up to n_cu workgroups cost 0.54.  The tail is split
+        // s ways when ceil-rounds(tail * s) / s, plus ~1 % of a round per split for the partial tiles, is shortest.
+        auto rounds = [&](int u) { return u <= slots / 2 ? 0.54 : (double)((u + slots - 1) / slots); };
+        int splits = 1;
+        double best = 0.9 * rounds(tail);
+        for (int sp = 2; sp <= std::min(64, n_stage / 4); ++sp) {
+            const double cost = rounds(tail * sp) / sp + 0.01 * sp;
+            if (cost < best) {
+                best = cost;
+                splits = sp;
+            }
+        }
+        if (splits >= 2) {
+            TBK_CHECK(m->ws_part.reserve((size_t)splits * tail * TBK_BM * TBK_BNP * 2 * sizeof(double)));
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised));
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds,
+                                        raised_split));
+            hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, false>), dim3(full), dim3(256), lds, s, a);
+            TBK_HIP(hipGetLastError());
+            HkArgs t = a;
+            t.block_offset = a.block_offset + full;
+            t.P = m->ws_part.as<double>();
+            t.splits = splits;
+            t.p_tiles = tail;
+            hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(tail, splits), dim3(256), lds, s, t);
+            TBK_HIP(hipGetLastError());
+            hipLaunchKernelGGL((hk_finish_tiles_kernel<MODE, CONV>), dim3(tail), dim3(256), 0, s, t);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
+    }
+    TBK_HIP((launch_plain<MODE, CONV>(a, grid, s)));
+    return TBK_OK;
+}
+
+template <int MODE, int CONV>
+hipError_t launch_plain(const HkArgs& a, int grid, hipStream_t s) {
+    const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);
     static bool raised[TBK_MAX_DEVICES] = {};
     static bool raised_split[TBK_MAX_DEVICES] = {};
     if (a.splits > 1) {
@@ -367,6 +464,8 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.a_tile_stride = TBK_BM;
     a.b_tile_stride = 0;
     a.rows_per_tile = TBK_BM;
+    a.block_offset = 0;
+    a.p_tiles = 0;
     if (nk <= 32 && m->k2 > 0) {
         // matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
         const int col_blocks = (a.ncol_pad + 255) / 256;
@@ -395,7 +494,7 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     // k-points 2137 -> 1340 us).  The operands are still read once.
     const int n_stage = (int)(m->k2 / TBK_BK);
     const int tiles = a.mt_count * a.nt_count;
-    if (tiles < 768 && n_stage >= 16) {
+    if (tiles < 2 * m->n_cu && n_stage >= 16) {
         int splits = std::min((1280 + tiles / 2) / tiles, n_stage / 4);
         const size_t per_split = (size_t)nk_pad * a.ncol_pad * 2 * sizeof(double);
         splits = (int)std::min<size_t>((size_t)splits, (size_t(256) << 20) / per_split);
@@ -408,11 +507,11 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     }
     StageTimer t(m, TBK_T_HK);
     if (mode == HK_TRI) {
-        TBK_HIP((launch<HK_TRI, 2>(a, grid, m->stream)));
+        TBK_CHECK((launch<HK_TRI, 2>(m, a, grid)));
     } else if (convention == 1) {
-        TBK_HIP((launch<HK_FULL, 1>(a, grid, m->stream)));
+        TBK_CHECK((launch<HK_FULL, 1>(m, a, grid)));
     } else {
-        TBK_HIP((launch<HK_FULL, 2>(a, grid, m->stream)));
+        TBK_CHECK((launch<HK_FULL, 2>(m, a, grid)));
     }
     return TBK_OK;
 }
@@ -446,6 +545,8 @@ int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, 
     a.a_tile_stride = 0;
     a.b_tile_stride = b_stride;
     a.rows_per_tile = line_len;
+    a.block_offset = 0;
+    a.p_tiles = 0;
     int grid;
     if (a.mt_count >= 32) {
         a.xcd_rows = 4;
@@ -455,6 +556,6 @@ int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, 
         grid = a.mt_count * a.nt_count;
     }
     StageTimer t(m, TBK_T_HK);
-    TBK_HIP((launch<HK_TRI, 2>(a, grid, m->stream)));
+    TBK_CHECK((launch<HK_TRI, 2>(m, a, grid)));
     return TBK_OK;
 }

@@ -502,3 +502,21 @@ def test_threads_sharing_one_model_and_threads_with_their_own():
     for (tag, idx, what), got in results.items():
         ref = expected_e[idx] if what == "e" else expected_h[idx]
         _close(got, ref, 1e-13)
+
+
+@pytest.mark.parametrize("n", [5, 13, 16, 17, 24, 32, 33, 64, 65, 100])
+def test_block_diagonal_spectra_symmetric_about_zero(n):
+    """Very sparse on-site blocks: the tridiagonal form is block diagonal (e_i = 0 exactly), most eigenvalues are
+    exactly 0 and the rest come in +/- pairs, so the first bisection midpoint IS an eigenvalue.  The polynomial
+    Sturm recurrence once zeroed out behind two consecutive zeros there (every positive eigenvalue came back as 0);
+    found by tools/fuzz_parity.py."""
+    rng = np.random.default_rng(1000 + n)
+    for fill in (0.02, 0.05, 0.2):
+        for _ in range(6):
+            mat = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * (rng.random((n, n)) < fill)
+            mat = (mat + mat.conj().T) / 2
+            model = tbmodels_amd.Model(hop={(0,): mat / 2}, size=n, dim=1, contains_cc=False)
+            ref = np.linalg.eigvalsh(mat)
+            for n_k in (1, 3, 4200):  # bisection for small calls, QL + bisection for the chunked pipeline
+                got = model.eigenval_array(rng.random((n_k, 1)))
+                _close(got, np.broadcast_to(ref, got.shape))
