@@ -41,15 +41,34 @@ def pick_case():
         nk = max(1, int(1e9 / (n * n * max(n_r, 1))))
     sparse = bool(rng.integers(0, 2))
     mesh = bool(rng.integers(0, 4) == 0) and dim >= 2
-    return dict(n=n, dim=dim, box=box, n_r=n_r, nk=nk, sparse=sparse, mesh=mesh)
+    # exact zeros, exact degeneracies and exact cancellations: small-integer / real / diagonal hoppings, and
+    # k-points on multiples of 1/4 (phases exactly 0, +-1, +-i)
+    kind = str(rng.choice(["random", "random", "integers", "real", "diagonal", "permutation"]))
+    special_k = bool(rng.integers(0, 3) == 0)
+    return dict(n=n, dim=dim, box=box, n_r=n_r, nk=nk, sparse=sparse, mesh=mesh, kind=kind, special_k=special_k)
 
 
 def build(case):
     n, dim, n_r = case["n"], case["dim"], case["n_r"]
     r_vec = syn.half_space_vectors(n_r, dim=dim, box=case["box"]) if n_r else np.zeros((0, dim), dtype=np.int32)
     scale = float(rng.choice([1e-6, 1.0, 1.0, 1.0, 1e3]))
-    hop = scale * (rng.standard_normal((n_r, n, n)) + 1j * rng.standard_normal((n_r, n, n))) / np.sqrt(max(n_r, 1) * n)
-    if case["sparse"]:
+    kind = case["kind"]
+    if kind == "integers":
+        hop = scale * (rng.integers(-2, 3, (n_r, n, n)) + 1j * rng.integers(-2, 3, (n_r, n, n))).astype(complex)
+        hop *= rng.random((n_r, n, n)) < rng.choice([0.02, 0.1, 0.5])
+    elif kind == "real":
+        hop = scale * rng.standard_normal((n_r, n, n)).astype(complex) / np.sqrt(max(n_r, 1) * n)
+    elif kind == "diagonal":
+        hop = np.zeros((n_r, n, n), dtype=complex)
+        idx = np.arange(n)
+        hop[:, idx, idx] = scale * rng.integers(-3, 4, (n_r, n))
+    elif kind == "permutation":
+        hop = np.zeros((n_r, n, n), dtype=complex)
+        for r in range(n_r):
+            hop[r, np.arange(n), rng.permutation(n)] = scale * rng.choice([1.0, -1.0, 1j, 0.5])
+    else:
+        hop = scale * (rng.standard_normal((n_r, n, n)) + 1j * rng.standard_normal((n_r, n, n))) / np.sqrt(max(n_r, 1) * n)
+    if case["sparse"] and kind in ("random", "real"):
         hop *= rng.random((n_r, n, n)) < rng.choice([0.02, 0.2, 0.6])
     if n_r:
         hop[0] = (hop[0] + hop[0].conj().T) / 4.0
@@ -60,6 +79,8 @@ def build(case):
         k = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, dim)
     else:
         k = (rng.random((case["nk"], dim)) - 0.5) * float(rng.choice([1.0, 4.0]))
+    if case["special_k"]:
+        k = np.round(k * 4) / 4
     return r_vec, hop, pos, np.ascontiguousarray(k), scale
 
 
@@ -72,7 +93,8 @@ def main():
         case = pick_case()
         r_vec, hop, pos, k, scale = build(case)
         model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=case["sparse"], size=case["n"], dim=case["dim"])
-        tol = 1e-10 * max(1.0, scale)
+        norm = float(np.abs(hop).sum(axis=(0, 2)).max()) if hop.size else 0.0  # bound on ||H||_inf / 2
+        tol = 1e-10 * max(1.0, scale, norm)
         try:
             e_gpu = np.array(model.eigenval(k)).reshape(len(k), case["n"])
             e_ref = np.array(oracle.eigenval(r_vec, hop, k, n_orb=case["n"])).reshape(len(k), case["n"])
@@ -88,7 +110,7 @@ def main():
             print("EXCEPTION", case, repr(exc), flush=True)
             continue
         n_cases += 1
-        rel = max(err_e, err_h, single) / max(1.0, scale)
+        rel = max(err_e, err_h, single) / max(1.0, scale, norm)
         worst = max(worst, rel)
         if max(err_e, err_h, single) > tol:
             failures.append((case, err_e, err_h, single))
