@@ -84,12 +84,57 @@ def build(case):
     return r_vec, hop, pos, np.ascontiguousarray(k), scale
 
 
+def kdotp_case():
+    """A random k.p model (and the k.p expansion of a random tight-binding model) against the oracle."""
+    import itertools  # pylint: disable=import-outside-toplevel
+
+    from tbmodels_amd.kdotp import KdotpModel  # pylint: disable=import-outside-toplevel
+
+    n = int(rng.choice([1, 2, 4, 8, 17, 33, 64, 70]))
+    dim = int(rng.choice([1, 2, 3]))
+    order = int(rng.choice([0, 1, 2, 3]))
+    powers = [p for p in itertools.product(range(order + 1), repeat=dim) if sum(p) <= order]
+    if len(powers) > 3 and rng.integers(0, 2):
+        powers = [powers[i] for i in sorted(rng.choice(len(powers), size=len(powers) // 2, replace=False))]
+    coeffs = rng.standard_normal((len(powers), n, n)) + 1j * rng.standard_normal((len(powers), n, n))
+    coeffs = coeffs + coeffs.conj().transpose(0, 2, 1)
+    nk = int(rng.choice([1, 2, 33, 500, 5000]))
+    k = (rng.random((nk, dim)) - 0.5) * float(rng.choice([0.1, 1.0, 3.0]))
+    model = KdotpModel({p: c for p, c in zip(powers, coeffs)})
+    pw = np.array(powers, dtype=np.int64).reshape(len(powers), dim)
+    h_ref = oracle.kdotp_hamilton(pw, coeffs, k)
+    e_ref = np.array(oracle.kdotp_eigenval(pw, coeffs, k))
+    size = max(1.0, float(np.abs(h_ref).sum(axis=-1).max()))
+    err = max(float(np.abs(model.hamilton(k) - h_ref).max()), float(np.abs(np.array(model.eigenval(k)) - e_ref).max()),
+              float(np.abs(model.eigenval(k[0]) - e_ref[0]).max()))
+    # construct_kdotp of a tight-binding model, dense and sparse
+    n_r = int(rng.choice([1, 3, 20])) if dim > 1 else int(rng.choice([1, 3, 4]))
+    r_vec = syn.half_space_vectors(n_r, dim=dim, box=3)
+    hop = rng.standard_normal((n_r, n, n)) + 1j * rng.standard_normal((n_r, n, n))
+    hop[0] = (hop[0] + hop[0].conj().T) / 4
+    k0 = rng.random(dim)
+    tb = tbmodels_amd.Model.from_packed(r_vec, hop, sparse=bool(rng.integers(0, 2)), size=n, dim=dim)
+    got = tb.construct_kdotp(k0, order)
+    pw2, cf2 = oracle.construct_kdotp(r_vec, hop, k0, order)
+    scale2 = max(1.0, float(np.abs(cf2).max()))
+    err2 = max(float(np.abs(got.taylor_coefficients[tuple(int(x) for x in p)] - c).max()) for p, c in zip(pw2, cf2))
+    return dict(kdotp=True, n=n, dim=dim, order=order, nk=nk, n_r=n_r), err / size, err2 / scale2
+
+
 def main():
     t_end = time.time() + budget
     n_cases = 0
     worst = 0.0
     failures = []
     while time.time() < t_end:
+        if rng.integers(0, 6) == 0:
+            case, err_a, err_b = kdotp_case()
+            n_cases += 1
+            worst = max(worst, err_a, err_b)
+            if max(err_a, err_b) > 1e-10:
+                failures.append((case, err_a, err_b))
+                print("FAIL", case, err_a, err_b, flush=True)
+            continue
         case = pick_case()
         r_vec, hop, pos, k, scale = build(case)
         model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=case["sparse"], size=case["n"], dim=case["dim"])
