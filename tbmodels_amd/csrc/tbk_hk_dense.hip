@@ -61,21 +61,26 @@ struct HkArgs {
     int mt_count;  // k tiles
     int nt_count;  // element tiles
     int xcd_rows;  // 0: plain order; > 0: k tiles per XCD super-row
-    // split-K (small k batches): blockIdx.y owns a contiguous range of K stages and stores its partial tile to
-    // P[split][k][e] (re, im) instead of scattering it; hk_finish_kernel adds the partials in fixed order
+    // split-K (small k batches): the launch covers `splits * unit_grid` units, unit u = split y = u / unit_grid of
+    // block b = u % unit_grid of the tile walk; a unit owns a contiguous range of K stages and stores its partial tile
+    // to P[y][k][e] (re, im) instead of scattering it; hk_finish_kernel adds the partials in fixed order
     double* P;
     int splits;
+    int unit_grid;
     int64_t p_rows;  // k rows per split in P
     // "lines" launches (second-level fold, tbk_fold.hip): k tile t is one mesh line -- its own operand at
     // Bt + t * b_tile_stride, the SAME phase rows for every line (a_tile_stride = 0), rows_per_tile k-points of output
     int64_t a_tile_stride;  // TBK_BM in ordinary launches
     int64_t b_tile_stride;  // 0 in ordinary launches
     int rows_per_tile;      // TBK_BM in ordinary launches
-    // "tail" launches: the tiles of the last, partly filled round of a launch are K-split on their own (launch()
-    // below): this launch covers blocks block_offset + blockIdx.x of the walk, and in a split launch with
-    // p_tiles > 0 the partial tile of block b goes to the compact P[split][b - block_offset][128][64] (re, im)
+    // "tail" launches: the units of the last, partly filled round of a launch are split along K once more (launch()
+    // below): this launch covers units block_offset + blockIdx.x, blockIdx.y < sub_splits takes a part of the unit's
+    // stage range, and the partial tile goes to the compact P2[blockIdx.y][blockIdx.x][128][64] (re, im);
+    // hk_finish_tiles_kernel adds them in order into H (splits == 1) or into the unit's P[y] (splits > 1)
     int block_offset;
-    int p_tiles;
+    int p_tiles;  // > 0: a tail launch of that many units
+    int sub_splits;
+    double* P2;
 };
 
 // One finished element of the packed tile -> H[k][i][j] (and H[k][j][i] conjugated in FULL mode), with the
@@ -133,8 +138,10 @@ template <int MODE, int CONV, bool SPLIT>
 __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
+    const int unit = (int)blockIdx.x + a.block_offset;
+    const int split_y = SPLIT ? unit / a.unit_grid : 0;
     int mt_idx, nt_idx;
-    if (!tile_of_block(a, (int)blockIdx.x + a.block_offset, mt_idx, nt_idx)) return;
+    if (!tile_of_block(a, SPLIT ? unit - split_y * a.unit_grid : unit, mt_idx, nt_idx)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,8 +171,13 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
     int s_begin = 0, n_stage = (int)(a.k2 / TBK_BK);
     if (SPLIT) {
         const int per = (n_stage + a.splits - 1) / a.splits;
-        s_begin = min((int)blockIdx.y * per, n_stage);
+        s_begin = min(split_y * per, n_stage);
         n_stage = min(s_begin + per, n_stage);
+        if (a.p_tiles > 0) {
+            const int per2 = (n_stage - s_begin + a.sub_splits - 1) / a.sub_splits;
+            s_begin = min(s_begin + (int)blockIdx.y * per2, n_stage);
+            n_stage = min(s_begin + per2, n_stage);
+        }
     }
 
     // global -> LDS without a register round trip (global_load_lds_dwordx4): every wave-instruction
@@ -233,9 +245,9 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                 if (SPLIT) {
                     double* part =
                         a.p_tiles > 0
-                            ? a.P + ((((size_t)blockIdx.y * a.p_tiles + blockIdx.x) * TBK_BM + local) * TBK_BNP +
-                                     (wn * 2 + j) * 16 + l15) * 2
-                            : a.P + (((size_t)blockIdx.y * a.p_rows + kq) * a.ncol_pad + e) * 2;
+                            ? a.P2 + ((((size_t)blockIdx.y * a.p_tiles + blockIdx.x) * TBK_BM + local) * TBK_BNP +
+                                      (wn * 2 + j) * 16 + l15) * 2
+                            : a.P + (((size_t)split_y * a.p_rows + kq) * a.ncol_pad + e) * 2;
                     *reinterpret_cast<d2*>(part) = (d2){acc[i][j][0][r], acc[i][j][1][r]};
                 } else {
                     store_element<MODE, CONV>(a, kq, oi, oj, acc[i][j][0][r], acc[i][j][1][r]);
@@ -298,11 +310,14 @@ __global__ void __launch_bounds__(256) hk_finish_kernel(const HkArgs a) {
     store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
 }
 
-// The same for a tail launch: one workgroup per tail tile, partial tiles in the compact layout.
+// Tail launches: one workgroup per tail unit adds its sub-split partial tiles in order and either finishes the
+// element (the launch was not split otherwise) or hands the sum to the unit's slot of P for hk_finish_kernel.
 template <int MODE, int CONV>
 __global__ void __launch_bounds__(256) hk_finish_tiles_kernel(const HkArgs a) {
+    const int unit = (int)blockIdx.x + a.block_offset;
+    const int split_y = unit / a.unit_grid;
     int mt_idx, nt_idx;
-    if (!tile_of_block(a, (int)blockIdx.x + a.block_offset, mt_idx, nt_idx)) return;
+    if (!tile_of_block(a, unit - split_y * a.unit_grid, mt_idx, nt_idx)) return;
     const int el = threadIdx.x & (TBK_BNP - 1);
     const int e = nt_idx * TBK_BNP + el;
     const int32_t ij = a.colmap[e];
@@ -311,13 +326,16 @@ __global__ void __launch_bounds__(256) hk_finish_tiles_kernel(const HkArgs a) {
         const int64_t kq = (int64_t)mt_idx * a.rows_per_tile + local;
         if (kq >= a.nk) break;
         double re = 0.0, im = 0.0;
-        for (int sp = 0; sp < a.splits; ++sp) {
+        for (int sp = 0; sp < a.sub_splits; ++sp) {
             const d2 v = *reinterpret_cast<const d2*>(
-                a.P + ((((size_t)sp * a.p_tiles + blockIdx.x) * TBK_BM + local) * TBK_BNP + el) * 2);
+                a.P2 + ((((size_t)sp * a.p_tiles + blockIdx.x) * TBK_BM + local) * TBK_BNP + el) * 2);
             re += v[0];
             im += v[1];
         }
-        store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
+        if (a.splits > 1)
+            *reinterpret_cast<d2*>(a.P + (((size_t)split_y * a.p_rows + kq) * a.ncol_pad + e) * 2) = (d2){re, im};
+        else
+            store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
     }
 }
 
@@ -344,14 +362,12 @@ hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
 }
 
 // Launches of a few rounds end on a ragged one (4096 k-points at N_orb = 64: 1056 tiles = 2.06 rounds of 512
-// workgroup slots take the time of 3; measured 1.26 us per k-point against 0.99 for long launches).  The blocks of
-// the last, partly filled round are therefore K-split among all slots: whole rounds in one ordinary launch, the
-// tail as a split launch over (tail blocks) x (slots / tail blocks) and a per-tile finish in fixed split order.
-// Above TAIL_MAX_ROUNDS the ragged round stops mattering (no difference measured at 16.5 vs 15.98 rounds).
+// workgroup slots take the time of 3; measured 1.26 us per k-point against 0.99 for long launches), split launches
+// likewise (1024 k-points: 264 tiles x 5 splits = 2.6 rounds).  The units (block x split) of the last, partly filled
+// round are therefore split along K once more among all slots: whole rounds in one ordinary launch, the tail as a
+// (tail units) x (sub-splits) launch and a per-unit finish in fixed order.  Above TAIL_MAX_ROUNDS the ragged round
+// stops mattering (no difference measured at 16.5 vs 15.98 rounds: the chip is power-limited there).
 constexpr int TAIL_MAX_ROUNDS = 12;
-
-template <int MODE, int CONV>
-hipError_t launch_plain(const HkArgs& a, int grid, hipStream_t s);
 
 static int tail_split_rounds() {
     static const int rounds = [] {
@@ -361,72 +377,70 @@ static int tail_split_rounds() {
     return rounds;
 }
 
+// `a.splits` >= 1 with a.P / a.p_rows set by the caller when > 1; `grid` blocks of the tile walk.
 template <int MODE, int CONV>
-int launch(tbk_model* m, const HkArgs& a, int grid) {
+int launch(tbk_model* m, const HkArgs& a0, int grid) {
     hipStream_t s = m->stream;
     const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
     static bool raised[TBK_MAX_DEVICES] = {};
     static bool raised_split[TBK_MAX_DEVICES] = {};
+    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised));
+    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds, raised_split));
+    HkArgs a = a0;
+    a.unit_grid = grid;
     const int slots = 2 * m->n_cu;  // __launch_bounds__(256, 2) and 72 KiB of LDS: two workgroups per CU
     const int n_stage = (int)(a.k2 / TBK_BK);
-    const int full = grid / slots * slots, tail = grid - full;
-    if (a.splits == 1 && full > 0 && grid < tail_split_rounds() * slots && tail > 0 && n_stage >= 16) {
-        // Time of u equal workgroups in units of a full round of two per CU: one alone on its CU runs at 1.06 ms per
-        // tile against 1.97 ms for each of two sharing it, so up to n_cu workgroups cost 0.54.  The tail is split
-        // s ways when ceil-rounds(tail * s) / s, plus ~1 % of a round per split for the partial tiles, is shortest.
+    const int units = grid * a.splits;
+    const int full = units / slots * slots, tail = units - full;
+    const int unit_stages = (n_stage + a.splits - 1) / a.splits;
+    int sub = 1;
+    if (full > 0 && tail > 0 && units < tail_split_rounds() * slots && unit_stages >= 8) {
+        // Time of u equal workgroups in rounds of two per CU: one alone on its CU runs at 1.06 ms per tile against
+        // 1.97 ms for each of two sharing it, so up to n_cu workgroups cost 0.54.  Sub-splitting the tail s ways
+        // costs rounds(tail * s) / s plus the partial tiles (~90 ns per tile and sub-split) and three launches.
         auto rounds = [&](int u) { return u <= slots / 2 ? 0.54 : (double)((u + slots - 1) / slots); };
-        int splits = 1;
-        double best = 0.9 * rounds(tail);
-        for (int sp = 2; sp <= std::min(64, n_stage / 4); ++sp) {
-            const double cost = rounds(tail * sp) / sp + 0.01 * sp;
+        const double round_ms = 1.97 * unit_stages / 512.0;
+        const double plain = rounds(tail) * round_ms;
+        double best = std::min(0.9 * plain, plain - 0.03);
+        for (int sp = 2; sp <= std::min(64, unit_stages / 4); ++sp) {
+            const double cost = rounds(tail * sp) / sp * round_ms + sp * tail * 9e-5 + 0.01;
             if (cost < best) {
                 best = cost;
-                splits = sp;
+                sub = sp;
             }
         }
-        if (splits >= 2) {
-            TBK_CHECK(m->ws_part.reserve((size_t)splits * tail * TBK_BM * TBK_BNP * 2 * sizeof(double)));
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised));
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds,
-                                        raised_split));
-            hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, false>), dim3(full), dim3(256), lds, s, a);
-            TBK_HIP(hipGetLastError());
-            HkArgs t = a;
-            t.block_offset = a.block_offset + full;
-            t.P = m->ws_part.as<double>();
-            t.splits = splits;
-            t.p_tiles = tail;
-            hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(tail, splits), dim3(256), lds, s, t);
-            TBK_HIP(hipGetLastError());
-            hipLaunchKernelGGL((hk_finish_tiles_kernel<MODE, CONV>), dim3(tail), dim3(256), 0, s, t);
-            TBK_HIP(hipGetLastError());
-            return TBK_OK;
-        }
     }
-    TBK_HIP((launch_plain<MODE, CONV>(a, grid, s)));
-    return TBK_OK;
-}
-
-template <int MODE, int CONV>
-hipError_t launch_plain(const HkArgs& a, int grid, hipStream_t s) {
-    const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);
-    static bool raised[TBK_MAX_DEVICES] = {};
-    static bool raised_split[TBK_MAX_DEVICES] = {};
+    const size_t base_bytes = a.splits > 1 ? (size_t)a.splits * a.p_rows * a.ncol_pad * 2 * sizeof(double) : 0;
+    if (sub >= 2) {
+        TBK_CHECK(m->ws_part.reserve(base_bytes + (size_t)sub * tail * TBK_BM * TBK_BNP * 2 * sizeof(double)));
+        a.P = a.splits > 1 ? m->ws_part.as<double>() : nullptr;
+        if (a.splits > 1)
+            hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(full), dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, false>), dim3(full), dim3(256), lds, s, a);
+        TBK_HIP(hipGetLastError());
+        HkArgs t = a;
+        t.block_offset = full;
+        t.p_tiles = tail;
+        t.sub_splits = sub;
+        t.P2 = reinterpret_cast<double*>(m->ws_part.as<char>() + base_bytes);
+        hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(tail, sub), dim3(256), lds, s, t);
+        TBK_HIP(hipGetLastError());
+        hipLaunchKernelGGL((hk_finish_tiles_kernel<MODE, CONV>), dim3(tail), dim3(256), 0, s, t);
+        TBK_HIP(hipGetLastError());
+    } else if (a.splits > 1) {
+        hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(units), dim3(256), lds, s, a);
+        TBK_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, false>), dim3(grid), dim3(256), lds, s, a);
+        TBK_HIP(hipGetLastError());
+    }
     if (a.splits > 1) {
-        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds,
-                                           raised_split);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, true>), dim3(grid, a.splits), dim3(256), lds, s, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
         const int64_t threads = a.nk * a.ncol_pad;
         hipLaunchKernelGGL((hk_finish_kernel<MODE, CONV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
-        return hipGetLastError();
+        TBK_HIP(hipGetLastError());
     }
-    hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((hk_dense_kernel<MODE, CONV, false>), dim3(grid), dim3(256), lds, s, a);
-    return hipGetLastError();
+    return TBK_OK;
 }
 
 }  // namespace
@@ -466,6 +480,9 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.rows_per_tile = TBK_BM;
     a.block_offset = 0;
     a.p_tiles = 0;
+    a.sub_splits = 1;
+    a.P2 = nullptr;
+    a.unit_grid = 1;
     if (nk <= 32 && m->k2 > 0) {
         // matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
         const int col_blocks = (a.ncol_pad + 255) / 256;
@@ -489,15 +506,17 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
         return TBK_OK;
     }
     // Small k batches: a workgroup's K loop is a serial chain (1.06 ms at N_R = 4096 whatever the batch), and fewer
-    // than ~512 workgroups leave CUs idle or end on a ragged round -- split K across blockIdx.y so that the launch
-    // fills the chip (~1280 workgroups; measured at N_orb = 64, N_R = 4096: one k-point 1056 -> 163 us, 1000
-    // k-points 2137 -> 1340 us).  The operands are still read once.
+    // tiles than workgroup slots leave CUs idle -- split K into ~1280 units (block x split) so that the launch fills
+    // the chip for two to three rounds; launch() cuts the ragged last round once more.  Partial tiles go to a
+    // workspace, hk_finish_kernel adds them in fixed order.  Measured at N_orb = 64, N_R = 4096: one k-point
+    // 1056 -> 163 us (before the matrix-vector path), 1000 k-points 2137 -> 1264 us.  (Just enough splits for ONE
+    // full round plus a sub-split tail was slower up to 500 k-points: three more launches on a 0.2 ms kernel.)
     const int n_stage = (int)(m->k2 / TBK_BK);
     const int tiles = a.mt_count * a.nt_count;
     if (tiles < 2 * m->n_cu && n_stage >= 16) {
         int splits = std::min((1280 + tiles / 2) / tiles, n_stage / 4);
         const size_t per_split = (size_t)nk_pad * a.ncol_pad * 2 * sizeof(double);
-        splits = (int)std::min<size_t>((size_t)splits, (size_t(256) << 20) / per_split);
+        splits = (int)std::min<size_t>((size_t)splits, (size_t(512) << 20) / per_split);
         if (splits > 1) {
             TBK_CHECK(m->ws_part.reserve(per_split * splits));
             a.P = m->ws_part.as<double>();
@@ -547,6 +566,9 @@ int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, 
     a.rows_per_tile = line_len;
     a.block_offset = 0;
     a.p_tiles = 0;
+    a.sub_splits = 1;
+    a.P2 = nullptr;
+    a.unit_grid = 1;
     int grid;
     if (a.mt_count >= 32) {
         a.xcd_rows = 4;
