@@ -25,7 +25,7 @@ import zlib
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _outbuf
 from ._sparse_matrix import csr as _csr
 
 try:  # fast content hash for the staging fingerprint; zlib is the fallback
@@ -607,7 +607,7 @@ class Model:
             )
         k_array, single = self._k_array(k)
         n_k = k_array.shape[0]
-        out = np.empty((n_k, self.size, self.size), dtype=np.complex128)
+        out = _outbuf.empty((n_k, self.size, self.size), np.complex128)
         pos = np.ascontiguousarray(self.pos, dtype=np.float64) if convention == 1 else None
         with self._call_lock:  # (re)staging and the call are one step for other threads (ctypes drops the GIL)
             _lib.check(
@@ -634,7 +634,7 @@ class Model:
             # scipy.linalg.eigvalsh(check_finite=True) on the NaN Hamiltonian
             raise ValueError("array must not contain infs or NaNs")
         n_k = k_array.shape[0]
-        out = np.empty((n_k, self.size), dtype=np.float64)
+        out = _outbuf.empty((n_k, self.size), np.float64)
         with self._call_lock:
             _lib.check(_lib.lib().tbk_eigenval(self._staged(), _lib.ptr(k_array), n_k, _lib.ptr(out)))
         if not np.isfinite(out).all():

@@ -177,6 +177,7 @@ struct tbk_model {
     hipStream_t stream_ql = nullptr;   // wave eigensolver: tridiagonal QL (latency-bound, overlaps the rest)
     hipEvent_t ev_hk[2] = {nullptr, nullptr};   // H[buf] written
     hipEvent_t ev_tri[2] = {nullptr, nullptr};  // H[buf] consumed, (d, e)[buf] written
+    hipEvent_t ev_out[2] = {nullptr, nullptr};  // tbk_hamilton: chunk in ws_out / ws_out2 computed
     hipEvent_t ev_ql[2] = {nullptr, nullptr};   // (d, e)[buf] consumed, eigenvalues written
     rocblas_handle blas = nullptr;
     DevBuf ws_phase;  // [K2][nk_pad] cos/sin rows
@@ -189,6 +190,7 @@ struct tbk_model {
     DevBuf ws_pos;
     DevBuf ws_orb;    // convention 1: orbital phase table of the current chunk
     DevBuf ws_out;
+    DevBuf ws_out2;  // second device buffer of the chunked H(k) download (tbk_hamilton)
     DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
     DevBuf ws_part;   // split-K partial tiles of the dense H(k) kernel (small k batches)
     DevBuf ws_kfold;  // k-points of a folded run without the folded component

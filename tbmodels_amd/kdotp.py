@@ -12,7 +12,7 @@ import threading
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _outbuf
 
 __all__ = ("KdotpModel",)
 
@@ -93,7 +93,7 @@ class KdotpModel:
         """H(k) at one k-point or a list of k-points (``kdotp.py:51-82``)."""
         k_array, single = self._k_array(k)
         _, size = self._shape()
-        out = np.empty((k_array.shape[0], size, size), dtype=np.complex128)
+        out = _outbuf.empty((k_array.shape[0], size, size), np.complex128)
         _lib.check(_lib.lib().tbk_kdotp_hamilton(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
         return out[0] if single else out
 
@@ -108,6 +108,6 @@ class KdotpModel:
         if not np.isfinite(k_array).all():
             raise ValueError("array must not contain infs or NaNs")
         _, size = self._shape()
-        out = np.empty((k_array.shape[0], size), dtype=np.float64)
+        out = _outbuf.empty((k_array.shape[0], size), np.float64)
         _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
         return out[0] if single else out
