@@ -466,6 +466,7 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     int grid;
     if (a.mt_count >= 32) {  // below that a plain round-robin over the XCDs balances better
         a.xcd_rows = 4;
+        if (const char* v = getenv("TBK_HK_XCD_ROWS")) a.xcd_rows = std::max(1, atoi(v));  // measurements only
         const int max_rows = (a.mt_count + 7) / 8;
         grid = max_rows * a.nt_count * 8;
     } else {
