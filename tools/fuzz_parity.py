@@ -3,7 +3,7 @@
 Random shapes against the oracle (GPU box): orbital counts around every kernel boundary, odd batch sizes, 1-4 lattice
 dimensions, dense / sparse storage, both conventions, mesh and random k-points, host and list / array returns.
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [big]
 
 Prints one line per case that exceeds 1e-10 and a summary; exit status 1 if any case failed.
 """
@@ -20,6 +20,7 @@ from oracle import tbk_oracle as oracle  # noqa: E402  (checker)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+big = len(sys.argv) > 3 and sys.argv[3] == "big"  # orbital counts up to and past the 512 limit of the wave solvers
 rng = np.random.default_rng(seed)
 
 N_EDGES = [1, 2, 3, 4, 7, 8, 9, 12, 13, 15, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 66, 80, 96, 127, 128, 129, 150,
@@ -28,7 +29,7 @@ NK_EDGES = [1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 500, 10
 
 
 def pick_case():
-    n = int(rng.choice(N_EDGES))
+    n = int(rng.choice([300, 383, 384, 385, 448, 449, 511, 512, 513, 520, 600] if big else N_EDGES))
     dim = int(rng.choice([1, 2, 3, 3, 3, 4]))
     box = {1: 12, 2: 12, 3: 12, 4: 3}[dim]
     max_r = {1: 13, 2: 313, 3: 3000, 4: 1000}[dim]
