@@ -310,6 +310,43 @@ __global__ void __launch_bounds__(256) hk_finish_kernel(const HkArgs a) {
     store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, re, im);
 }
 
+// The same for many splits and few k-points (the matrix-vector path: ~100 K slices, one k-point): 16 threads per
+// element, thread j adds splits j, j + 16, ... and the 16 partial sums are combined in a fixed tree -- the one-thread
+// loop was a chain of ~100 dependent loads, 31 us of a 117 us single-k hamilton() call.
+template <int MODE, int CONV>
+__global__ void __launch_bounds__(256) hk_finish_wide_kernel(const HkArgs a) {
+    __shared__ double part[4][16][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int el = lane & 15;
+    const int j = wave * 4 + (lane >> 4);  // 0 .. 15
+    const int64_t idx = (int64_t)blockIdx.x * 16 + el;
+    const int e = (int)(idx % a.ncol_pad);
+    const int64_t kq = idx / a.ncol_pad;
+    double re = 0.0, im = 0.0;
+    if (kq < a.nk)
+        for (int sp = j; sp < a.splits; sp += 16) {
+            const d2 v = *reinterpret_cast<const d2*>(a.P + (((size_t)sp * a.p_rows + kq) * a.ncol_pad + e) * 2);
+            re += v[0];
+            im += v[1];
+        }
+    re += __shfl_xor(re, 16, 64);
+    im += __shfl_xor(im, 16, 64);
+    re += __shfl_xor(re, 32, 64);
+    im += __shfl_xor(im, 32, 64);
+    if (lane < 16) {
+        part[wave][el][0] = re;
+        part[wave][el][1] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && kq < a.nk) {
+        const int32_t ij = a.colmap[e];
+        if (ij < 0) return;
+        const double sr = (part[0][el][0] + part[1][el][0]) + (part[2][el][0] + part[3][el][0]);
+        const double si = (part[0][el][1] + part[1][el][1]) + (part[2][el][1] + part[3][el][1]);
+        store_element<MODE, CONV>(a, kq, ij >> 16, ij & 0xffff, sr, si);
+    }
+}
+
 // Tail launches: one workgroup per tail unit adds its sub-split partial tiles in order and either finishes the
 // element (the launch was not split otherwise) or hands the sum to the unit's slot of P for hk_finish_kernel.
 template <int MODE, int CONV>
@@ -357,7 +394,10 @@ hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t threads = a.nk * a.ncol_pad;
-    hipLaunchKernelGGL((hk_finish_kernel<MODE, CONV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    if (a.splits >= 32)
+        hipLaunchKernelGGL((hk_finish_wide_kernel<MODE, CONV>), dim3((unsigned)((threads + 15) / 16)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((hk_finish_kernel<MODE, CONV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
