@@ -699,6 +699,7 @@ static int eigenval_device_impl(tbk_model* m, const double* d_k, const double* h
     if (nk == 0) return TBK_OK;
     TBK_ARG(d_k && d_E, "k / E is NULL");
     TBK_HIP(hipSetDevice(m->device));
+    m->call_nk = nk;
     if (m->eigensolver == TBK_EIG_WAVE && !tbk_eig_small_supported(m->n_orb)) {
         tbk_set_error("TBK_EIG_WAVE handles n_orb <= 64 only (n_orb = %d)", m->n_orb);
         return TBK_ERR_ARGUMENT;

@@ -25,6 +25,8 @@
 
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "tbk_internal.h"
 
 namespace {
@@ -449,13 +451,19 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(ST_MAXN)
+// LPE lanes per eigenvalue (1, 4 or 16): with LPE > 1 every sweep tests LPE interior points of the bracket at once and
+// keeps the one of the LPE + 1 sub-intervals that holds the eigenvalue (multisection): log2(LPE + 1) bits per sweep
+// instead of one.  It spends LPE times the lanes to cut the serial chain, so it is for calls of a few matrices only
+// (a single 64 x 64 matrix: 57 sweeps = 116 us with one lane per eigenvalue, 14 sweeps with 16).
+template <int LPE>
+__global__ void __launch_bounds__(1024)
 tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E, int n, double* __restrict__ out) {
     // 16 n bytes of LDS (dynamic): at n = 64 a block must fit beside the 64 KiB QL blocks of the previous chunk
     extern __shared__ __attribute__((aligned(16))) double bs_smem[];
+    const int n_pad = (n + 63) & ~63;
     double* sd = bs_smem;
-    double* se2 = bs_smem + blockDim.x;  // se2[i] = e_i^2 couples i and i+1
-    __shared__ double sred[2][ST_MAXN / 64];
+    double* se2 = bs_smem + n_pad;  // se2[i] = e_i^2 couples i and i+1
+    __shared__ double sred[2][16];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int nwave = blockDim.x >> 6;
@@ -508,13 +516,15 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const double slack = 4.0 * 2.220446049250313e-16 * scale * n + 1e-300;
     double lo = gl - slack, hi = gu + slack;
     const double tol = 2.0 * 2.220446049250313e-16 * scale + 1e-300;
-    // same trip count for every lane: halve the Gershgorin interval down to `tol`
+    // same trip count for every lane: cut the Gershgorin interval by LPE + 1 per sweep down to `tol`
     int iters = 2;
-    for (double w = hi - lo; w > tol && iters < 1100; w *= 0.5) ++iters;
+    for (double w = hi - lo; w > tol && iters < 1100; w *= 1.0 / (LPE + 1)) ++iters;
 
-    const int m = tid;  // this lane's eigenvalue index
+    const int m = tid / LPE;    // this lane's eigenvalue index
+    const int sub = tid % LPE;  // ... and which interior point of the bracket it tests
     for (int it = 0; it < iters; ++it) {
-        const double x = 0.5 * (lo + hi);
+        const double width = hi - lo;
+        const double x = (LPE == 1) ? 0.5 * (lo + hi) : lo + width * ((sub + 1) * (1.0 / (LPE + 1)));
         // Sturm count at x: sign changes along p_0 = 1, p_1, ..., p_n, a zero taking the sign opposite to its
         // predecessor.  Signs are carried as integer bits (11 VALU issues per step; the bool / select form compiled
         // to 37 and made the single-k eigenval call 0.34 ms at n = 64).
@@ -554,12 +564,25 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         }
         for (; i0 < n; ++i0) step(sd[i0], se2[i0 - 1]);  // ragged tail (< 8 steps)
         rescale();
-        if (cnt > m)
-            hi = x;  // more than m eigenvalues below x: the m-th lies left of x
-        else
-            lo = x;
+        if (LPE == 1) {
+            if (cnt > m)
+                hi = x;  // more than m eigenvalues below x: the m-th lies left of x
+            else
+                lo = x;
+        } else {
+            // z = how many of the group's points have the m-th eigenvalue to their right (cnt <= m is monotone in
+            // sub): the eigenvalue lies between point z - 1 (or lo) and point z (or hi); the same arithmetic in every
+            // lane of the group, so the group keeps one common bracket
+            int z = (cnt > m) ? 0 : 1;
+#pragma unroll
+            for (int off = 1; off < LPE; off <<= 1) z += __shfl_xor(z, off, 64);
+            const double new_lo = (z == 0) ? lo : lo + width * (z * (1.0 / (LPE + 1)));
+            const double new_hi = (z == LPE) ? hi : lo + width * ((z + 1) * (1.0 / (LPE + 1)));
+            lo = new_lo;
+            hi = new_hi;
+        }
     }
-    if (tid < n) out[mat * n + tid] = ldexp(0.5 * (lo + hi), -sc_exp);
+    if (sub == 0 && m < n) out[mat * n + m] = ldexp(0.5 * (lo + hi), -sc_exp);
 }
 
 template <int NU, int NB, int ST_THREADS>
@@ -609,9 +632,19 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_QL, s);
-    const int threads = (n + 63) / 64 * 64;
-    hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)nk), dim3(threads), 2 * threads * sizeof(double), s, d_de,
-                       d_de + (size_t)nk * n, n, d_E);
+    const int n_pad = (n + 63) / 64 * 64;
+    const size_t lds = 2 * (size_t)n_pad * sizeof(double);
+    const double* d_e = d_de + (size_t)nk * n;
+    // a few matrices cannot fill the chip with one lane per eigenvalue: spend lanes on shorter chains instead.  By the
+    // size of the CALL, not of this chunk: TBK_OPT_K_CHUNK must not change results, and the variants differ in the
+    // last bit.
+    const int64_t call_nk = std::max(m->call_nk, nk);
+    if (call_nk <= 32 && n_pad * 16 <= 1024)
+        hipLaunchKernelGGL(tridiag_bisect_kernel<16>, dim3((unsigned)nk), dim3(n_pad * 16), lds, s, d_de, d_e, n, d_E);
+    else if (call_nk <= 512 && n_pad * 4 <= 1024)
+        hipLaunchKernelGGL(tridiag_bisect_kernel<4>, dim3((unsigned)nk), dim3(n_pad * 4), lds, s, d_de, d_e, n, d_E);
+    else
+        hipLaunchKernelGGL(tridiag_bisect_kernel<1>, dim3((unsigned)nk), dim3(n_pad), lds, s, d_de, d_e, n, d_E);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

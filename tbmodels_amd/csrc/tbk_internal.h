@@ -132,6 +132,7 @@ struct tbk_model {
     // (ctypes drops the GIL for the duration of a call).  Recursive: the host-buffer calls go through the device ones.
     std::recursive_mutex mu;
     int device = 0;
+    int64_t call_nk = 0;  // k-points of the eigenvalue call in progress: choices that must not depend on the chunking
     int n_cu = 256;  // compute units of the device (workgroup slots per round = 2 * n_cu for the H(k) kernel)
     int dim = 0;
     int n_orb = 0;
