@@ -4,7 +4,6 @@ import os
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tbmodels_amd  # noqa: E402

@@ -7,7 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tbmodels_amd  # noqa: E402
-from tbmodels_amd import _lib, synthetic as syn  # noqa: E402
+from tbmodels_amd import synthetic as syn  # noqa: E402
 
 n_r = int(os.environ.get("NR", "64"))
 r_vec, hop, pos = syn.dense_model_arrays(64, n_r, syn.MODEL_SEED + 2)
