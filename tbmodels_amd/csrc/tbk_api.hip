@@ -299,7 +299,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     void* ptrs[] = {m->d_R, m->d_colmap, m->d_B, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_powers};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_H2, &m->ws_E,   &m->ws_E2,
+    DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,
                       &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);

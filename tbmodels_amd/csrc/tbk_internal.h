@@ -183,7 +183,6 @@ struct tbk_model {
     rocblas_handle blas = nullptr;
     DevBuf ws_phase;  // [K2][nk_pad] cos/sin rows
     DevBuf ws_H;      // [chunk][n_orb][n_orb] complex
-    DevBuf ws_H2;     // second H buffer of the pipelined wave eigensolver
     DevBuf ws_E;      // rocSOLVER: [chunk][n_orb] off-diagonal scratch; wave solver: (d, e) of buffer 0
     DevBuf ws_E2;     // wave solver: (d, e) of buffer 1
     DevBuf ws_info;   // [chunk] int
