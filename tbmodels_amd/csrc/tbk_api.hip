@@ -422,7 +422,9 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // matrix (VALU work ~ n per matrix).  Measured crossover at n = 64: ~49 000 k-points (24576: 30.4 vs 31.5 ms,
 // 32768: 39.7 vs 40.2, 49152: 59.6 vs 59.4, 65536: 78.3 vs 77.2).
 constexpr int64_t TBK_SMALL_CALL = 4096;
-constexpr int TBK_SMALL_CALL_MIN_N = 12;  // below this the QL chain (61 us at n = 8) is the shorter one
+// (Up to 12 orbitals the QL chain used to be the shorter one -- 61 us at n = 8 -- until small matrices got the idle
+// lanes of their wave for multisection: 1000 silicon k-points 59 -> ~25 us, so every small call bisects now.)
+constexpr int TBK_SMALL_CALL_MIN_N = 0;
 
 static int launch_tridiag_eigenvalues(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E,
                                       bool beside_ql = false, bool small_call = false) {

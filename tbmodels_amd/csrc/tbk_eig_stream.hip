@@ -637,14 +637,21 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     const double* d_e = d_de + (size_t)nk * n;
     // a few matrices cannot fill the chip with one lane per eigenvalue: spend lanes on shorter chains instead.  By the
     // size of the CALL, not of this chunk: TBK_OPT_K_CHUNK must not change results, and the variants differ in the
-    // last bit.
+    // last bit.  Small matrices get the lanes their first wave would leave idle anyway (8 orbitals: 8 per eigenvalue).
     const int64_t call_nk = std::max(m->call_nk, nk);
-    if (call_nk <= 32 && n_pad * 16 <= 1024)
-        hipLaunchKernelGGL(tridiag_bisect_kernel<16>, dim3((unsigned)nk), dim3(n_pad * 16), lds, s, d_de, d_e, n, d_E);
-    else if (call_nk <= 512 && n_pad * 4 <= 1024)
-        hipLaunchKernelGGL(tridiag_bisect_kernel<4>, dim3((unsigned)nk), dim3(n_pad * 4), lds, s, d_de, d_e, n, d_E);
-    else
-        hipLaunchKernelGGL(tridiag_bisect_kernel<1>, dim3((unsigned)nk), dim3(n_pad), lds, s, d_de, d_e, n, d_E);
+    int lpe = call_nk <= 32 ? 16 : call_nk <= 512 ? 4 : 1;
+    while (lpe < 16 && n * lpe * 2 <= 64) lpe *= 2;
+    while (lpe > 1 && n * lpe > 1024) lpe /= 2;
+    const unsigned threads = (unsigned)((n * lpe + 63) / 64 * 64);
+#define TBK_BISECT(L) hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk), dim3(threads), lds, s, d_de, d_e, n, d_E)
+    switch (lpe) {
+        case 16: TBK_BISECT(16); break;
+        case 8: TBK_BISECT(8); break;
+        case 4: TBK_BISECT(4); break;
+        case 2: TBK_BISECT(2); break;
+        default: TBK_BISECT(1); break;
+    }
+#undef TBK_BISECT
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
