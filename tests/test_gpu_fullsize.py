@@ -56,6 +56,28 @@ def test_config2_headline_shape_100k():
     assert np.abs(ham1 - oracle.hamilton(r_vec, hop, k[idx[:8]], 1, pos=pos)).max() < 1e-10
 
 
+def test_headline_shape_intermediate_batches():
+    """Batches between the matrix-vector path and the long launches at the headline shape, where the H(k) launch is
+    K-split, tail-split, or both (tbk_hk_dense.hip: launch()): every k-point must come out as it does in a
+    20-point call (matrix-vector path, checked against the oracle in the test above), and tr H(k) must match."""
+    r_vec, hop, pos = syn.dense_model_arrays(64, 4096, syn.MODEL_SEED + 2)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.pin_staging()
+    traces = np.einsum("rii->r", hop)
+    rng = np.random.default_rng(11)
+    for n_k in (40, 129, 600, 1000, 1500, 2100, 4200, 6000):
+        k = syn.random_kpoints(n_k, seed=n_k)
+        ham = model.hamilton(k, convention=1)
+        eig = model.eigenval_array(k)
+        assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+        assert np.abs(np.einsum("kii->k", ham).real - eig.sum(axis=1)).max() < 1e-10
+        for start in {0, n_k - 20, int(rng.integers(0, n_k - 20)), int(rng.integers(0, n_k - 20))}:
+            window = slice(start, start + 20)
+            assert np.abs(ham[window] - model.hamilton(k[window], convention=1)).max() < 1e-12
+            assert np.abs(eig[window] - model.eigenval_array(k[window])).max() < 1e-12
+        assert np.array_equal(ham, model.hamilton(k, convention=1))  # fixed summation order
+
+
 def test_config3_sparse_shape():
     """Config 3: CSR N_orb=256, N_R=512, 2 % fill (k list shortened: the N=256 eigensolve is ~0.1 ms per k)."""
     r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(256, 512, syn.MODEL_SEED + 3)
