@@ -105,8 +105,6 @@ class KdotpModel:
     def eigenval_array(self, k):
         """``eigenval`` as one ``(NK, N)`` array instead of a list of rows (see ``Model.eigenval_array``)."""
         k_array, single = self._k_array(k)
-        if not np.isfinite(k_array).all():
-            raise ValueError("array must not contain infs or NaNs")
         _, size = self._shape()
         out = _outbuf.empty((k_array.shape[0], size), np.float64)
         _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))

@@ -273,11 +273,37 @@ def test_eigenval_array_is_the_list_as_one_array(silicon, kdotp_golden):
     assert np.array_equal(np.array(kp.eigenval(g["order2_dk"])), kp.eigenval_array(g["order2_dk"]))
 
 
-def test_non_finite_k_is_value_error(silicon):
+def test_non_finite_k_is_value_error(silicon, kdotp_golden):
+    """One NaN / Inf k component anywhere in a batch: the device-side check of the eigenvalues raises scipy's
+    ValueError for the whole call (every solver path), the next call on the same handle is clean again, and
+    hamilton() returns the NaNs like the reference."""
+    from tbmodels_amd import _lib
+    from tbmodels_amd.kdotp import KdotpModel
+
     model = tbmodels_amd.Model.from_packed(silicon["R"], silicon["hop"])
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match="infs or NaNs"):
         model.eigenval([[0.1, np.nan, 0.2]])
     assert np.isnan(model.hamilton([0.1, np.nan, 0.2])).any()
+    for n_orb, n_k, solver in [(8, 20000, "auto"), (40, 700, "auto"), (40, 9000, "rocsolver"), (64, 45000, "auto"), (100, 300, "auto")]:
+        r_vec, hop, pos = syn.dense_model_arrays(n_orb, 5, syn.MODEL_SEED + n_orb)
+        model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+        model.set_option(_lib.TBK_OPT_EIGENSOLVER, {"auto": _lib.TBK_EIG_AUTO, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[solver])
+        k = syn.random_kpoints(n_k, seed=n_orb)
+        clean = model.eigenval_array(k)
+        for where, bad in [(0, np.nan), (n_k // 2, np.inf), (n_k - 1, -np.inf), (n_k - 1, np.nan)]:
+            broken = k.copy()
+            broken[where, 1] = bad
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                model.eigenval_array(broken)
+        assert np.array_equal(model.eigenval_array(k), clean)
+    g = kdotp_golden
+    kp = KdotpModel({tuple(p): c for p, c in zip(g["order2_powers"].tolist(), g["order2_coeffs"])})
+    k = np.array(g["order2_dk"], dtype=float)
+    k[3, 0] = np.inf
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        kp.eigenval(k)
+    constant = KdotpModel({(0, 0, 0): g["order0_coeffs"][0]})  # k does not enter: like the reference, no error
+    assert np.isfinite(constant.eigenval(k)).all()
 
 
 @pytest.mark.parametrize("n_orb,n_k", [(8, 5), (8, 6000), (40, 3), (64, 50000), (100, 4), (300, 2)])
