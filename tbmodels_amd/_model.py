@@ -581,7 +581,9 @@ class Model:
     # ------------------------------------------------------------------ the hot path
     def _k_array(self, k):
         """``np.array(k, ndmin=1)``; 1-D (or scalar) means one k-point (``_tb_model.py:1103-1108``)."""
-        k_array = np.array(k, ndmin=1)
+        k_array = np.asarray(k)  # np.array(k, ndmin=1) without its copy: k is only read
+        if k_array.ndim == 0:
+            k_array = k_array.reshape(1)
         single = k_array.ndim == 1
         if single:
             k_array = k_array.reshape((1, -1))

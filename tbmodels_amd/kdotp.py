@@ -80,7 +80,9 @@ class KdotpModel:
 
     def _k_array(self, k):
         dim, _ = self._shape()
-        k_array = np.array(k, ndmin=1)
+        k_array = np.asarray(k)  # np.array(k, ndmin=1) without its copy: k is only read
+        if k_array.ndim == 0:
+            k_array = k_array.reshape(1)
         single = k_array.ndim == 1
         if single:
             k_array = k_array.reshape((1, -1))
