@@ -393,14 +393,15 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
         TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();
         const double* kc = d_k + c0 * m->dim;
-        TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
+        const bool own_rows = tbk_hk_inline_phases(m, nkc);  // a few k-points: the H(k) kernel makes its phase rows
+        if (!own_rows) TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
         const double* d_orb = nullptr;
         if (convention == 1) {
             TBK_CHECK(m->ws_orb.reserve((size_t)nkc * m->n_orb * 2 * sizeof(double)));
             TBK_CHECK(tbk_launch_orbital_phases(m, kc, d_pos, nkc, m->ws_orb.as<double>()));
             d_orb = m->ws_orb.as<double>();
         }
-        TBK_CHECK(build_h(m, d_A, nkc, nk_pad, HK_FULL, convention, kc, d_orb, d_H + (size_t)c0 * nn2));
+        TBK_CHECK(build_h(m, own_rows ? nullptr : d_A, nkc, nk_pad, HK_FULL, convention, kc, d_orb, d_H + (size_t)c0 * nn2));
     }
     return TBK_OK;
 }
@@ -466,6 +467,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         TBK_CHECK(m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * nk_pad * sizeof(double)));
         double* d_A = m->ws_phase.as<double>();
         const double* kc = d_k + c0 * m->dim;
+        if (tbk_hk_inline_phases(m, nkc)) return build_h(m, nullptr, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H);
         TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
         return build_h(m, d_A, nkc, nk_pad, HK_TRI, 2, kc, nullptr, d_H);
     };

@@ -49,7 +49,9 @@ struct HkArgs {
     const double* A;
     const double* Bt;
     const int32_t* colmap;
-    const double* kpts;  // unused
+    const double* kpts;  // [nk][dim]: read by the matrix-vector kernel when it makes its own phase rows (A == nullptr)
+    const int32_t* R;    // [n_r_pad][dim] lattice vectors, same use
+    int64_t n_r;
     const double* pos;   // convention 1 only: orbital phase table e[k][p] = exp(2 pi i k.pos_p), [nk][n_orb][2]
     double* H;
     int64_t k2;
@@ -261,12 +263,32 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 // spend most of its work on padding (127/128 for one k-point), so this is a plain matrix-vector product on the vector
 // unit -- one thread per packed element, up to 32 accumulator pairs, K split over blockIdx.y like the split-K launch above and finished by
 // the same hk_finish_kernel.  Bound by reading Bt once (272 MB at N_orb = 64, N_R = 4096: ~55 us).
-template <int NKV>
+template <int NKV, bool INLINE_PHASES>
 __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) double s_rows[];  // INLINE_PHASES: [rows_per_slice][NKV]
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.ncol_pad) return;
     const int64_t kk0 = (int64_t)blockIdx.y * rows_per_slice;
     const int64_t kk1 = min(kk0 + rows_per_slice, a.k2);
+    if (INLINE_PHASES) {
+        // the slice's phase rows, made here instead of by a phase_rows_kernel launch of their own (one dependent
+        // launch less: ~10 us of a 90 us single-k hamilton() call); same arithmetic as tbk_phase.hip
+        const int cells = (int)(kk1 - kk0) * NKV;
+        for (int idx = threadIdx.x; idx < cells; idx += 256) {
+            const int row = idx / NKV, q = idx % NKV;
+            const int64_t kk = kk0 + row, r = kk >> 1;
+            double v = 0.0;
+            if (q < a.nk && r < a.n_r) {
+                double dot = 0.0;
+                for (int d = 0; d < a.dim; ++d) dot = fma(a.kpts[(int64_t)q * a.dim + d], (double)a.R[r * a.dim + d], dot);
+                double sn, cs;
+                sincospi(2.0 * dot, &sn, &cs);
+                v = (kk & 1) ? sn : cs;
+            }
+            s_rows[idx] = v;
+        }
+        __syncthreads();
+    }
+    if (e >= a.ncol_pad) return;
     const int64_t ldb = (int64_t)a.ncol_pad * 2;
     const double* bre = a.Bt + (size_t)(e >> 4) * 32 + (e & 15);  // Bt[kk][tile][re | im][16]
     double acc[NKV][2];
@@ -275,7 +297,8 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
 #pragma unroll 4
     for (int64_t kk = kk0; kk < kk1; ++kk) {
         const double br = bre[kk * ldb], bi = bre[kk * ldb + 16];
-        const double* arow = a.A + kk * a.nk_pad;  // uniform: phase row kk, k-points 0 .. NKV-1
+        // uniform: phase row kk, k-points 0 .. NKV-1
+        const double* arow = INLINE_PHASES ? s_rows + (kk - kk0) * NKV : a.A + kk * a.nk_pad;
 #pragma unroll
         for (int q = 0; q < NKV; ++q) {
             const double aq = arow[q];
@@ -379,18 +402,27 @@ __global__ void __launch_bounds__(256) hk_finish_tiles_kernel(const HkArgs a) {
 template <int MODE, int CONV>
 hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
     const dim3 grid((unsigned)((a.ncol_pad + 255) / 256), (unsigned)a.splits);
+#define TBK_GEMV(N)                                                                                              \
+    do {                                                                                                         \
+        if (a.A == nullptr)                                                                                      \
+            hipLaunchKernelGGL((hk_gemv_kernel<N, true>), grid, dim3(256), (size_t)rows_per_slice * N * sizeof(double), s, a, \
+                               rows_per_slice);                                                                  \
+        else                                                                                                     \
+            hipLaunchKernelGGL((hk_gemv_kernel<N, false>), grid, dim3(256), 0, s, a, rows_per_slice);            \
+    } while (0)
     if (a.nk <= 1)
-        hipLaunchKernelGGL(hk_gemv_kernel<1>, grid, dim3(256), 0, s, a, rows_per_slice);
+        TBK_GEMV(1);
     else if (a.nk <= 2)
-        hipLaunchKernelGGL(hk_gemv_kernel<2>, grid, dim3(256), 0, s, a, rows_per_slice);
+        TBK_GEMV(2);
     else if (a.nk <= 4)
-        hipLaunchKernelGGL(hk_gemv_kernel<4>, grid, dim3(256), 0, s, a, rows_per_slice);
+        TBK_GEMV(4);
     else if (a.nk <= 8)
-        hipLaunchKernelGGL(hk_gemv_kernel<8>, grid, dim3(256), 0, s, a, rows_per_slice);
+        TBK_GEMV(8);
     else if (a.nk <= 16)
-        hipLaunchKernelGGL(hk_gemv_kernel<16>, grid, dim3(256), 0, s, a, rows_per_slice);
+        TBK_GEMV(16);
     else
-        hipLaunchKernelGGL(hk_gemv_kernel<32>, grid, dim3(256), 0, s, a, rows_per_slice);
+        TBK_GEMV(32);
+#undef TBK_GEMV
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t threads = a.nk * a.ncol_pad;
@@ -483,7 +515,29 @@ int launch(tbk_model* m, const HkArgs& a0, int grid) {
     return TBK_OK;
 }
 
+// K slices of the matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
+void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, int* rows_out) {
+    const int col_blocks = (m->ncol_pad + 255) / 256;
+    const size_t per_split = (size_t)nk * m->ncol_pad * 2 * sizeof(double);
+    int slices = std::max(1, std::min(1024 / col_blocks, (int)(m->k2 / 32)));
+    slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices, (size_t(64) << 20) / per_split));
+    const int rows_per_slice = (int)((m->k2 + slices - 1) / slices);
+    *slices_out = (int)((m->k2 + rows_per_slice - 1) / rows_per_slice);
+    *rows_out = rows_per_slice;
+}
+
 }  // namespace
+
+// True when tbk_launch_hk_dense will take the matrix-vector path AND can make its phase rows itself: the caller then
+// skips tbk_launch_phase and passes d_A = nullptr.
+bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk) {
+    if (nk < 1 || nk > 32 || m->k2 <= 0 || m->kdotp || m->sparse || m->d_R == nullptr) return false;
+    int slices, rows;
+    gemv_plan(m, nk, &slices, &rows);
+    int nkv = 1;
+    while (nkv < nk) nkv *= 2;
+    return (size_t)rows * nkv * sizeof(double) <= (size_t(32) << 10);
+}
 
 int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
                         int convention, const double* d_k, const double* d_pos, double* d_H) {
@@ -493,6 +547,8 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.Bt = m->d_B;
     a.colmap = m->d_colmap;
     a.kpts = d_k;
+    a.R = m->d_R;
+    a.n_r = m->n_r;
     a.pos = d_pos;
     a.H = d_H;
     a.k2 = m->k2;
@@ -525,13 +581,10 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.P2 = nullptr;
     a.unit_grid = 1;
     if (nk <= 32 && m->k2 > 0) {
-        // matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
-        const int col_blocks = (a.ncol_pad + 255) / 256;
+        int slices, rows_per_slice;
+        gemv_plan(m, nk, &slices, &rows_per_slice);
         const size_t per_split = (size_t)nk * a.ncol_pad * 2 * sizeof(double);
-        int slices = std::max(1, std::min(1024 / col_blocks, (int)(m->k2 / 32)));
-        slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices, (size_t(64) << 20) / per_split));
-        const int rows_per_slice = (int)((m->k2 + slices - 1) / slices);
-        slices = (int)((m->k2 + rows_per_slice - 1) / rows_per_slice);
+        TBK_ARG(d_A != nullptr || (tbk_hk_inline_phases(m, nk) && d_k != nullptr), "phase rows missing");
         TBK_CHECK(m->ws_part.reserve(per_split * slices));
         a.P = m->ws_part.as<double>();
         a.splits = slices;
@@ -589,6 +642,8 @@ int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, 
     a.Bt = m->d_B;
     a.colmap = m->d_colmap;
     a.kpts = nullptr;
+    a.R = m->d_R;
+    a.n_r = m->n_r;
     a.pos = nullptr;
     a.H = d_H;
     a.k2 = m->k2;
