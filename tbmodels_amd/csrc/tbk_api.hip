@@ -424,8 +424,7 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // 32768: 39.7 vs 40.2, 49152: 59.6 vs 59.4, 65536: 78.3 vs 77.2).
 constexpr int64_t TBK_SMALL_CALL = 4096;
 // (Up to 12 orbitals the QL chain used to be the shorter one -- 61 us at n = 8 -- until small matrices got the idle
-// lanes of their wave for multisection: 1000 silicon k-points 59 -> ~25 us, so every small call bisects now.)
-constexpr int TBK_SMALL_CALL_MIN_N = 0;
+// lanes of their wave for multisection: 1000 silicon k-points 59 -> 20 us, so small calls bisect at every size now.)
 
 static int launch_tridiag_eigenvalues(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E,
                                       bool beside_ql = false, bool small_call = false) {
@@ -480,7 +479,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const int64_t n_chunks = (int64_t)sched.size();
     const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
     // a property of the call, not of its chunking: TBK_OPT_K_CHUNK must not change the results
-    const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, 640 * (int64_t)m->n_orb) && m->n_orb > TBK_SMALL_CALL_MIN_N;
+    const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, 640 * (int64_t)m->n_orb);
     TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
@@ -532,7 +531,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         const int b = (int)((n_chunks - 1) & 1);
         TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_eig, debuf[b]->as<double>(), prev_nkc,
                                              d_E + (size_t)prev_c0 * n, n_chunks > 1,
-                                             small_call || (n_chunks > 1 && m->n_orb > TBK_SMALL_CALL_MIN_N)));
+                                             small_call || n_chunks > 1));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_eig));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues
