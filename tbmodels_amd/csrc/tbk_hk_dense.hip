@@ -269,6 +269,8 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int64_t kk0 = (int64_t)blockIdx.y * rows_per_slice;
     const int64_t kk1 = min(kk0 + rows_per_slice, a.k2);
+    const int64_t kbase = (int64_t)blockIdx.z * NKV;  // small models: groups of NKV k-points over blockIdx.z
+    const int nk_here = (int)min((int64_t)NKV, a.nk - kbase);
     if (INLINE_PHASES) {
         // the slice's phase rows, made here instead of by a phase_rows_kernel launch of their own (one dependent
         // launch less: ~10 us of a 90 us single-k hamilton() call); same arithmetic as tbk_phase.hip
@@ -277,9 +279,9 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
             const int row = idx / NKV, q = idx % NKV;
             const int64_t kk = kk0 + row, r = kk >> 1;
             double v = 0.0;
-            if (q < a.nk && r < a.n_r) {
+            if (q < nk_here && r < a.n_r) {
                 double dot = 0.0;
-                for (int d = 0; d < a.dim; ++d) dot = fma(a.kpts[(int64_t)q * a.dim + d], (double)a.R[r * a.dim + d], dot);
+                for (int d = 0; d < a.dim; ++d) dot = fma(a.kpts[(kbase + q) * a.dim + d], (double)a.R[r * a.dim + d], dot);
                 double sn, cs;
                 sincospi(2.0 * dot, &sn, &cs);
                 v = (kk & 1) ? sn : cs;
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
     for (int64_t kk = kk0; kk < kk1; ++kk) {
         const double br = bre[kk * ldb], bi = bre[kk * ldb + 16];
         // uniform: phase row kk, k-points 0 .. NKV-1
-        const double* arow = INLINE_PHASES ? s_rows + (kk - kk0) * NKV : a.A + kk * a.nk_pad;
+        const double* arow = INLINE_PHASES ? s_rows + (kk - kk0) * NKV : a.A + kk * a.nk_pad + kbase;
 #pragma unroll
         for (int q = 0; q < NKV; ++q) {
             const double aq = arow[q];
@@ -308,8 +310,8 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
     }
 #pragma unroll
     for (int q = 0; q < NKV; ++q) {
-        if (q >= a.nk) break;
-        double* part = a.P + (((size_t)blockIdx.y * a.p_rows + q) * a.ncol_pad + e) * 2;
+        if (q >= nk_here) break;
+        double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kbase + q) * a.ncol_pad + e) * 2;
         *reinterpret_cast<d2*>(part) = (d2){acc[q][0], acc[q][1]};
     }
 }
@@ -401,7 +403,7 @@ __global__ void __launch_bounds__(256) hk_finish_tiles_kernel(const HkArgs a) {
 
 template <int MODE, int CONV>
 hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
-    const dim3 grid((unsigned)((a.ncol_pad + 255) / 256), (unsigned)a.splits);
+    const dim3 grid((unsigned)((a.ncol_pad + 255) / 256), (unsigned)a.splits, (unsigned)((a.nk + 31) / 32));
 #define TBK_GEMV(N)                                                                                              \
     do {                                                                                                         \
         if (a.A == nullptr)                                                                                      \
@@ -531,12 +533,21 @@ void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, int* rows_out) {
 // True when tbk_launch_hk_dense will take the matrix-vector path AND can make its phase rows itself: the caller then
 // skips tbk_launch_phase and passes d_A = nullptr.
 bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk) {
-    if (nk < 1 || nk > 32 || m->k2 <= 0 || m->kdotp || m->sparse || m->d_R == nullptr) return false;
+    if (!tbk_hk_gemv_path(m, nk) || m->kdotp || m->d_R == nullptr) return false;
     int slices, rows;
     gemv_plan(m, nk, &slices, &rows);
     int nkv = 1;
-    while (nkv < nk) nkv *= 2;
+    while (nkv < std::min<int64_t>(nk, 32)) nkv *= 2;
     return (size_t)rows * nkv * sizeof(double) <= (size_t(32) << 10);
+}
+
+// The matrix-vector path: up to 32 k-points of any model, and up to 4096 k-points (in groups of 32) of a SMALL model --
+// at most 22 orbitals and fewer than 128 lattice vectors, i.e. a handful of MFMA tiles walking a dozen K stages one
+// load latency at a time (the 1000-point silicon grid: 31 us in the tile kernel, ~10 us here).
+bool tbk_hk_gemv_path(const tbk_model* m, int64_t nk) {
+    if (nk < 1 || m->k2 <= 0 || m->sparse) return false;
+    if (nk <= 32) return true;
+    return nk <= 4096 && m->ncol_pad <= 256 && m->k2 < 16 * TBK_BK;
 }
 
 int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
@@ -580,7 +591,7 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.sub_splits = 1;
     a.P2 = nullptr;
     a.unit_grid = 1;
-    if (nk <= 32 && m->k2 > 0) {
+    if (tbk_hk_gemv_path(m, nk)) {
         int slices, rows_per_slice;
         gemv_plan(m, nk, &slices, &rows_per_slice);
         const size_t per_split = (size_t)nk * a.ncol_pad * 2 * sizeof(double);

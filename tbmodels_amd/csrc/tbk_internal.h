@@ -247,6 +247,7 @@ int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);    // f
 bool tbk_eig_stream_supported(int n);
 int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
 bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk);  // tbk_hk_dense.hip
+bool tbk_hk_gemv_path(const tbk_model* m, int64_t nk);
 int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E);
 size_t tbk_eig_scratch_per_k(const tbk_model* m);
 

@@ -546,3 +546,19 @@ def test_block_diagonal_spectra_symmetric_about_zero(n):
             for n_k in (1, 3, 4200):  # bisection for small calls, QL + bisection for the chunked pipeline
                 got = model.eigenval_array(rng.random((n_k, 1)))
                 _close(got, np.broadcast_to(ref, got.shape))
+
+
+@pytest.mark.parametrize("n_k", [33, 64, 65, 1000, 4096, 4097])
+def test_small_model_batches_take_the_grouped_matrix_vector_path(silicon, n_k):
+    """Small models (<= 22 orbitals, < 128 lattice vectors) evaluate up to 4096 k-points in groups of 32 with the
+    matrix-vector kernel (tbk_hk_gemv_path); 4097 k-points are back on the MFMA tiles.  Both conventions, both H modes."""
+    model = tbmodels_amd.Model.from_packed(silicon["R"], silicon["hop"], pos=silicon["pos"])
+    k = syn.random_kpoints(n_k, seed=n_k) * 2.0 - 0.7
+    sub = np.unique(np.concatenate([np.arange(0, n_k, max(1, n_k // 37)), [n_k - 1, n_k - 2, 31, 32]]))
+    ham = model.hamilton(k)
+    _close(ham[sub], oracle.hamilton(silicon["R"], silicon["hop"], k[sub]))
+    _close(model.hamilton(k, convention=1)[sub], oracle.hamilton(silicon["R"], silicon["hop"], k[sub], 1, pos=silicon["pos"]))
+    eig = model.eigenval_array(k)
+    _close(eig[sub], np.array(oracle.eigenval(silicon["R"], silicon["hop"], k[sub])))
+    _close(eig.sum(axis=1), np.einsum("kii->k", ham).real, 1e-12)  # every row, not only the sampled ones
+    assert np.array_equal(ham, np.conj(np.swapaxes(ham, 1, 2)))
