@@ -745,7 +745,11 @@ __global__ void __launch_bounds__(256) flag_nonfinite_kernel(const double* __res
 
 static int eigenval_device_impl(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E) {
     TBK_CHECK(eigenval_device_solve(m, d_k, h_k, nk, d_E));
-    if (nk > 0 && m != nullptr) {
+    // the wave solvers raise the flag themselves (QL and bisection see every non-finite (d, e) and answer NaN);
+    // rocSOLVER's eigenvalues get the pass over the output
+    const bool own_solvers = m != nullptr && m->eigensolver != TBK_EIG_ROCSOLVER &&
+                             (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb)));
+    if (nk > 0 && m != nullptr && !own_solvers) {
         const int64_t total = nk * m->n_orb;
         const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8 * 1024);
         hipLaunchKernelGGL(flag_nonfinite_kernel, dim3(blocks), dim3(256), 0, m->stream, d_E, total, m->ws_flag.as<int>() + 1);

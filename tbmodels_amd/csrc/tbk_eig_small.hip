@@ -477,6 +477,7 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
         for (int i = 0; i < n; ++i) finite = finite && isfinite(d[i * QL_LD]) && isfinite(e[i * QL_LD]);
         if (!finite) {
             for (int i = 0; i < n; ++i) d[i * QL_LD] = __builtin_nan("");
+            atomicAdd(fail_count + 1, 1);  // flags[1]: non-finite input (tbk_eigenval_check -> TBK_ERR_NOT_FINITE)
         }
         for (int l = 0; l < n && !failed && finite; ++l) {
             int iter = 0;

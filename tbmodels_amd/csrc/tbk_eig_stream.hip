@@ -457,7 +457,8 @@ __device__ __forceinline__ double wave_max(double v) {
 // (a single 64 x 64 matrix: 57 sweeps = 116 us with one lane per eigenvalue, 14 sweeps with 16).
 template <int LPE>
 __global__ void __launch_bounds__(1024)
-tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E, int n, double* __restrict__ out) {
+tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E, int n, double* __restrict__ out,
+                      int* __restrict__ flags) {
     // 16 n bytes of LDS (dynamic): at n = 64 a block must fit beside the 64 KiB QL blocks of the previous chunk
     extern __shared__ __attribute__((aligned(16))) double bs_smem[];
     const int n_pad = (n + 63) & ~63;
@@ -490,6 +491,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     // The caller maps non-finite eigenvalues to the ValueError of scipy's check_finite (_tb_model.py:1147-1150).
     if (__syncthreads_or(bad)) {
         if (tid < n) out[mat * n + tid] = __builtin_nan("");
+        if (tid == 0) atomicAdd(flags + 1, 1);  // flags[1]: non-finite input (tbk_eigenval_check -> TBK_ERR_NOT_FINITE)
         return;
     }
     double gl = sred[0][0], gu = sred[1][0];
@@ -643,7 +645,8 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     while (lpe < 16 && n * lpe * 2 <= 64) lpe *= 2;
     while (lpe > 1 && n * lpe > 1024) lpe /= 2;
     const unsigned threads = (unsigned)((n * lpe + 63) / 64 * 64);
-#define TBK_BISECT(L) hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk), dim3(threads), lds, s, d_de, d_e, n, d_E)
+#define TBK_BISECT(L) \
+    hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
     switch (lpe) {
         case 16: TBK_BISECT(16); break;
         case 8: TBK_BISECT(8); break;
