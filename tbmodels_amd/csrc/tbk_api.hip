@@ -353,7 +353,12 @@ static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
     int64_t budget = std::min<int64_t>((int64_t)(free_b / 4), int64_t(6) << 30);
     int64_t chunk = budget / per_k / TBK_BM * TBK_BM;
-    chunk = std::max<int64_t>(TBK_BM, std::min<int64_t>(chunk, 32768));
+    // 32768 k-points per chunk at 64 orbitals and above; small matrices take proportionally more (up to 1 M at 8
+    // orbitals): a chunk is ~6 launches and one QL latency chain whatever its size, and 20 M k-points of an
+    // 8-orbital model spent 42 of 92 GPU-ms in 612 of those chains
+    int64_t cap = 32768;
+    if (n < 64) cap *= std::min<int64_t>(32, (64 / n) * (64 / n));
+    chunk = std::max<int64_t>(TBK_BM, std::min<int64_t>(chunk, cap));
     if (m->k_chunk > 0) chunk = round_up(m->k_chunk, TBK_BM);
     else if (chunk >= 4096) chunk = chunk / 4096 * 4096;  // 32 k tiles: equal shares for the 8 XCDs
     return std::min(chunk, round_up(nk, TBK_BM));
