@@ -562,3 +562,17 @@ def test_small_model_batches_take_the_grouped_matrix_vector_path(silicon, n_k):
     _close(eig[sub], np.array(oracle.eigenval(silicon["R"], silicon["hop"], k[sub])))
     _close(eig.sum(axis=1), np.einsum("kii->k", ham).real, 1e-12)  # every row, not only the sampled ones
     assert np.array_equal(ham, np.conj(np.swapaxes(ham, 1, 2)))
+
+
+def test_fixed_seed_fuzz_sample():
+    """A fixed-seed sample of tools/fuzz_parity.py (random shapes around the kernel boundaries, structured hoppings,
+    k.p models) so that the randomised comparison with the oracle is part of every GPU run, reproducibly."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    fuzz.configure(seconds=120.0, seed=20261002, cases=40)
+    assert fuzz.main() == 0

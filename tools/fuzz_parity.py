@@ -18,10 +18,17 @@ import tbmodels_amd  # noqa: E402
 from tbmodels_amd import synthetic as syn  # noqa: E402
 from oracle import tbk_oracle as oracle  # noqa: E402  (checker)
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-big = len(sys.argv) > 3 and sys.argv[3] == "big"  # orbital counts up to and past the 512 limit of the wave solvers
-rng = np.random.default_rng(seed)
+budget = 120.0
+big = False  # orbital counts up to and past the 512 limit of the wave solvers
+max_cases = None
+rng = np.random.default_rng(1)
+
+
+def configure(seconds=120.0, seed=1, big_sizes=False, cases=None):
+    """Set the run's budget, seed, size class and (optionally) a case limit -- also the entry point for tests."""
+    global budget, big, max_cases, rng  # pylint: disable=global-statement
+    budget, big, max_cases = float(seconds), bool(big_sizes), cases
+    rng = np.random.default_rng(seed)
 
 N_EDGES = [1, 2, 3, 4, 7, 8, 9, 12, 13, 15, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 66, 80, 96, 127, 128, 129, 150,
            191, 192, 193, 200, 255, 256, 257, 300, 383, 384, 385]
@@ -127,7 +134,7 @@ def main():
     n_cases = 0
     worst = 0.0
     failures = []
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or n_cases < max_cases):
         if rng.integers(0, 6) == 0:
             case, err_a, err_b = kdotp_case()
             n_cases += 1
@@ -166,4 +173,6 @@ def main():
 
 
 if __name__ == "__main__":
+    configure(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+              len(sys.argv) > 3 and sys.argv[3] == "big")
     sys.exit(main())
