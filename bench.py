@@ -274,6 +274,7 @@ def main():
     d_gather = None
     comm = None
     collective = "none"
+    rccl_ranks = 0
     host_gather = None
     force_comm = os.environ.get("TBK_BENCH_FORCE_COMM") == "1"  # exercise RCCL with a 1-rank communicator
     if world > 1 or force_comm:
@@ -297,14 +298,23 @@ def main():
         all_ok = (status == 0) if group is None else group.allreduce_min(1.0 if status == 0 else 0.0) == 1.0
         if all_ok:
             collective = "rccl all-gather (xGMI) of device buffers on its own stream, overlapping the next step"
+            n_ranks, my_rank = ctypes.c_int(0), ctypes.c_int(-1)
+            _lib.check(lib.tbk_comm_ranks(comm, ctypes.byref(n_ranks), ctypes.byref(my_rank)))
+            rccl_ranks = n_ranks.value  # ncclCommCount: what RCCL itself says joined
+            if rccl_ranks != world or my_rank.value != rank:
+                raise SystemExit("RCCL communicator has %d ranks (this one is %d), expected %d (rank %d)"
+                                 % (rccl_ranks, my_rank.value, world, rank))
         else:
-            # e.g. several ranks sharing one GPU: RCCL refuses; gather on the host instead and say so
-            sys.stderr.write("[bench] RCCL communicator unavailable (%s); falling back to a host all-gather\n"
-                             % _lib.last_error())
+            # e.g. several ranks sharing one GPU: RCCL refuses.  A scaling run must not print a number RCCL never
+            # produced: fail, unless the host-gather fallback was asked for explicitly (launch-mechanics tests)
+            message = "[bench] RCCL communicator unavailable (%s)" % _lib.last_error()
+            if os.environ.get("TBK_BENCH_ALLOW_HOST_GATHER") != "1":
+                raise SystemExit(message + "; set TBK_BENCH_ALLOW_HOST_GATHER=1 to gather through the host instead")
+            sys.stderr.write(message + "; TBK_BENCH_ALLOW_HOST_GATHER=1: falling back to a host all-gather\n")
             if status == 0:
                 lib.tbk_comm_destroy(comm)
             comm = None
-            collective = "host all-gather (RCCL unavailable)"
+            collective = "host all-gather (RCCL unavailable, TBK_BENCH_ALLOW_HOST_GATHER=1)"
             h_slab = np.empty((nk_gpu, n_orb))
 
             def host_gather():
@@ -312,6 +322,7 @@ def main():
                 group.all_gather_array(h_slab)
 
     step_no = [0]
+    k_hint = _lib.ptr(k_slab) if args.config == "cfg4" else None
 
     def step():
         if args.construct_only:
@@ -324,7 +335,9 @@ def main():
         d_out = d_e_pair[pair]
         if comm is not None:
             _lib.check(lib.tbk_comm_wait_slot(comm, model, pair))
-        _lib.check(lib.tbk_eigenval_device(model, d_k, nk_gpu, d_out))
+        # (the mesh config hands over the host array it uploaded: device lists are never read back, so runs of a
+        # shared k component are only recognised through it -- include/tbk.h)
+        _lib.check(lib.tbk_eigenval_device_hint(model, d_k, k_hint, nk_gpu, d_out))
         if comm is not None:
             _lib.check(lib.tbk_comm_allgather_f64_overlapped(comm, model, d_out, d_gather_pair[pair], e_count, pair))
         elif host_gather is not None:
@@ -361,6 +374,51 @@ def main():
     _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
     stage_ms = {name: ms[i] for i, name in enumerate(_lib.STAGE_NAMES)}
     stage_n = {name: launches[i] for i, name in enumerate(_lib.STAGE_NAMES)}
+
+    # --- after the clock: per-rank split of one step (N > 1), and the host-buffer API leg (N = 1) ---------------
+    per_rank = None
+    if world > 1 and comm is not None and not args.construct_only:
+        split = np.zeros(2)
+        barrier()
+        t1 = time.perf_counter()
+        _lib.check(lib.tbk_eigenval_device_hint(model, d_k, k_hint, nk_gpu, d_e_pair[0]))
+        _lib.check(lib.tbk_synchronize(model))
+        split[0] = (time.perf_counter() - t1) * 1e3
+        barrier()
+        t1 = time.perf_counter()
+        _lib.check(lib.tbk_comm_allgather_f64(comm, model, d_e_pair[0], d_gather_pair[0], e_count))
+        _lib.check(lib.tbk_synchronize(model))
+        split[1] = (time.perf_counter() - t1) * 1e3
+        parts = group.all_gather_array(split)
+        per_rank = {"compute_ms": [round(float(p[0]), 3) for p in parts],
+                    "allgather_ms": [round(float(p[1]), 3) for p in parts],
+                    "note": "one step, not overlapped: eigenval on the rank's slab, then the RCCL all-gather alone"}
+    host_api = None
+    if world == 1 and rank == 0 and not args.construct_only:
+        # SURVEY 8(d) "Evidence": wall-clock through the drop-in surface -- host k in, host eigenvalues out (H2D of k,
+        # all kernels, the non-finite check, D2H), i.e. tbk_eigenval, what Model.eigenval_array calls; plus the
+        # reference's return type (a Python list of row arrays, _tb_model.py:1148-1150)
+        e_host = np.empty((nk_gpu, n_orb))
+        _lib.check(lib.tbk_eigenval(model, _lib.ptr(k_slab), nk_gpu, _lib.ptr(e_host)))  # sizes the staging buffers
+        t1 = time.perf_counter()
+        _lib.check(lib.tbk_eigenval(model, _lib.ptr(k_slab), nk_gpu, _lib.ptr(e_host)))
+        dt_call = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        as_list = list(e_host)
+        dt_list = time.perf_counter() - t1
+        del as_list
+        host_api = {
+            "value": round(nk_gpu / dt_call, 1), "unit": "k-points/s", "ms_per_call": round(dt_call * 1e3, 3),
+            "includes": "H2D of k, all kernels, non-finite check, D2H of eigenvalues (tbk_eigenval on host buffers)",
+            "list_return_ms": round(dt_list * 1e3, 3),
+            "value_with_list_return": round(nk_gpu / (dt_call + dt_list), 1),
+        }
+        _lib.check(lib.tbk_get_timing(model, None, None, 1))  # drop the stage events of these two extra calls
+    peak_measured = None
+    if rank == 0 and arrays["kind"] == "dense" and os.environ.get("TBK_BENCH_SKIP_PEAK") != "1":
+        tf = ctypes.c_double(0.0)
+        _lib.check(lib.tbk_mfma_f64_peak(device, ctypes.byref(tf)))  # ~1 s: a bare v_mfma_f64_16x16x4_f64 loop
+        peak_measured = round(tf.value, 2)
 
     # --- correctness checks on rank 0 (after the clock stopped) ----------------------------------
     # (i) the first k-points of the slab against the oracle (with the CPU baseline below);
@@ -401,31 +459,35 @@ def main():
         hk_ms_avg = stage_ms["hk"] / hk_launches
         k_per_launch = nk_gpu * args.steps / hk_launches
         if arrays["kind"] == "dense":
-            achieved = f_k * k_per_launch / (hk_ms_avg * 1e-3) / 1e12 if hk_ms_avg > 0 else 0.0
+            secs = hk_ms_avg * 1e-3
+            algorithmic = f_k * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
+            executed = f_exec * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
             traffic, traffic_src = (None, None)
             if args.config == "cfg2" and not args.nr:
                 traffic, traffic_src = measured_traffic("hk_dense", k_per_launch)
             roofline = {
-                "kernel": "hk_dense_kernel", "bound": "mfma", "achieved": round(achieved, 3),
-                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                "kernel": "hk_dense_kernel", "bound": "mfma",
+                # the flops the matrix pipe EXECUTES: the staged operand is real and symmetrised, only the packed
+                # upper triangle is contracted -- half of SURVEY 8d's 8 N^2 N_R per k-point
+                "achieved": round(executed, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(executed / FP64_MFMA_PEAK_TFLOPS, 4),
+                "peak_measured": peak_measured,
+                "frac_of_peak_measured": round(executed / peak_measured, 4) if peak_measured else None,
+                "achieved_algorithmic": round(algorithmic, 3),
+                "algorithmic_speedup": round(f_k / f_exec, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE+WRITE_SIZE)",
                 "traffic_source": traffic_src,
+                "hbm_frac": round(traffic / secs / 8.0e12, 4) if traffic and hk_ms_avg > 0 else None,
                 "algorithmic_bytes_per_launch": (16.0 * n_orb * (n_orb + 1) / 2 + 8 * dim) * k_per_launch
                                                 + 16.0 * n_orb * n_orb * n_r,
-                "executed_tflops": round(f_exec * k_per_launch / (hk_ms_avg * 1e-3) / 1e12, 3) if hk_ms_avg > 0 else 0.0,
-                # `frac` prices SURVEY 8d's algorithmic 8 N^2 N_R flops per k-point against the peak; the kernel
-                # contracts only the packed upper triangle (half those flops), so the share of the matrix pipe it
-                # actually occupies is frac_executed
-                "frac_executed": round(f_exec * k_per_launch / (hk_ms_avg * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
-                if hk_ms_avg > 0 else 0.0,
                 "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
                 "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
             }
             if args.config == "cfg4":
                 # mesh planes are evaluated on the folded model (csrc/tbk_fold.hip): the contraction executes ~13x
-                # fewer flops than the direct sum these figures price, so `frac` says how much faster than the
-                # direct path's roofline the run is, not how busy the matrix pipe was
-                roofline["note"] = "folded evaluation: frac and executed_tflops refer to the UNFOLDED flop count"
+                # fewer flops than the direct sum these figures price
+                roofline["note"] = ("folded evaluation: the flop figures price the UNFOLDED sum; the matrix pipe "
+                                    "executes far fewer, so `frac` is not its utilisation here")
         else:
             out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not args.construct_only else n_orb * n_orb)
             b_k = out_bytes + 8 * dim
@@ -477,11 +539,15 @@ def main():
                 "sharding": "contiguous k slabs, hoppings replicated, all-gather of eigenvalue slabs" if world > 1
                             else "single GPU",
                 "collective": collective,
+                "rccl_ranks": rccl_ranks,
                 "eigensolver": args.eigensolver,
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
+            "host_api": host_api,
+            "rccl_ranks": rccl_ranks,
+            "per_rank": per_rank,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "max_abs_err_vs_oracle": parity,
             "max_trace_identity_err_4096_rows": trace_err,

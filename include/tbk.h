@@ -25,7 +25,8 @@
  *     message of the calling thread's last failure;
  *   - "host" entry points take caller-owned host memory and return when the result is in it;
  *     "device" entry points take device pointers on the model's device, enqueue on the model's
- *     stream and return without synchronising (tbk_synchronize waits);
+ *     streams and return without synchronising and without reading device memory back
+ *     (tbk_synchronize waits);
  *   - a handle's staged model is immutable after creation (re-create it when model.hop changes);
  *     host threads calling into ONE handle are serialised by a lock inside it (they share its
  *     workspaces and streams); different handles are independent and run concurrently.
@@ -94,6 +95,9 @@ void tbk_model_destroy(tbk_model* m);
 int tbk_model_set_option(tbk_model* m, int option, int64_t value);
 int tbk_model_info(const tbk_model* m, int* device, int* dim, int* n_orb, int64_t* n_r,
                    int* is_sparse, int64_t* staged_bytes);
+/* Event counters of a handle since its creation (which path the eigenvalue calls took). */
+enum { TBK_CNT_EIGENVAL_CALLS = 0, TBK_CNT_FOLDED_CALLS = 1, TBK_CNT_FOLDED_KPOINTS = 2, TBK_CNT_COUNT = 3 };
+int tbk_model_counter(tbk_model* m, int counter, int64_t* value);
 
 /* ---- the hot path, host buffers (what Model.hamilton / Model.eigenval call) -------------- */
 
@@ -108,6 +112,12 @@ int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E_out);
 int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, int convention,
                         const double* d_pos, double* d_H);
 int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E);
+/* The same for a caller that still holds the host array it uploaded: h_k == the contents of d_k (or NULL).
+ * Device-resident lists are never read back -- that would synchronise -- so long runs of one shared k component
+ * (uniform meshes in meshgrid order, stacks of planes; TBK_OPT_FOLD) are only recognised through h_k: the run
+ * STRUCTURE and the shared-component values are taken from h_k, everything else from d_k.  tbk_eigenval_device is
+ * this call with h_k = NULL (never folds); tbk_eigenval (host buffers) always has the list. */
+int tbk_eigenval_device_hint(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E);
 /* Check the info flags of the eigenvalue calls since the last check (synchronises). */
 int tbk_eigenval_check(tbk_model* m);
 int tbk_synchronize(tbk_model* m);
@@ -144,6 +154,8 @@ int tbk_get_timing(tbk_model* m, double* ms, int64_t* launches, int reset);
 int tbk_comm_unique_id(void* id128);
 int tbk_comm_create(int device, int world_size, int rank, const void* id128, tbk_comm** out);
 void tbk_comm_destroy(tbk_comm* c);
+/* Size of the communicator and this process' rank in it, as RCCL reports them (ncclCommCount / ncclCommUserRank). */
+int tbk_comm_ranks(tbk_comm* c, int* count, int* rank);
 /* All-gather of per-rank eigenvalue slabs: every rank contributes `count` doubles from d_send and
  * receives world_size * count doubles in rank order in d_recv.  Enqueued on `m`'s stream. */
 int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,

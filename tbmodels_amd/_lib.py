@@ -24,6 +24,7 @@ TBK_ERR_NO_CONVERGENCE = 5
 
 TBK_EIG_AUTO, TBK_EIG_WAVE, TBK_EIG_ROCSOLVER = 0, 1, 2
 TBK_OPT_EIGENSOLVER, TBK_OPT_K_CHUNK, TBK_OPT_TIMING, TBK_OPT_FOLD = 1, 2, 3, 4
+TBK_CNT_EIGENVAL_CALLS, TBK_CNT_FOLDED_CALLS, TBK_CNT_FOLDED_KPOINTS = 0, 1, 2
 TBK_T_PHASE, TBK_T_HK, TBK_T_EIG, TBK_T_QL, TBK_T_COUNT = 0, 1, 2, 3, 4
 STAGE_NAMES = ("phase", "hk", "eig", "ql")
 
@@ -50,6 +51,8 @@ SIGNATURES = {
     "tbk_eigenval": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "tbk_hamilton_device": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _vp]),
     "tbk_eigenval_device": (_c_int, [_vp, _vp, _c_i64, _vp]),
+    "tbk_eigenval_device_hint": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),
+    "tbk_model_counter": (_c_int, [_vp, _c_int, ctypes.POINTER(_c_i64)]),
     "tbk_eigenval_check": (_c_int, [_vp]),
     "tbk_synchronize": (_c_int, [_vp]),
     "tbk_kdotp_create": (_c_int, [_c_int, _c_int, _c_int, _c_i64, _vp, _vp, _pp]),
@@ -66,6 +69,7 @@ SIGNATURES = {
     "tbk_comm_unique_id": (_c_int, [_vp]),
     "tbk_comm_create": (_c_int, [_c_int, _c_int, _c_int, _vp, _pp]),
     "tbk_comm_destroy": (None, [_vp]),
+    "tbk_comm_ranks": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "tbk_comm_allgather_f64": (_c_int, [_vp, _vp, _vp, _vp, _c_i64]),
     "tbk_comm_allgather_f64_overlapped": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int]),
     "tbk_comm_wait_slot": (_c_int, [_vp, _vp, _c_int]),

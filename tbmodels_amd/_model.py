@@ -70,8 +70,44 @@ class _HopDict(co.defaultdict):
         self.exposed = False
         self.version = 0
 
-    def __reduce__(self):  # the defaultdict protocol iterates items(): keep that from marking the source
-        return (type(self), (self.default_factory,), None, None, iter(dict.items(self)))
+    def __reduce__(self):
+        # pickle: the items are set through __setitem__ (which marks the new dict exposed) and the state is applied
+        # AFTER them -- nobody holds references into a freshly unpickled dict, so it starts clean.  Iterating with
+        # dict.items keeps pickling from marking the SOURCE exposed.
+        return (type(self), (self.default_factory,), {"exposed": False, "version": 0}, None, iter(dict.items(self)))
+
+    def __copy__(self):  # copy.copy(model.hop): the copy shares every matrix with the source
+        self.exposed = True
+        new = type(self)(self.default_factory)
+        dict.update(new, self)
+        new.exposed = True
+        return new
+
+    def __deepcopy__(self, memo):  # private copies of the matrices: a clean dict
+        import copy as _copy  # pylint: disable=import-outside-toplevel
+
+        new = type(self)(self.default_factory)
+        for key, value in dict.items(self):
+            dict.__setitem__(new, key, _copy.deepcopy(value, memo))
+        return new
+
+    def __iter__(self):
+        # overriding __iter__ takes dict(hop), {**hop} and dict.update(other, hop) off CPython's exact-dict fast path:
+        # they then go through keys() + __getitem__, which marks the exposure
+        return dict.__iter__(self)
+
+    def __or__(self, other):  # hop | {...}: the result holds the same matrix objects
+        self.exposed = True
+        return co.defaultdict.__or__(self, other)
+
+    def __ror__(self, other):
+        self.exposed = True
+        return co.defaultdict.__ror__(self, other)
+
+    def __ior__(self, other):  # hop |= {...}: contents change behind the edit counter
+        self.exposed = True
+        dict.update(self, other)
+        return self
 
     def __getitem__(self, key):
         self.exposed = True
@@ -474,11 +510,10 @@ class Model:
         return state
 
     def __setstate__(self, state):
+        # (the hop dict's exposure flag / edit counter are NOT touched here: copy.copy(model) shares the dict with
+        # the original, whose handed-out references stay live; a pickled dict resets itself in _HopDict.__reduce__)
         self.__dict__.update(state)
         self._call_lock = threading.RLock()
-        if isinstance(self.hop, _HopDict):  # nobody outside holds references into a freshly unpickled model
-            self.hop.exposed = False
-            self.hop.version = 0
 
     def __del__(self):
         self._drop_staging()

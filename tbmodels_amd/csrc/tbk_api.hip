@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <new>
 #include <vector>
@@ -58,6 +59,43 @@ void DevBuf::release() {
     bytes = 0;
 }
 
+// roctx ranges (rocprofv3 --marker-trace labels the timeline with them): the tools library is looked up at run time,
+// so libtbk.so has no link-time dependency on it; ranges are only pushed while TBK_OPT_TIMING is on.
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi& roctx_api() {
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            a.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (a.push && a.pop) break;
+            a.push = nullptr;
+            a.pop = nullptr;
+        }
+        return a;
+    }();
+    return api;
+}
+const char* const kStageNames[TBK_T_COUNT] = {"tbk:phase_rows", "tbk:hk_contraction", "tbk:tridiag_reduction",
+                                              "tbk:tridiag_eigenvalues"};
+}  // namespace
+
+void tbk_range_push(const char* name) {
+    const RoctxApi& api = roctx_api();
+    if (api.push) (void)api.push(name);
+}
+
+void tbk_range_pop() {
+    const RoctxApi& api = roctx_api();
+    if (api.pop) (void)api.pop();
+}
+
 StageTimer::StageTimer(tbk_model* m_, int stage, hipStream_t s)
     : m(m_), on(m_->timing), stream(s ? s : m_->stream) {
     ev.stage = stage;
@@ -66,6 +104,7 @@ StageTimer::StageTimer(tbk_model* m_, int stage, hipStream_t s)
             on = false;
             return;
         }
+        tbk_range_push(kStageNames[stage]);
         (void)hipEventRecord(ev.start, stream);
     }
 }
@@ -73,6 +112,7 @@ StageTimer::StageTimer(tbk_model* m_, int stage, hipStream_t s)
 StageTimer::~StageTimer() {
     if (on) {
         (void)hipEventRecord(ev.stop, stream);
+        tbk_range_pop();
         m->events.push_back(ev);
     }
 }
@@ -551,33 +591,9 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
 static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E, bool* done) {
     *done = false;
     if (!m->fold_enabled || m->sparse || m->kdotp || m->dim < 2 || m->n_r < 64 || nk < 1024) return TBK_OK;
-    std::vector<double> host_copy;
-    if (h_k == nullptr) {
-        // device-resident k list: the run structure is read on the host (24 B per k-point) -- but only after its
-        // first 4096 points show a component with long runs (random lists stop here: 0.1 MB, not the list)
-        // The probe synchronises the stream, which would serialise back-to-back asynchronous calls: a (pointer,
-        // length) pair that did not qualify is remembered and not probed again (a miss only costs the shortcut).
-        if (d_k == m->fold_miss_ptr && nk == m->fold_miss_nk) return TBK_OK;
-        const int64_t probe = std::min<int64_t>(nk, 4096);
-        host_copy.resize((size_t)nk * m->dim);
-        TBK_HIP(hipMemcpyAsync(host_copy.data(), d_k, (size_t)probe * m->dim * sizeof(double), hipMemcpyDeviceToHost,
-                               m->stream));
-        TBK_HIP(hipStreamSynchronize(m->stream));
-        bool plausible = false;
-        for (int d = 0; d < m->dim && !plausible; ++d) {
-            int64_t changes = 0;
-            for (int64_t i = 1; i < probe; ++i) changes += host_copy[(size_t)i * m->dim + d] != host_copy[(size_t)(i - 1) * m->dim + d];
-            plausible = changes * tbk_fold_min_run() < probe;
-        }
-        if (!plausible) {
-            m->fold_miss_ptr = d_k;
-            m->fold_miss_nk = nk;
-            return TBK_OK;
-        }
-        TBK_HIP(hipMemcpyAsync(host_copy.data(), d_k, host_copy.size() * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-        TBK_HIP(hipStreamSynchronize(m->stream));
-        h_k = host_copy.data();
-    }
+    // Device-resident lists are never read back (include/tbk.h: the device entry points enqueue and return): the run
+    // structure comes from the caller's host copy of the list (tbk_eigenval / tbk_eigenval_device_hint) or not at all.
+    if (h_k == nullptr) return TBK_OK;
     std::vector<int64_t> runs;
     const int f = tbk_fold_choose(m, h_k, nk, runs);
     if (f < 0) return TBK_OK;
@@ -696,6 +712,8 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
         return TBK_OK;
     };
     TBK_CHECK(eigenval_wave_pipeline(m, d_k, nk, d_E, &folded));
+    m->counters[TBK_CNT_FOLDED_CALLS] += 1;
+    m->counters[TBK_CNT_FOLDED_KPOINTS] += nk;
     *done = true;
     return TBK_OK;
 }
@@ -708,6 +726,7 @@ static int eigenval_device_solve(tbk_model* m, const double* d_k, const double* 
     TBK_ARG(d_k && d_E, "k / E is NULL");
     TBK_HIP(hipSetDevice(m->device));
     m->call_nk = nk;
+    m->counters[TBK_CNT_EIGENVAL_CALLS] += 1;
     if (m->eigensolver == TBK_EIG_WAVE && !tbk_eig_small_supported(m->n_orb)) {
         tbk_set_error("TBK_EIG_WAVE handles n_orb <= 64 only (n_orb = %d)", m->n_orb);
         return TBK_ERR_ARGUMENT;
@@ -765,6 +784,18 @@ static int eigenval_device_impl(tbk_model* m, const double* d_k, const double* h
 
 extern "C" int tbk_eigenval_device(tbk_model* m, const double* d_k, int64_t nk, double* d_E) {
     return eigenval_device_impl(m, d_k, nullptr, nk, d_E);
+}
+
+extern "C" int tbk_eigenval_device_hint(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E) {
+    return eigenval_device_impl(m, d_k, h_k, nk, d_E);
+}
+
+extern "C" int tbk_model_counter(tbk_model* m, int counter, int64_t* value) {
+    TBK_ARG(m != nullptr && value != nullptr, "model / value is NULL");
+    TBK_ARG(counter >= 0 && counter < TBK_CNT_COUNT, "unknown counter");
+    TBK_LOCK(m);
+    *value = m->counters[counter];
+    return TBK_OK;
 }
 
 extern "C" int tbk_synchronize(tbk_model* m) {

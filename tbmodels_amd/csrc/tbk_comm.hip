@@ -95,7 +95,10 @@ extern "C" int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d
     if (count == 0) return TBK_OK;
     TBK_ARG(d_send && d_recv, "send / recv is NULL");
     TBK_HIP(hipSetDevice(c->device));
-    TBK_NCCL(ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, m->stream));
+    if (m->timing) tbk_range_push("tbk:allgather_eigenvalues");
+    const ncclResult_t r = ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, m->stream);
+    if (m->timing) tbk_range_pop();
+    TBK_NCCL(r);
     return TBK_OK;
 }
 
@@ -113,7 +116,10 @@ extern "C" int tbk_comm_allgather_f64_overlapped(tbk_comm* c, tbk_model* m, cons
     TBK_HIP(hipSetDevice(c->device));
     TBK_HIP(hipEventRecord(c->ready, m->stream));
     TBK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
-    TBK_NCCL(ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, c->stream));
+    if (m->timing) tbk_range_push("tbk:allgather_eigenvalues(overlapped)");
+    const ncclResult_t r = ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, c->stream);
+    if (m->timing) tbk_range_pop();
+    TBK_NCCL(r);
     TBK_HIP(hipEventRecord(c->done[slot], c->stream));
     return TBK_OK;
 }
@@ -123,6 +129,18 @@ extern "C" int tbk_comm_wait_slot(tbk_comm* c, tbk_model* m, int slot) {
     TBK_ARG(slot == 0 || slot == 1, "bad slot");
     TBK_HIP(hipSetDevice(c->device));
     TBK_HIP(hipStreamWaitEvent(m->stream, c->done[slot], 0));  // no-op if the slot was never used
+    return TBK_OK;
+}
+
+// Ranks that joined the communicator, as RCCL itself reports it (ncclCommCount) -- evidence that a multi-GPU run
+// really went through an N-rank communicator.
+extern "C" int tbk_comm_ranks(tbk_comm* c, int* count, int* rank) {
+    TBK_ARG(c != nullptr && count != nullptr, "comm / count is NULL");
+    int n = 0, r = 0;
+    TBK_NCCL(ncclCommCount(c->comm, &n));
+    TBK_NCCL(ncclCommUserRank(c->comm, &r));
+    *count = n;
+    if (rank) *rank = r;
     return TBK_OK;
 }
 

@@ -164,8 +164,7 @@ struct tbk_model {
     std::vector<int32_t> h_R;  // host copy of the lattice vectors [n_r][dim]
     tbk_fold_plan_t fold[TBK_MAX_DIM];
     bool fold_enabled = true;
-    const double* fold_miss_ptr = nullptr;  // last device k list that did not qualify (not probed again)
-    int64_t fold_miss_nk = 0;
+    int64_t counters[TBK_CNT_COUNT] = {0, 0, 0};  // tbk_model_counter
 
     // --- options ---
     int eigensolver = TBK_EIG_AUTO;
@@ -203,6 +202,10 @@ struct tbk_model {
 struct tbk_kdotp {
     tbk_model* core = nullptr;  // the dense pipeline with monomial rows in place of phase rows
 };
+
+// roctx range around a stage (no-ops unless a roctx library can be loaded); tbk_api.hip
+void tbk_range_push(const char* name);
+void tbk_range_pop();
 
 // timing scope helper: records a start/stop pair on the model stream when timing is on
 struct StageTimer {

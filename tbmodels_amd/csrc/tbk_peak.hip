@@ -18,10 +18,13 @@ __global__ void __launch_bounds__(256) mfma_f64_loop(double* out, int iters, dou
     for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
     double a = seed == 0.0 ? 0.0 : seed + threadIdx.x * 1e-3;
     double b = seed == 0.0 ? 0.0 : seed - threadIdx.x * 1e-3;
+    // The accumulators are pinned to VGPRs by the constraint: written with the builtin, hipcc moved all 64
+    // accumulator registers between VGPRs and AGPRs on every trip (128 v_accvgpr moves per 8 MFMAs: the loop
+    // reported 47 TFLOP/s while the H(k) kernel sustained 68).
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
     double s = 0.0;
 #pragma unroll

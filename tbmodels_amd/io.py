@@ -12,6 +12,7 @@ layouts are the ones ``fsc.hdf5_io`` produces, so files travel between the two p
                                    ``hop/<i>/{R, data, indices, indptr, shape}`` (`_tb_model.py:1038-1058`)
 ``[bands_inspect.]kpoints_explicit``  ``kpoints`` ``(NK, dim)`` float64
 ``bands_inspect.eigenvals_data``   ``kpoints_obj`` (a k-points object), ``eigenvals`` ``(NK, N)`` float64
+``tbmodels.kdotp_model``           ``taylor_coefficients`` (``kdotp.py:19-36``; dict of power tuple -> matrix)
 (no tag, ``hop`` present)          legacy model file: loaded with a ``DeprecationWarning`` (`io.py:30-40`)
 =================================  ==================================================================
 """
@@ -91,6 +92,10 @@ def _decode(tree):
     tag = tree.get("type_tag") if isinstance(tree, dict) else None
     if tag == "tbmodels.model":
         return Model.from_hdf5(tree)
+    if tag == "tbmodels.kdotp_model":
+        from .kdotp import KdotpModel  # pylint: disable=import-outside-toplevel
+
+        return KdotpModel.from_hdf5(tree)
     if tag in ("kpoints_explicit", "bands_inspect.kpoints_explicit"):
         return KpointsExplicit.from_hdf5(tree)
     if tag in ("eigenvals_data", "bands_inspect.eigenvals_data"):

@@ -31,12 +31,15 @@ class KdotpModel:
             tuple(key): np.array(mat, dtype=complex) for key, mat in taylor_coefficients.items()
         }
         self._handle = None
+        self._staged_key = None
+        self._pinned = False
         self._call_lock = threading.RLock()
         self.device = 0
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_handle"] = None
+        state["_staged_key"] = None
         state.pop("_call_lock", None)
         return state
 
@@ -45,6 +48,9 @@ class KdotpModel:
         self._call_lock = threading.RLock()
 
     def __del__(self):
+        self._drop_staging()
+
+    def _drop_staging(self):
         handle = getattr(self, "_handle", None)
         if handle is not None:
             try:
@@ -52,6 +58,35 @@ class KdotpModel:
             except Exception:  # pylint: disable=broad-except
                 pass
         self._handle = None
+        self._staged_key = None
+
+    def pin_staging(self, pinned=True):
+        """Skip the per-call content check of ``taylor_coefficients`` (the caller promises not to edit them)."""
+        self._pinned = bool(pinned)
+
+    def _staging_key(self):
+        """What the staged copy is valid for: device, the power tuples in order, and the coefficient bytes.
+        ``taylor_coefficients`` is a public, mutable dict that the reference reads on every call
+        (``kdotp.py:51-82``), so the content is re-validated per call like ``Model``'s hoppings."""
+        try:
+            import xxhash  # pylint: disable=import-outside-toplevel
+
+            running = xxhash.xxh3_64()
+            update = running.update
+            digest = running.intdigest
+        except ImportError:  # pragma: no cover
+            import hashlib  # pylint: disable=import-outside-toplevel
+
+            running = hashlib.blake2b(digest_size=8)
+            update = running.update
+            digest = running.digest
+        keys = []
+        for key, mat in self.taylor_coefficients.items():
+            keys.append(tuple(key))
+            arr = np.ascontiguousarray(mat, dtype=np.complex128)
+            keys.append(arr.shape)
+            update(arr.view(np.uint8).reshape(-1).data)
+        return (int(self.device), tuple(keys), digest())
 
     def _shape(self):
         if not self.taylor_coefficients:
@@ -64,7 +99,13 @@ class KdotpModel:
             return self._staged_locked()
 
     def _staged_locked(self):
+        key = None
+        if self._handle is not None and not self._pinned:
+            key = self._staging_key()
+            if key != self._staged_key:
+                self._drop_staging()
         if self._handle is None:
+            key = key if key is not None else self._staging_key()
             dim, size = self._shape()
             keys = list(self.taylor_coefficients.keys())
             powers = np.array(keys, dtype=np.int32).reshape(len(keys), dim)
@@ -76,6 +117,7 @@ class KdotpModel:
                 )
             )
             self._handle = handle
+            self._staged_key = key
         return self._handle
 
     def _k_array(self, k):
@@ -96,7 +138,8 @@ class KdotpModel:
         k_array, single = self._k_array(k)
         _, size = self._shape()
         out = _outbuf.empty((k_array.shape[0], size, size), np.complex128)
-        _lib.check(_lib.lib().tbk_kdotp_hamilton(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
+        with self._call_lock:  # re-validating the staged copy and the call are one step for other threads
+            _lib.check(_lib.lib().tbk_kdotp_hamilton(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
         return out[0] if single else out
 
     def eigenval(self, k):
@@ -109,5 +152,56 @@ class KdotpModel:
         k_array, single = self._k_array(k)
         _, size = self._shape()
         out = _outbuf.empty((k_array.shape[0], size), np.float64)
-        _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
+        with self._call_lock:
+            _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
         return out[0] if single else out
+
+    # ------------------------------------------------------------------ HDF5 (``tbmodels.kdotp_model``)
+    def to_hdf5(self):
+        """
+        The tree ``hdf5_lite.write`` stores for the reference's ``SimpleHDF5Mapping`` serialisation of this class
+        (``kdotp.py:19-36``: one attribute, ``taylor_coefficients``, a dict with tuple keys).  The dict / tuple
+        layout follows ``fsc.hdf5_io`` 1.0.x as far as it can be told without the package (not installed here, and
+        the reference ships no such file): ``builtins.dict`` = ``keys`` + ``values`` lists.
+        """
+        def number(x):
+            return {"type_tag": "builtins.number", "value": np.int64(x)}
+
+        def sequence(tag, items):
+            tree = {"type_tag": tag}
+            tree.update({str(i): item for i, item in enumerate(items)})
+            return tree
+
+        keys = [sequence("builtins.tuple", [number(x) for x in key]) for key in self.taylor_coefficients]
+        values = [{"type_tag": "numpy.ndarray", "value": np.asarray(mat, dtype=complex)}
+                  for mat in self.taylor_coefficients.values()]
+        return {
+            "type_tag": "tbmodels.kdotp_model",
+            "taylor_coefficients": {
+                "type_tag": "builtins.dict",
+                "keys": sequence("builtins.list", keys),
+                "values": sequence("builtins.list", values),
+            },
+        }
+
+    @classmethod
+    def from_hdf5(cls, tree):
+        """Inverse of :meth:`to_hdf5`; also accepts the ``items`` (list of pairs) form of a ``builtins.dict``."""
+        def plain(node):
+            if isinstance(node, dict):
+                tag = node.get("type_tag")
+                if isinstance(tag, bytes):
+                    tag = tag.decode()
+                if tag in ("builtins.list", "builtins.tuple"):
+                    items = [plain(node[name]) for name in sorted((n for n in node if n != "type_tag"), key=int)]
+                    return tuple(items) if tag == "builtins.tuple" else items
+                if "value" in node:
+                    return node["value"]
+            return node
+
+        coeff = tree["taylor_coefficients"]
+        if "items" in coeff:
+            pairs = plain(coeff["items"])
+        else:
+            pairs = zip(plain(coeff["keys"]), plain(coeff["values"]))
+        return cls({tuple(int(x) for x in key): np.array(mat) for key, mat in pairs})

@@ -18,7 +18,6 @@ The data path (eigenvalue slabs) never goes through these on a GPU box: it is th
 """
 
 import os
-import shutil
 import time
 
 import numpy as np
@@ -26,27 +25,53 @@ import numpy as np
 __all__ = ("FileGroup", "TorchGroup", "group_from_env")
 
 
-class FileGroup:
-    """Single-node process group backed by a shared directory (``/dev/shm`` when available)."""
+def _run_token():
+    """
+    A string that is the same in every rank of ONE launch and differs between launches: the launcher's pid plus its
+    start time (``/proc/<ppid>/stat`` field 22, so a recycled pid does not collide).  ``TBK_RDZV_TOKEN`` overrides it
+    for ranks that do not share a parent process.
+    """
+    token = os.environ.get("TBK_RDZV_TOKEN")
+    if token:
+        return token
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as handle:
+            start = handle.read().rsplit(")", 1)[1].split()[19]  # field 22 (starttime), counted after "(comm)"
+    except (OSError, IndexError):
+        pass
+    return "%d-%s" % (ppid, start)
 
-    def __init__(self, rank, world, path, poll_s=2e-4, timeout_s=600.0):
+
+class FileGroup:
+    """
+    Single-node process group backed by a shared directory (``/dev/shm`` when available).
+
+    Every file name carries the launch's run token (:func:`_run_token`): a directory that still holds the files of an
+    earlier, crashed run -- a reused ``TBK_RDZV_DIR`` -- cannot feed this run a stale RCCL id or stale slabs.
+    """
+
+    def __init__(self, rank, world, path, poll_s=2e-4, timeout_s=600.0, token=None):
         self.rank = int(rank)
         self.world = int(world)
         self.path = path
         self.poll_s = poll_s
         self.timeout_s = timeout_s
+        self.token = token or _run_token()
         self._seq = 0
         os.makedirs(path, exist_ok=True)
 
     # -- primitives ---------------------------------------------------------------------------
     def _put(self, name, data):
+        name = "%s.%s" % (self.token, name)
         tmp = os.path.join(self.path, ".%s.%d.tmp" % (name, self.rank))
         with open(tmp, "wb") as handle:
             handle.write(data)
         os.replace(tmp, os.path.join(self.path, name))  # atomic: readers never see a partial file
 
     def _get(self, name):
-        target = os.path.join(self.path, name)
+        target = os.path.join(self.path, "%s.%s" % (self.token, name))
         deadline = time.monotonic() + self.timeout_s
         while True:
             try:
@@ -100,7 +125,17 @@ class FileGroup:
             return
         for r in range(1, self.world):
             self._get("bye.r%d" % r)
-        shutil.rmtree(self.path, ignore_errors=True)
+        # this run's files only: the directory may be a user-supplied one that other runs share
+        for name in os.listdir(self.path):
+            if name.startswith(self.token + ".") or name.startswith("." + self.token + "."):
+                try:
+                    os.unlink(os.path.join(self.path, name))
+                except OSError:
+                    pass
+        try:
+            os.rmdir(self.path)
+        except OSError:
+            pass
 
 
 class TorchGroup:

@@ -65,6 +65,7 @@ class ShardedEigenval:
         self.device = device
         self.evaluate = evaluate
         self._comm = None
+        self._buffers = {}  # name -> (device pointer, bytes): reused from call to call
         if device is not None:
             model.device = int(device)
 
@@ -82,6 +83,9 @@ class ShardedEigenval:
         return self._comm
 
     def close(self):
+        for pointer, _ in self._buffers.values():
+            _lib.lib().tbk_device_free(self.device, pointer)
+        self._buffers = {}
         if self._comm is not None:
             _lib.lib().tbk_comm_destroy(self._comm)
             self._comm = None
@@ -106,39 +110,84 @@ class ShardedEigenval:
     def _host_gather(self, k, start, stop, per, n_k, n_orb):
         evaluate = self.evaluate or (lambda ks: np.array(self.model.eigenval(ks)).reshape(len(ks), n_orb))
         slab = np.zeros((per, n_orb), dtype=np.float64)
+        failure = None
         if stop > start:
-            slab[: stop - start] = np.asarray(evaluate(k[start:stop])).reshape(stop - start, n_orb)
+            try:
+                slab[: stop - start] = np.asarray(evaluate(k[start:stop])).reshape(stop - start, n_orb)
+            except (ValueError, np.linalg.LinAlgError) as exc:  # e.g. NaN in this rank's slab only
+                failure = exc
+        # all ranks take the same branch: the failure of one is raised on every rank, after the same collectives
+        failed = self.group.allreduce_max(1.0 if failure is not None else 0.0)
         pieces = self.group.all_gather_array(slab)
+        if failure is not None:
+            raise failure
+        if failed:
+            raise ValueError("a peer rank failed while evaluating its k slab")
         return np.concatenate(pieces, axis=0)[:n_k].copy()
 
     def _device_gather(self, k, start, stop, per, n_k, n_orb):
         with self.model._call_lock:  # pylint: disable=protected-access  # staged handle stays valid for the whole exchange
             return self._device_gather_locked(k, start, stop, per, n_k, n_orb)
 
+    def _buffer(self, name, nbytes):
+        """Persistent device buffer `name` of at least `nbytes` (grow-only: no malloc / free -- each one a device
+        synchronisation -- on the calls after the largest one)."""
+        have = self._buffers.get(name)
+        if have is not None and have[1] >= nbytes:
+            return have[0]
+        lib = _lib.lib()
+        if have is not None:
+            lib.tbk_device_free(self.device, have[0])
+            del self._buffers[name]
+        p = ctypes.c_void_p()
+        size = max(int(nbytes), 8)
+        _lib.check(lib.tbk_device_malloc(self.device, size, ctypes.byref(p)))
+        self._buffers[name] = (p, size)
+        return p
+
     def _device_gather_locked(self, k, start, stop, per, n_k, n_orb):
         lib = _lib.lib()
         handle = self.model._staged()  # pylint: disable=protected-access
         comm = self._communicator()
         dev = self.device
-
-        def dmalloc(nbytes):
-            p = ctypes.c_void_p()
-            _lib.check(lib.tbk_device_malloc(dev, max(nbytes, 8), ctypes.byref(p)))
-            return p
-
         k_slab = np.ascontiguousarray(k[start:stop])
-        d_k = dmalloc(k_slab.nbytes)
-        d_send = dmalloc(per * n_orb * 8)
-        d_recv = dmalloc(self.world * per * n_orb * 8)
-        try:
-            if stop > start:
-                _lib.check(lib.tbk_memcpy_h2d(dev, d_k, _lib.ptr(k_slab), k_slab.nbytes))
-                _lib.check(lib.tbk_eigenval_device(handle, d_k, stop - start, d_send))
-            _lib.check(lib.tbk_comm_allgather_f64(comm, handle, d_send, d_recv, per * n_orb))
-            _lib.check(lib.tbk_eigenval_check(handle))  # synchronises
-            out = np.empty((self.world * per, n_orb), dtype=np.float64)
-            _lib.check(lib.tbk_memcpy_d2h(dev, _lib.ptr(out), d_recv, out.nbytes))
-        finally:
-            for p in (d_k, d_send, d_recv):
-                lib.tbk_device_free(dev, p)
+        d_k = self._buffer("k", k_slab.nbytes)
+        d_send = self._buffer("send", per * n_orb * 8)
+        d_recv = self._buffer("recv", self.world * per * n_orb * 8)
+        # Every rank goes through the SAME sequence of collectives whatever happens locally: a rank that raised
+        # before the all-gather (or after it, on a NaN in its own slab only) would leave the others hanging in the
+        # next collective.  Local failures are carried as a status and reduced over the ranks before anyone raises.
+        status, message = 0, ""
+        if stop > start:
+            status = lib.tbk_memcpy_h2d(dev, d_k, _lib.ptr(k_slab), k_slab.nbytes)
+            if status == 0:
+                # the host slab goes along as the structure hint: mesh slabs are folded (include/tbk.h)
+                status = lib.tbk_eigenval_device_hint(handle, d_k, _lib.ptr(k_slab), stop - start, d_send)
+            if status != 0:
+                message = _lib.last_error()
+        gather_status = lib.tbk_comm_allgather_f64(comm, handle, d_send, d_recv, per * n_orb)
+        if gather_status != 0 and status == 0:
+            status, message = gather_status, _lib.last_error()
+        check_status = lib.tbk_eigenval_check(handle)  # synchronises; non-finite / non-converged flags of THIS rank
+        if check_status != 0 and status == 0:
+            status, message = check_status, _lib.last_error()
+        worst = int(self.group.allreduce_max(float(status)))
+        if worst != 0:
+            if status == 0:
+                status = worst
+                message = "a peer rank failed (status %d) while evaluating its k slab" % worst
+            _raise_status(status, message)
+        out = np.empty((self.world * per, n_orb), dtype=np.float64)
+        _lib.check(lib.tbk_memcpy_d2h(dev, _lib.ptr(out), d_recv, out.nbytes))
         return out[:n_k].copy()
+
+
+def _raise_status(status, message):
+    """The exception `_lib.check` would raise for `status`, with an explicit message."""
+    if status in (_lib.TBK_ERR_ARGUMENT, _lib.TBK_ERR_NOT_FINITE):
+        raise ValueError(message)
+    if status == _lib.TBK_ERR_MEMORY:
+        raise MemoryError(message)
+    if status == _lib.TBK_ERR_NO_CONVERGENCE:
+        raise np.linalg.LinAlgError(message)
+    raise RuntimeError(message)

@@ -78,33 +78,52 @@ def test_headline_shape_intermediate_batches():
         assert np.array_equal(ham, model.hamilton(k, convention=1))  # fixed summation order
 
 
-def test_config3_sparse_shape():
-    """Config 3: CSR N_orb=256, N_R=512, 2 % fill (k list shortened: the N=256 eigensolve is ~0.1 ms per k)."""
-    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(256, 512, syn.MODEL_SEED + 3)
-    hop_dict = {}
+def _csr_model(n_orb, n_r, seed):
     import scipy.sparse as sp
 
+    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(n_orb, n_r, seed)
+    hop_dict = {}
     for idx, r in enumerate(r_vec):
         sl = slice(r_ptr[idx], r_ptr[idx + 1])
-        hop_dict[tuple(int(x) for x in r)] = sp.csr_matrix((val[sl], (row[sl], col[sl])), shape=(256, 256))
-    model = tbmodels_amd.Model(hop=hop_dict, pos=pos, size=256, contains_cc=False, sparse=True)
-    k = syn.random_kpoints(4096)
-    eig = np.array(model.eigenval(k))
-    assert np.all(np.diff(eig, axis=1) >= 0)
+        hop_dict[tuple(int(x) for x in r)] = sp.csr_matrix((val[sl], (row[sl], col[sl])), shape=(n_orb, n_orb))
+    model = tbmodels_amd.Model(hop=hop_dict, pos=pos, size=n_orb, contains_cc=False, sparse=True)
     diag = row == col
     traces = np.zeros(len(r_vec), dtype=complex)
     np.add.at(traces, np.searchsorted(r_ptr, np.flatnonzero(diag), side="right") - 1, val[diag])
+    return model, (r_vec, r_ptr, row, col, val, pos), traces
+
+
+def test_config3_sparse_shape_full_50k():
+    """Config 3 at full size: CSR N_orb=256, N_R=512, 2 % fill, all 50 000 random k-points (per-k independence:
+    ``_tb_model.py:1111-1123``; eigenvalues: ``:1147-1150``).  The call runs through many k chunks of the
+    reduction || bisection pipeline; every row is checked by the trace identity, 16 rows against the oracle, and the
+    rows shared with a 4096-point call / with other chunkings must come out bit-identical."""
+    model, (r_vec, r_ptr, row, col, val, pos), traces = _csr_model(256, 512, syn.MODEL_SEED + 3)
+    k = syn.random_kpoints(50_000)
+    eig = model.eigenval_array(k)
+    assert eig.shape == (50_000, 256) and np.isfinite(eig).all()
+    assert np.all(np.diff(eig, axis=1) >= 0)
     assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
     dense_hop = syn.csr_to_dense(256, r_ptr, row, col, val)
-    ref = np.array(oracle.eigenval(r_vec, dense_hop, k[:6]))
-    assert np.abs(eig[:6] - ref).max() < 1e-10
+    idx = np.sort(np.random.default_rng(5).choice(len(k), 16, replace=False))
+    ref = np.array(oracle.eigenval(r_vec, dense_hop, k[idx]))
+    assert np.abs(eig[idx] - ref).max() < 1e-10
+    # the 4096-point call of the shortened test: same rows, same bits (one chunk there, many here)
+    head = model.eigenval_array(k[:4096])
+    assert np.array_equal(head, eig[:4096])
+    # the chunking is not allowed to change anything either
+    for chunk in (1024, 3000):
+        model.set_option(_lib.TBK_OPT_K_CHUNK, chunk)
+        assert np.array_equal(model.eigenval_array(k[:9000]), eig[:9000])
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 0)
     # the sparse kernel and the dense MFMA kernel agree on H(k) (tests/test_sparse_dense.py of the reference)
     dense = tbmodels_amd.Model.from_packed(r_vec, dense_hop, pos=pos)
     assert np.abs(model.hamilton(k[:16]) - dense.hamilton(k[:16])).max() < 1e-12
+    assert np.abs(dense.eigenval_array(k[:512]) - eig[:512]).max() < 1e-11
 
 
 def test_config5_large_orbital_shape_reduced_R():
-    """Config 5 orbital count (N_orb=512, rocSOLVER path) at reduced N_R so the host model stays small."""
+    """Config 5 orbital count (N_orb=512) at reduced N_R: the quick form of the full-size test below."""
     r_vec, hop, pos = syn.dense_model_arrays(512, 64, syn.MODEL_SEED + 5)
     k = syn.random_kpoints(64)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
@@ -113,6 +132,79 @@ def test_config5_large_orbital_shape_reduced_R():
     assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
     ref = np.array(oracle.eigenval(r_vec, hop, k[:4]))
     assert np.abs(eig[:4] - ref).max() < 1e-10
+
+
+def test_config5_large_orbital_shape_full():
+    """Config 5 at full size: dense N_orb=512, N_R=2048 (8.6 GB of hoppings), 10 000 random k-points, staged straight
+    through the C ABI (the host model class would copy the 8.6 GB twice).  Trace identity on every row, 4 rows against
+    the oracle, and a second run must give the same bits (race detector for the N=512 reduction pipeline)."""
+    import ctypes
+
+    n_orb, n_r, n_k = 512, 2048, 10_000
+    r_vec, hop, _ = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 5)
+    k = syn.random_kpoints(n_k)
+    lib = _lib.lib()
+    handle = ctypes.c_void_p()
+    _lib.check(lib.tbk_model_create_dense(0, 3, n_orb, n_r, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)))
+    try:
+        eig = np.empty((n_k, n_orb))
+        _lib.check(lib.tbk_eigenval(handle, _lib.ptr(k), n_k, _lib.ptr(eig)))
+        assert np.isfinite(eig).all() and np.all(np.diff(eig, axis=1) >= 0)
+        traces = np.einsum("rii->r", hop)
+        assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+        idx = np.array([0, 3333, 6667, n_k - 1])
+        ref = np.array(oracle.eigenval(r_vec, hop, k[idx]))
+        assert np.abs(eig[idx] - ref).max() < 1e-10
+        again = np.empty_like(eig)
+        _lib.check(lib.tbk_eigenval(handle, _lib.ptr(k), n_k, _lib.ptr(again)))
+        assert np.array_equal(again, eig)
+        # a short call (one chunk; its H(k) launch is tail-split along K, so sums are ordered differently)
+        head = np.empty((700, n_orb))
+        _lib.check(lib.tbk_eigenval(handle, _lib.ptr(k), 700, _lib.ptr(head)))
+        assert np.abs(head - eig[:700]).max() < 1e-12
+    finally:
+        lib.tbk_model_destroy(handle)
+
+
+def test_config4_headline_model_on_the_100_cubed_mesh():
+    """Config 4 at full size on one GPU: the cfg2 model (N_orb=64, N_R=4096) on the 100 x 100 x 100 mesh, i.e. the
+    two-level folded evaluation (csrc/tbk_fold.hip) over 10^6 k-points, and the 8 contiguous slabs the 8-GPU run
+    hands to its ranks (``sharding.slab_bounds``), evaluated one after the other."""
+    from tbmodels_amd.sharding import slab_bounds
+
+    r_vec, hop, pos = syn.dense_model_arrays(64, 4096, syn.MODEL_SEED + 2)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.pin_staging()
+    n = 100
+    k = syn.uniform_grid(n)
+    whole = model.eigenval_array(k)
+    assert whole.shape == (n ** 3, 64) and np.isfinite(whole).all()
+    assert np.all(np.diff(whole, axis=1) >= 0)
+    # trace identity on 4096 rows drawn from the whole mesh (every chunk of the pipeline)
+    rows = np.sort(np.random.default_rng(6).choice(n ** 3, 4096, replace=False))
+    traces = np.einsum("rii->r", hop)
+    assert np.abs(whole[rows].sum(axis=1) - _trace_from_hoppings(r_vec, traces, k[rows])).max() < 1e-10
+    # 64 rows against the oracle
+    idx = np.sort(np.random.default_rng(7).choice(n ** 3, 64, replace=False))
+    ref = np.array(oracle.eigenval(r_vec, hop, k[idx]))
+    assert np.abs(whole[idx] - ref).max() < 1e-10
+    # folded against direct evaluation on three whole planes (first, an interior one, last)
+    model.set_option(_lib.TBK_OPT_FOLD, 0)
+    try:
+        for plane in (0, 37, n - 1):
+            sl = slice(plane * n * n, (plane + 1) * n * n)
+            direct = model.eigenval_array(k[sl])
+            assert np.abs(direct - whole[sl]).max() < 1e-11
+    finally:
+        model.set_option(_lib.TBK_OPT_FOLD, 1)
+    # the 8 slabs of the sharded run, concatenated, equal the whole (slab edges cut planes in half: ragged runs)
+    parts = []
+    for rank in range(8):
+        lo, hi = slab_bounds(n ** 3, 8, rank)
+        parts.append(model.eigenval_array(syn.grid_slab(n, lo, hi)))
+    assert np.abs(np.concatenate(parts) - whole).max() < 1e-11
+    # and the whole call is reproducible bit for bit
+    assert np.array_equal(model.eigenval_array(k), whole)
 
 
 def test_config4_grid_slabs_match_whole():

@@ -214,6 +214,87 @@ def test_pickle_and_copy_keep_the_source_unexposed():
     assert clone._staging_key()[0] == "version" and model._staging_key()[0] != "version"
 
 
+def test_every_route_that_hands_out_a_matrix_marks_the_dict_exposed():
+    """``dict(hop)``, ``{**hop}``, ``copy.copy(hop)`` went through C-level dict fast paths that bypassed
+    the exposure tracking, ``hop |= ...`` changed contents behind the edit counter, and ``copy.copy(model)`` reset
+    the flags of the dict it SHARES with the original: each of them left the staged copy silently stale."""
+    import copy
+
+    def fresh():
+        model = toy_model(0.1, 0.2)
+        assert model._staging_key()[0] == "version"
+        return model
+
+    routes = {
+        "dict()": lambda m: dict(m.hop),
+        "**": lambda m: {**m.hop},
+        "copy.copy(hop)": lambda m: copy.copy(m.hop),
+        "dict.update(other, hop)": lambda m: {}.update(m.hop),
+        "hop | {}": lambda m: m.hop | {},
+        "{} | hop": lambda m: {} | m.hop,
+        "list(hop.values())": lambda m: list(m.hop.values()),
+    }
+    for name, route in routes.items():
+        model = fresh()
+        route(model)
+        assert model._staging_key() == model._fingerprint(), name  # content-hashed from now on
+    # a matrix obtained through one of them, edited in place, changes the key
+    model = fresh()
+    handed_out = dict(model.hop)
+    before = model._staging_key()
+    next(iter(handed_out.values()))[0, 0] += 1.0
+    assert model._staging_key() != before
+    # |= changes the contents: the key must change
+    model = fresh()
+    before = model._staging_key()
+    model.hop |= {(7, 0, 0): np.eye(2, dtype=complex)}
+    assert model._staging_key() != before and (7, 0, 0) in model.hop
+    # keys-only access stays free
+    model = fresh()
+    assert sorted(model.hop) and list(model.hop.keys()) and len(model.hop) and (0, 0, 0) in model.hop
+    assert model._staging_key()[0] == "version"
+    # copy.copy(model) shares the dict: a reference handed out by the original stays tracked in both
+    model = fresh()
+    mat = model.hop[(0, 0, 0)]
+    clone = copy.copy(model)
+    assert clone.hop is model.hop
+    before = clone._staging_key()
+    assert before == clone._fingerprint()
+    mat[0, 0] += 1.0
+    assert clone._staging_key() != before and model._staging_key() == clone._staging_key()
+
+
+def test_kdotp_model_revalidates_its_staged_copy():
+    """``KdotpModel.taylor_coefficients`` is a public dict the reference reads on every call (kdotp.py:51-82): the
+    staging key follows edits of the matrices, of the key set and of ``device``; HDF5 round trip."""
+    from tbmodels_amd import io
+
+    kp = tbmodels_amd.KdotpModel({(0, 0, 1): np.eye(2), (1, 0, 0): np.array([[0, 1j], [-1j, 0]])})
+    key = kp._staging_key()
+    assert kp._staging_key() == key
+    kp.taylor_coefficients[(0, 0, 1)][0, 0] = 2.0
+    key2 = kp._staging_key()
+    assert key2 != key
+    kp.taylor_coefficients[(2, 0, 0)] = np.eye(2, dtype=complex)
+    key3 = kp._staging_key()
+    assert key3 != key2
+    kp.device = 1
+    assert kp._staging_key() != key3
+    clone = pickle.loads(pickle.dumps(kp))
+    assert clone._handle is None and clone._staged_key is None
+    assert clone._staging_key() == kp._staging_key()
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "kp.hdf5")
+        io.save(kp, path)
+        loaded = io.load(path)
+    assert isinstance(loaded, tbmodels_amd.KdotpModel)
+    assert list(loaded.taylor_coefficients) == list(kp.taylor_coefficients)
+    for power, mat in kp.taylor_coefficients.items():
+        assert np.array_equal(loaded.taylor_coefficients[power], mat)
+
+
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports exactly what include/tbk.h declares."""
     with open(os.path.join(ROOT, "include", "tbk.h")) as handle:

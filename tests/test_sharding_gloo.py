@@ -103,3 +103,58 @@ def test_world_size_n_allgather(tmp_path, backend, n_k, world):
         assert calls.sum() == hi - lo  # each rank evaluated exactly its slab
         total_calls += calls.sum()
     assert total_calls == n_k
+
+
+def _failing_worker(rank, world, out_dir, token):
+    sys.path.insert(0, ROOT)
+    import tbmodels_amd
+    from tbmodels_amd import synthetic as syn
+    from tbmodels_amd.rendezvous import FileGroup
+    from tbmodels_amd.sharding import ShardedEigenval
+    from oracle import tbk_oracle as oracle
+
+    group = FileGroup(rank, world, os.path.join(out_dir, "rdzv"), token=token)
+    r_vec, hop, pos = syn.dense_model_arrays(6, 10, syn.MODEL_SEED + 42)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+
+    def evaluate(k_slab):
+        if not np.isfinite(k_slab).all():  # scipy's check_finite on this rank's slab only
+            raise ValueError("array must not contain infs or NaNs")
+        return np.array(oracle.eigenval(r_vec, hop, k_slab))
+
+    sharded = ShardedEigenval(model, group, device=None, evaluate=evaluate)
+    k = syn.random_kpoints(12)
+    k[1, 0] = np.nan  # lands in rank 0's slab
+    try:
+        sharded(k)
+        outcome = "returned"
+    except ValueError:
+        outcome = "ValueError"
+    # both ranks are still in step: the next collective and a clean second call go through
+    good = sharded(syn.random_kpoints(12))
+    assert good.shape == (12, 6)
+    with open(os.path.join(out_dir, "outcome%d.txt" % rank), "w") as handle:
+        handle.write(outcome)
+    group.close()
+
+
+def test_failure_on_one_rank_is_raised_on_every_rank(tmp_path):
+    """A NaN in ONE rank's slab: every rank raises (the others used to return the gathered NaN rows and run on into
+    the next collective alone), and the group stays usable.  The rendezvous directory still holds files of an
+    earlier run with the same names: the run token keeps them out."""
+    import multiprocessing as mp
+
+    rdzv = tmp_path / "rdzv"
+    rdzv.mkdir()
+    for name in ("ag.000001.r0", "ag.000001.r1", "bc.000001", "stale-run.ag.000001.r1"):
+        (rdzv / name).write_bytes(b"\xff" * 8)  # leftovers of a crashed run (old naming and another token)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_failing_worker, args=(rank, 2, str(tmp_path), "this-run")) for rank in range(2)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(timeout=300)
+        assert proc.exitcode == 0, "worker exited with %r" % proc.exitcode
+    for rank in range(2):
+        assert (tmp_path / ("outcome%d.txt" % rank)).read_text() == "ValueError"
+    assert sorted(p.name for p in rdzv.iterdir()) == ["ag.000001.r0", "ag.000001.r1", "bc.000001", "stale-run.ag.000001.r1"]

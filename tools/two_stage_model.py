@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""
+NumPy model of the two-stage Hermitian tridiagonalisation of csrc/tbk_eig_band.hip (64 < n <= 512):
+
+    stage 1   dense -> band of half-width B = 8: panels of 8 rows, Householder QR of the panel, two-sided
+              compact-WY update of the trailing matrix as ONE pass over its 16 x 16 tiles per panel
+              (update with the previous panel's (V, W) + product with the next panel's V in the same pass)
+    stage 2   band -> tridiagonal: Householder bulge chasing on the band (length-8 reflectors, 8 x 8 blocks)
+
+This file is the executable statement of the data flow the kernels follow (same index conventions, same
+order of phases, the same formulas for the reflector from Gram sums); `python tools/two_stage_model.py`
+checks it against numpy.linalg.eigvalsh.  It is design tooling: nothing in the product imports it.
+Reference step it replaces: scipy.linalg.eigvalsh per k-point, /root/reference/src/tbmodels/_tb_model.py:1147-1150.
+"""
+
+import numpy as np
+
+B = 8      # band half-width = panel height
+TS = 16    # MFMA tile edge
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 1
+# ------------------------------------------------------------------------------------------------
+def panel_qr(y):
+    """
+    Householder QR of y (m x 8, rows = 'threads'), with every reflector built from ONE round of sums over the rows:
+    g[c'] = sum_{i >= c} conj(y[i, c]) y[i, c'] plus the broadcast row c.  Returns V (m x 8, unit lower trapezoidal),
+    tau (8), R rows (8 x 8 upper triangular, rows >= m are absent).
+    """
+    m = y.shape[0]
+    y = y.copy()
+    V = np.zeros((m, B), dtype=complex)
+    tau = np.zeros(B, dtype=complex)
+    for c in range(B):
+        if c > m - 2:  # no row below the diagonal: nothing to eliminate (tau = 0)
+            continue
+        g = np.array([np.vdot(y[c:, c], y[c:, cp]) for cp in range(B)])  # one reduction round
+        row = y[c, :].copy()  # broadcast by the thread that owns row c
+        alpha = row[c]
+        gcc = g[c].real
+        sigma = gcc - abs(alpha) ** 2
+        if gcc == 0.0 or (sigma == 0.0 and alpha.imag == 0.0):
+            continue
+        beta = -np.copysign(np.sqrt(gcc), alpha.real)
+        tau[c] = (beta - alpha) / beta
+        scale = 1.0 / (alpha - beta)
+        v = y[:, c] * scale
+        v[:c] = 0.0
+        v[c] = 1.0
+        V[:, c] = v
+        # z[c'] = v^H y[:, c'] from the Gram sums
+        z = np.conj(scale) * (g - np.conj(alpha) * row) + row
+        for cp in range(c + 1, B):
+            y[c:, cp] -= np.conj(tau[c]) * v[c:] * z[cp]
+        y[c, c] = beta
+        y[c + 1:, c] = 0.0
+    return V, tau, y[:min(m, B), :]
+
+
+def t_factor(V, tau):
+    """Upper triangular T of the compact WY form Q = I - V T V^H from the Gram matrix G = V^H V (one reduction round)."""
+    G = V.conj().T @ V
+    T = np.zeros((B, B), dtype=complex)
+    for c in range(B):
+        T[c, c] = tau[c]
+        if c:
+            T[:c, c] = -tau[c] * (T[:c, :c] @ G[:c, c])
+    return T
+
+
+def big_pass(A, n, s_zero_rows, VW, Vn):
+    """
+    One pass over the 16 x 16 tiles (I <= J) of the stored upper triangle that touch rows / columns >= 16*floor(s/16):
+    tile -= VW_I . rot(VW_J)^H   (VW = [V | W] per row; rows < s are zero, so finished band rows are rewritten unchanged)
+    X_I += tile Vn_J,  X_J += tile^H Vn_I  (J != I).  Tiles are walked in the kernel's cyclic order.
+    """
+    nbk = (n + TS - 1) // TS
+    I0 = s_zero_rows // TS
+    na = nbk - I0
+    X = np.zeros((nbk * TS, B), dtype=complex)
+    VWp = np.zeros((nbk * TS, 2 * B), dtype=complex)
+    VWp[:n] = VW
+    Vnp = np.zeros((nbk * TS, B), dtype=complex)
+    Vnp[:n] = Vn
+    WVp = np.concatenate([VWp[:, B:], VWp[:, :B]], axis=1)  # [W | V]: the k-rotated partner operand
+    Ap = np.full((nbk * TS, nbk * TS), np.nan + 0j)
+    Ap[:n, :n] = A
+    Ap[:n, n:] = 0.0
+    Ap[n:, :] = 0.0
+
+    def visit(I, J):  # I <= J
+        ri, rj = slice(TS * I, TS * I + TS), slice(TS * J, TS * J + TS)
+        tile = Ap[ri, rj].copy()
+        tile -= VWp[ri] @ WVp[rj].conj().T
+        if I == J:
+            iu = np.triu_indices(TS)
+            full = np.zeros_like(tile)
+            full[iu] = tile[iu]
+            full = full + np.triu(full, 1).conj().T  # mirror of the stored upper part
+            Ap[ri, rj][iu] = tile[iu]
+            up = Ap[ri, rj]
+            up[iu] = tile[iu]
+            X[ri] += full @ Vnp[rj]
+        else:
+            Ap[ri, rj] = tile
+            X[ri] += tile @ Vnp[rj]
+            X[rj] += tile.conj().T @ Vnp[ri]
+
+    for t in range(na // 2 + 1):
+        for a in range(na):
+            if na % 2 == 0 and t == na // 2 and a >= na // 2:
+                continue
+            a2 = (a + t) % na
+            if t == 0:
+                visit(I0 + a, I0 + a)
+            else:
+                visit(I0 + min(a, a2), I0 + max(a, a2))
+    A[:, :] = Ap[:n, :n]
+    return X[:n]
+
+
+def stage1_band(H):
+    """Upper-triangle-only reduction of Hermitian H to a band of half-width B; returns the band as an (n, B+1) array
+    band[i, d] = H'[i, i+d]."""
+    n = H.shape[0]
+    A = np.triu(H).astype(complex)
+    A[np.tril_indices(n, -1)] = np.nan  # nothing may read the lower triangle
+    VW = np.zeros((n, 2 * B), dtype=complex)  # previous panel's [V | W], global row index
+    n_panels = 0
+    p = 0
+    while True:
+        s = B * p + B  # first row of the panel's QR = start of the trailing matrix after it
+        m = n - s
+        if m < 2:
+            break
+        g_rows = np.arange(B * p, B * p + B)
+        # --- look-ahead: block row p (8 rows x columns >= 8p), brought up to date with the pending (V, W)
+        cols = np.arange(B * p, n)
+        x = np.zeros((len(cols), B), dtype=complex)  # thread i holds column i of the block row
+        for t, i in enumerate(cols):
+            for r, g in enumerate(g_rows):
+                x[t, r] = A[g, i] if i >= g else np.conj(A[i, g])
+        Vg, Wg = VW[g_rows, :B], VW[g_rows, B:]  # the 8 pending rows (broadcast)
+        for t, i in enumerate(cols):
+            x[t, :] -= Vg @ VW[i, B:].conj() + Wg @ VW[i, :B].conj()
+        # diagonal block: final
+        for t, i in enumerate(cols[:B]):
+            for r, g in enumerate(g_rows):
+                if g <= i:
+                    A[g, i] = x[t, r]
+        # --- panel QR on threads i >= s: y = conj(x)
+        y = x[B:, :].conj()
+        V, tau, R = panel_qr(y)
+        for c in range(R.shape[0]):  # thread s + c writes its column of the block row: conj(R[c, r]) for r >= c
+            for r in range(B):
+                A[g_rows[r], s + c] = np.conj(R[c, r]) if r >= c else 0.0
+        A[g_rows[0]:g_rows[0] + B, s + R.shape[0]:] = 0.0  # (the kernel leaves these stale: nobody reads them)
+        T = t_factor(V, tau)
+        Vn = np.zeros((n, B), dtype=complex)
+        Vn[s:] = V
+        # --- the pending rows were consumed by the look-ahead: zero them, then the big pass
+        VW[:s, :] = 0.0
+        Xr = big_pass(A, n, s, VW, Vn)
+        # --- W of this panel
+        X = Xr @ T
+        X[:s] = 0.0
+        S = T.conj().T @ (Vn.conj().T @ X)
+        W = X - 0.5 * Vn @ S
+        VW = np.concatenate([Vn, W], axis=1)
+        n_panels += 1
+        p += 1
+    # final pass: apply the last pending update (no look-ahead took any of its rows)
+    big_pass(A, n, B * p, VW, np.zeros((n, B), dtype=complex))
+    band = np.zeros((n, B + 1), dtype=complex)
+    for i in range(n):
+        for d in range(min(B, n - 1 - i) + 1):
+            band[i, d] = A[i, i + d]
+    # everything outside the band must be negligible where it was defined
+    return band, A
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 2
+# ------------------------------------------------------------------------------------------------
+def larfg(x):
+    """LAPACK zlarfg: (beta, v, tau) with (I - tau v v^H)^H x = beta e_1, v[0] = 1."""
+    alpha = x[0]
+    sigma = np.vdot(x[1:], x[1:]).real
+    v = np.zeros_like(x)
+    v[0] = 1.0
+    if sigma == 0.0 and alpha.imag == 0.0:
+        return alpha.real, v, 0.0
+    beta = -np.copysign(np.sqrt(abs(alpha) ** 2 + sigma), alpha.real)
+    tau = (beta - alpha) / beta
+    v[1:] = x[1:] / (alpha - beta)
+    return beta, v, tau
+
+
+def stage2_tridiag(band):
+    """
+    Band (upper storage band[i, d] = H[i, i+d]) -> real tridiagonal (d, e) by bulge chasing.  Works on the LOWER band
+    L[j, dd] = H[j+dd, j] = conj(band[j, dd]) with room for the bulge: dd in [0, 2B).
+    """
+    n = band.shape[0]
+    L = np.zeros((n + 2 * B, 2 * B), dtype=complex)  # padded columns: the kernel's LDS array
+    L[:n, :B + 1] = band.conj()
+
+    def get(i, j):  # lower element (i >= j)
+        return L[j, i - j]
+
+    def put(i, j, v):
+        L[j, i - j] = v
+
+    for j in range(n - 2):
+        # ---- step 0: eliminate column j below the sub-diagonal
+        r0, r1 = j + 1, min(j + B, n - 1)
+        x = np.array([get(i, j) for i in range(r0, r1 + 1)])
+        if len(x) >= 2:
+            beta, v, tau = larfg(x)
+            put(r0, j, beta)
+            for i in range(r0 + 1, r1 + 1):
+                put(i, j, 0.0)
+        else:
+            v, tau = np.ones(1, dtype=complex), 0.0
+        while True:
+            nb = r1 - r0 + 1
+            # two-sided on the diagonal block D = A[r0:r1+1, r0:r1+1]:  D <- H^H D H, H = I - tau v v^H
+            D = np.zeros((nb, nb), dtype=complex)
+            for a in range(nb):
+                for b_ in range(a + 1):
+                    D[a, b_] = get(r0 + a, r0 + b_)
+                    D[b_, a] = np.conj(D[a, b_])
+            for a in range(nb):
+                D[a, a] = D[a, a].real
+            if tau != 0.0:
+                # H^H D H with H^H = I - conj(tau) v v^H
+                y = D @ v
+                rho = np.vdot(v, y).real
+                w = tau * y - 0.5 * abs(tau) ** 2 * rho * v  # D <- D - v w^H - w v^H ... derive below
+                # H^H D H = D - conj(tau) v (v^H D) - tau (D v) v^H + |tau|^2 rho v v^H
+                D = D - np.conj(tau) * np.outer(v, y.conj()) - tau * np.outer(y, v.conj()) + abs(tau) ** 2 * rho * np.outer(v, v.conj())
+            for a in range(nb):
+                for b_ in range(a + 1):
+                    put(r0 + a, r0 + b_, D[a, b_])
+            # block below: rows q0..q1, columns r0..r1:  Bk <- Bk H  (right-apply), creates the bulge
+            q0, q1 = r1 + 1, min(r1 + B, n - 1)
+            if q0 > n - 1:
+                break
+            nq = q1 - q0 + 1
+            Bk = np.zeros((nq, nb), dtype=complex)
+            for a in range(nq):
+                for b_ in range(nb):
+                    if (q0 + a) - (r0 + b_) < 2 * B:
+                        Bk[a, b_] = get(q0 + a, r0 + b_)
+            if tau != 0.0:
+                Bk = Bk - tau * np.outer(Bk @ v, v.conj())
+            # next reflector from the first column of the bulge block
+            x = Bk[:, 0].copy()
+            if nq >= 2:
+                beta, v2, tau2 = larfg(x)
+                Bk[0, 0] = beta
+                Bk[1:, 0] = 0.0
+                if tau2 != 0.0:  # left-apply H2^H to the remaining columns
+                    z = v2.conj() @ Bk[:, 1:]
+                    Bk[:, 1:] -= np.conj(tau2) * np.outer(v2, z)
+            else:
+                v2, tau2 = np.ones(1, dtype=complex), 0.0
+            for a in range(nq):
+                for b_ in range(nb):
+                    if (q0 + a) - (r0 + b_) < 2 * B:
+                        put(q0 + a, r0 + b_, Bk[a, b_])
+            r0, r1, v, tau = q0, q1, v2, tau2
+    d = L[:n, 0].real.copy()
+    e_c = L[:n - 1, 1].copy()
+    return d, np.abs(e_c), L
+
+
+def tridiag_eigvals(d, e):
+    import scipy.linalg as la
+
+    return la.eigvalsh_tridiagonal(d, e)
+
+
+def main():
+    rng = np.random.default_rng(0)
+    for n in (65, 72, 80, 96, 100, 129, 200, 256):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        H = (M + M.conj().T) / 2
+        band, A = stage1_band(H)
+        off = 0.0
+        for i in range(n):
+            for jj in range(i + B + 1, n):
+                if not np.isnan(A[i, jj]):
+                    off = max(off, abs(A[i, jj]))
+        Hb = np.zeros((n, n), dtype=complex)
+        for i in range(n):
+            for dd in range(min(B, n - 1 - i) + 1):
+                Hb[i, i + dd] = band[i, dd]
+                Hb[i + dd, i] = np.conj(band[i, dd])
+        ref = np.linalg.eigvalsh(H)
+        e1 = np.abs(np.linalg.eigvalsh(Hb) - ref).max()
+        d, e, _ = stage2_tridiag(band)
+        e2 = np.abs(tridiag_eigvals(d, e) - ref).max()
+        print("n=%3d  off-band residue %.1e  band eig err %.2e  tridiag eig err %.2e" % (n, off, e1, e2))
+        assert e1 < 1e-12 * n and e2 < 1e-12 * n
+
+
+if __name__ == "__main__":
+    main()
