@@ -122,6 +122,15 @@ int tbk_eigenval_device_hint(tbk_model* m, const double* d_k, const double* h_k,
 int tbk_eigenval_check(tbk_model* m);
 int tbk_synchronize(tbk_model* m);
 
+/* ---- the eigensolver's reduction stage alone (scipy.linalg.eigvalsh of _tb_model.py:1149 = this + the tridiagonal stage)
+ * nk Hermitian matrices H[nk][n_orb][n_orb][2] (row-major; only the upper triangle i <= j is read) are reduced to real
+ * symmetric tridiagonal form with the same eigenvalues: d[nk][n_orb] diagonals, e[nk][n_orb] off-diagonals (e[.][n-1] = 0).
+ * n_orb <= 512.  H_reduced (may be NULL) receives the work copy of the matrices as the reduction left it: for
+ * 64 < n_orb <= 512 (two-stage reduction) its upper triangle holds the band form of half-width 8 after stage one.
+ * Host buffers; synchronous.  For tests and for callers that bring their own matrices. */
+int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, double* d, double* e,
+                           double* H_reduced);
+
 /* ---- k.p models (kdotp.py:51-100): H(k) = sum_p prod_d k_d^powers[p][d] * coeffs[p] ------- */
 int tbk_kdotp_create(int device, int dim, int n_orb, int64_t n_p, const int32_t* powers,
                      const double* coeffs, tbk_kdotp** out);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "tbk_model_counter": (_c_int, [_vp, _c_int, ctypes.POINTER(_c_i64)]),
     "tbk_eigenval_check": (_c_int, [_vp]),
     "tbk_synchronize": (_c_int, [_vp]),
+    "tbk_tridiagonal_reduce": (_c_int, [_c_int, _c_int, _c_i64, _vp, _vp, _vp, _vp]),
     "tbk_kdotp_create": (_c_int, [_c_int, _c_int, _c_int, _c_i64, _vp, _vp, _pp]),
     "tbk_kdotp_destroy": (None, [_vp]),
     "tbk_kdotp_hamilton": (_c_int, [_vp, _vp, _c_i64, _vp]),

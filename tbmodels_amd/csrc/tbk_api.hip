@@ -340,7 +340,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);
     delete m;
@@ -892,6 +892,40 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
     TBK_HIP(hipMemcpyAsync(E_out, m->ws_out.ptr, (size_t)nk * m->n_orb * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
     return tbk_eigenval_check(m);  // synchronises
+}
+
+// ------------------------------------------------------------------------------------------------
+// the reduction stage alone, on caller-supplied matrices
+// ------------------------------------------------------------------------------------------------
+extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, double* d, double* e,
+                                      double* H_reduced) {
+    TBK_ARG(nk >= 0, "nk < 0");
+    TBK_ARG(n_orb >= 1 && n_orb <= 512, "n_orb must be in [1, 512] (larger matrices go through rocSOLVER as a whole)");
+    if (nk == 0) return TBK_OK;
+    TBK_ARG(H && d && e, "H / d / e is NULL");
+    tbk_model* m = nullptr;
+    TBK_CHECK(create_common(device, 1, n_orb, 0, nullptr, 2, &m));
+    const size_t n = (size_t)n_orb, mat_bytes = n * n * 2 * sizeof(double);
+    int rc = [&]() -> int {
+        TBK_LOCK(m);
+        m->call_nk = nk;
+        TBK_CHECK(m->ws_H.reserve((size_t)nk * mat_bytes));
+        TBK_CHECK(m->ws_E.reserve((size_t)nk * n * 2 * sizeof(double)));
+        TBK_HIP(hipMemcpyAsync(m->ws_H.ptr, H, (size_t)nk * mat_bytes, hipMemcpyHostToDevice, m->stream));
+        if (tbk_eig_small_supported(n_orb))
+            TBK_CHECK(tbk_launch_tridiag(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>()));
+        else
+            TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>()));
+        TBK_HIP(hipMemcpyAsync(d, m->ws_E.ptr, (size_t)nk * n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipMemcpyAsync(e, m->ws_E.as<double>() + (size_t)nk * n, (size_t)nk * n * sizeof(double), hipMemcpyDeviceToHost,
+                               m->stream));
+        if (H_reduced)
+            TBK_HIP(hipMemcpyAsync(H_reduced, m->ws_H.ptr, (size_t)nk * mat_bytes, hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+        return TBK_OK;
+    }();
+    tbk_model_destroy(m);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

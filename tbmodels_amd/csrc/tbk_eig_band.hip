@@ -1,0 +1,832 @@
+// tbk_eig_band.hip -- two-stage Householder tridiagonalisation for 64 < n_orb <= 512, one workgroup per matrix:
+//
+//   stage 1  band_reduce_kernel   dense -> band of half-width 8.  Panels of 8 rows; per panel ONE pass over the
+//                                 16 x 16 tiles of the stored (upper) triangle of the trailing matrix, on the matrix
+//                                 pipe (v_mfma_f64_16x16x4_f64): the rank-16 update with the previous panel's (V, W)
+//                                 and the product with the next panel's V in the same visit of a tile.
+//   stage 2  band_chase_kernel    band -> tridiagonal by Householder bulge chasing in LDS, one sweep per wave,
+//                                 sweeps pipelined three blocks apart.
+//
+// Reference step: scipy.linalg.eigvalsh per k-point (/root/reference/src/tbmodels/_tb_model.py:1147-1150).
+// The one-stage reduction of tbk_eig_stream.hip reads the trailing triangle once per Householder step
+// (16 n^3 / 6 bytes per matrix: 56 MB at n = 256, BLAS-2 on the vector unit); here the triangle is read and
+// written once per 8 steps (11 MB at n = 256) and the O(n^3) work is GEMM-shaped.  tools/two_stage_model.py is
+// the NumPy statement of the same data flow (index conventions, phases, formulas); the comments below refer to it.
+//
+// Conventions: H is the row-major n x n complex matrix of which only the upper triangle (i <= j) is valid
+// (the H(k) kernels' TRI output); nothing here reads the lower triangle.  Householder reflectors follow LAPACK
+// (zlarfg / zgeqr2 / zlarft): H_c = I - tau_c v_c v_c^H, Q = H_0 ... H_7 = I - V T V^H.
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "tbk_internal.h"
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int PB = 8;    // panel height = band half-width
+constexpr int TS = 16;   // MFMA tile edge
+
+__device__ __forceinline__ d2 cmul(d2 a, d2 b) { return (d2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
+__device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1] * b[1], a[1] * b[0] - a[0] * b[1]}; }  // a conj(b)
+__device__ __forceinline__ d2 conjd(d2 a) { return (d2){a[0], -a[1]}; }
+// acc += a b      /   acc += a conj(b)   /   acc -= a conj(b)
+__device__ __forceinline__ void cfma(d2& acc, d2 a, d2 b) {
+    acc[0] = fma(a[0], b[0], acc[0]);
+    acc[1] = fma(a[0], b[1], acc[1]);
+    acc[0] = fma(-a[1], b[1], acc[0]);
+    acc[1] = fma(a[1], b[0], acc[1]);
+}
+__device__ __forceinline__ void cfmac(d2& acc, d2 a, d2 b) {
+    acc[0] = fma(a[0], b[0], acc[0]);
+    acc[1] = fma(a[1], b[0], acc[1]);
+    acc[0] = fma(a[1], b[1], acc[0]);
+    acc[1] = fma(-a[0], b[1], acc[1]);
+}
+__device__ __forceinline__ void cfnmac(d2& acc, d2 a, d2 b) {
+    acc[0] = fma(-a[0], b[0], acc[0]);
+    acc[1] = fma(-a[1], b[0], acc[1]);
+    acc[0] = fma(-a[1], b[1], acc[0]);
+    acc[1] = fma(a[0], b[1], acc[1]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// x <- [sum of x over the lane pair | sum of y over the lane pair] (lower | upper 32 lanes, or even | odd rows of 16)
+__device__ __forceinline__ void swap_add(double& x, double y, bool half32) {
+    unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+    unsigned yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+    if (half32) {
+        const auto rl = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+        x = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    } else {
+        const auto rl = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+        x = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+}
+
+// four wave-wide sums at once: lane l ends with the total of value (l >> 4); fixed summation tree
+__device__ __forceinline__ double reduce4(double p0, double p1, double p2, double p3) {
+    swap_add(p0, p2, true);
+    swap_add(p1, p3, true);
+    swap_add(p0, p1, false);
+    double v = p0;
+    v += dpp_mov<0x128>(v);  // row_ror 8, 4, 2, 1
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    return v;
+}
+
+// barrier with explicit waits: LDS traffic (lgkmcnt) and the global stores other waves of this workgroup re-read (vmcnt)
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Workgroup sums of up to 64 per-thread values, fixed order (transposed butterflies inside a wave, then the waves in
+// index order).  Values are handed over four at a time -- wave_partial4(slot, ...) for slots 0, 4, 8, ... -- so that
+// a caller never holds more than four of them in registers; wg_finish(nv) makes the totals readable in s_tot[0 .. nv).
+__device__ __forceinline__ void wave_partial4(int slot, double p0, double p1, double p2, double p3, double* s_part, int lane, int wave) {
+    const double t = reduce4(p0, p1, p2, p3);
+    if ((lane & 15) == 0) s_part[wave * 64 + slot + (lane >> 4)] = t;
+}
+template <int NW>
+__device__ __forceinline__ void wg_finish(int nv, double* s_part, double* s_tot, int tid) {
+    wg_sync();
+    if (tid < nv) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += s_part[w * 64 + tid];
+        s_tot[tid] = acc;
+    }
+    wg_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1
+// ------------------------------------------------------------------------------------------------
+// The previous panel's [V | W] rows live in global memory in MFMA-fragment order, so that a 16-row block is four
+// contiguous 1 KiB wave loads: entry (row, c) of block I = row / 16 at  ((I * 4 + c / 4) * 64 + (c % 4) * 16 + row % 16).
+__device__ __forceinline__ size_t vw_index(int row, int c) {
+    return ((size_t)(row >> 4) * 4 + (c >> 2)) * 64 + (size_t)(c & 3) * 16 + (row & 15);
+}
+
+struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l holds [l % 16][l / 16 + 4 s], s = 0..3
+    double re[4], im[4];
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int* __restrict__ flags) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) double br_smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbk = (n + TS - 1) / TS;
+    const int npad = nbk * TS;
+    d2* sVn = reinterpret_cast<d2*>(br_smem);              // [npad][8]   next panel's V (rows < s are zero)
+    d2* sX = sVn + (size_t)npad * PB;                      // [npad][8]   A V of the next panel
+    double* sTr = reinterpret_cast<double*>(sX + (size_t)npad * PB);  // [NW][16][17] tile transposition, one plane per wave
+    double* sPart = sTr + NW * 16 * 17;                    // [NW][64]
+    double* sTot = sPart + NW * 64;                        // [64]
+    d2* sRow = reinterpret_cast<d2*>(sTot + 64);           // [2][8] row c of the panel (QR), broadcast; alternating
+    d2* sG = sRow + 16;                                    // [8][16] the pending [V | W] rows of the look-ahead
+    d2* sS = sG + 128;                                     // [64]  S = T^H M T
+    d2* sT = sS + 64;                                      // [8][8] T of the current panel
+    d2* sTau = sT + 64;                                    // [8]
+
+    const size_t mat = blockIdx.x;
+    double* H = Hall + mat * (size_t)n * n * 2;
+    d2* VW = VWall + mat * (size_t)nbk * 256;
+    (void)flags;
+
+    // the pending-update buffer starts out empty
+    for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
+    bool have_update = false;
+
+    auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
+
+    // ---- one pass over the tiles of the trailing triangle (model: big_pass) ----
+    // s: rows / columns below s are finished (their V / W / Vn rows are zero);  with_hemm: accumulate X = A Vn
+    auto big_pass = [&](int s, bool with_update, bool with_hemm) {
+        const int I0 = s / TS;
+        const int na = nbk - I0;
+        const int lrow = lane & 15, lq = lane >> 4;
+        double* tr = sTr + wave * (16 * 17);
+        const int n_q = (na + NW - 1) / NW;
+        const int n_t = na / 2;
+        for (int q = 0; q < n_q; ++q) {
+            const int a = wave + NW * q;
+            const bool own_valid = a < na;
+            const int I = I0 + a;
+            Frag own;
+            double own_b[4];
+            d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = (d4){0.0, 0.0, 0.0, 0.0};
+            if (own_valid) {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const d2 v = VW[((size_t)I * 4 + sg) * 64 + lane];
+                    own.re[sg] = v[0];
+                    own.im[sg] = v[1];
+                    own_b[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(I * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                }
+            }
+            for (int t = 0; t <= n_t; ++t) {
+                bool active = own_valid && !((na & 1) == 0 && t == n_t && t > 0 && a >= n_t);
+                if (active) {
+                    int a2 = a + t;
+                    if (a2 >= na) a2 -= na;
+                    const int I2 = I0 + a2;
+                    const bool diag = (t == 0);
+                    const bool own_is_row = I <= I2;
+                    const int Ir = own_is_row ? I : I2, Jc = own_is_row ? I2 : I;
+                    // partner operands
+                    Frag par;
+                    double par_b[4];
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) {
+                        if (with_update && !diag) {
+                            const d2 v = VW[((size_t)I2 * 4 + sg) * 64 + lane];
+                            par.re[sg] = v[0];
+                            par.im[sg] = v[1];
+                        } else {
+                            par.re[sg] = own.re[sg];
+                            par.im[sg] = own.im[sg];
+                        }
+                        par_b[sg] = diag ? own_b[sg]
+                                         : reinterpret_cast<const double*>(sVn)[(size_t)(I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                    }
+                    // the tile, accumulator layout: lane l holds (row lq + 4 r, column lrow)
+                    d4 tre, tim;
+                    const int gc = Jc * TS + lrow;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = Ir * TS + lq + 4 * r;
+                        d2 v = (d2){0.0, 0.0};
+                        if (gr < n && gc < n) v = *Hat(gr, gc);
+                        tre[r] = v[0];
+                        tim[r] = v[1];
+                    }
+                    if (with_update) {
+                        // tile -= [V | W]_row . ([W | V]_col)^H : A = row block, k-step sg; B = conj(col block, k-step (sg + 2) % 4)
+#pragma unroll
+                        for (int sg = 0; sg < 4; ++sg) {
+                            const int sb = (sg + 2) & 3;
+                            const double ar = own_is_row ? own.re[sg] : par.re[sg], ai = own_is_row ? own.im[sg] : par.im[sg];
+                            const double br = own_is_row ? par.re[sb] : own.re[sb], bi = own_is_row ? par.im[sb] : own.im[sb];
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, tre, 0, 0, 1);  // -ar br
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, tre, 0, 0, 1);  // -ai bi
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, tim, 0, 0, 1);  // -ai br
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, tim, 0, 0, 0);  // +ar bi
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gr = Ir * TS + lq + 4 * r;
+                            if (gr < n && gc < n) *Hat(gr, gc) = (d2){tre[r], tim[r]};
+                        }
+                    }
+                    if (with_hemm) {
+                        // transposed copy through this wave's LDS plane: element [lrow][lq + 4 sg]
+                        double ttre[4], ttim[4];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tre[r];
+                        lds_fence();
+#pragma unroll
+                        for (int sg = 0; sg < 4; ++sg) ttre[sg] = tr[lrow * 17 + lq + 4 * sg];
+                        lds_fence();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tim[r];
+                        lds_fence();
+#pragma unroll
+                        for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
+                        lds_fence();
+                        d4 p1 = (d4){0.0, 0.0, 0.0, 0.0}, p2 = p1, q1 = p1, q2 = p1;
+                        if (diag) {
+                            // Hermitian tile of which only the upper part is valid: operand element [i = lrow][j = lq + 4 sg]
+                            // is the transposed copy where i <= j, the conjugate of the accumulator element otherwise
+#pragma unroll
+                            for (int sg = 0; sg < 4; ++sg) {
+                                const bool upper = lrow <= lq + 4 * sg;
+                                const double ar = upper ? ttre[sg] : tre[sg];
+                                const double ai = upper ? ttim[sg] : -tim[sg];
+                                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, own_b[sg], p1, 0, 0, 0);
+                                p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, own_b[sg], p2, 0, 0, 0);
+                            }
+                            own1 += p1;
+                            own2 += p2;
+                        } else {
+                            // row part  X_Ir += tile Vn_Jc ;  column part  X_Jc += tile^H Vn_Ir
+                            const double* b_col = own_is_row ? par_b : own_b;  // Vn of the column block
+                            const double* b_row = own_is_row ? own_b : par_b;  // Vn of the row block
+#pragma unroll
+                            for (int sg = 0; sg < 4; ++sg) {
+                                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], b_col[sg], p1, 0, 0, 0);
+                                p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], b_col[sg], p2, 0, 0, 0);
+                                q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], b_row[sg], q1, 0, 0, 0);
+                                q2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], b_row[sg], q2, 0, 0, 1);  // conj
+                            }
+                            d4 o1, o2;
+                            if (own_is_row) {
+                                own1 += p1;
+                                own2 += p2;
+                                o1 = q1;
+                                o2 = q2;
+                            } else {
+                                own1 += q1;
+                                own2 += q2;
+                                o1 = p1;
+                                o2 = p2;
+                            }
+                            // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
+                            double* xs = reinterpret_cast<double*>(sX);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double rot = dpp_mov<0x128>(o2[r]);  // the other half of the 16-lane row
+                                const double val = (lrow < 8) ? o1[r] - rot : o1[r] + rot;
+                                const size_t at = (size_t)(I2 * TS + lq + 4 * r) * 16 + 2 * (lrow & 7) + (lrow >> 3);
+                                xs[at] += val;
+                            }
+                        }
+                    }
+                }
+                wg_sync();  // partner blocks of different steps overlap
+            }
+            if (with_hemm) {
+                if (own_valid) {
+                    double* xs = reinterpret_cast<double*>(sX);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double rot = dpp_mov<0x128>(own2[r]);
+                        const double val = (lrow < 8) ? own1[r] - rot : own1[r] + rot;
+                        const size_t at = (size_t)(I * TS + lq + 4 * r) * 16 + 2 * (lrow & 7) + (lrow >> 3);
+                        xs[at] += val;
+                    }
+                }
+                wg_sync();
+            }
+        }
+    };
+
+    const int i_row = tid;  // thread <-> global row / column index in the thread-per-row phases
+    int p = 0;
+    for (;; ++p) {
+        const int g0 = PB * p;       // first row of the panel
+        const int s = g0 + PB;       // start of the trailing matrix behind it
+        const int m = n - s;
+        if (m < 2) break;
+        // ---- look-ahead: block row p (8 rows, columns >= 8 p) brought up to date with the pending (V, W) ----
+        if (have_update && tid < 128) sG[tid] = VW[vw_index(g0 + (tid >> 4), tid & 15)];
+        wg_sync();
+        d2 x[PB];
+#pragma unroll
+        for (int r = 0; r < PB; ++r) x[r] = (d2){0.0, 0.0};
+        const bool in_rows = i_row >= g0 && i_row < n;
+        if (in_rows) {
+#pragma unroll
+            for (int r = 0; r < PB; ++r) {
+                const int g = g0 + r;
+                if (g < n) {
+                    if (i_row >= g) {
+                        x[r] = *Hat(g, i_row);
+                    } else {
+                        x[r] = conjd(*Hat(i_row, g));
+                    }
+                }
+            }
+            if (have_update) {
+                d2 vw[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) vw[c] = VW[vw_index(i_row, c)];
+#pragma unroll
+                for (int r = 0; r < PB; ++r) {
+#pragma unroll
+                    for (int t = 0; t < PB; ++t) {
+                        cfnmac(x[r], sG[r * 16 + t], vw[PB + t]);      // - V[g][t] conj(W[i][t])
+                        cfnmac(x[r], sG[r * 16 + PB + t], vw[t]);      // - W[g][t] conj(V[i][t])
+                    }
+                }
+            }
+            // the diagonal block is final
+            if (i_row < s) {
+#pragma unroll
+                for (int r = 0; r < PB; ++r)
+                    if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[r];
+            }
+        }
+        // ---- Householder QR of the panel on threads i >= s: y = conj(x) (model: panel_qr) ----
+        const bool qr_row = i_row >= s && i_row < n;
+        d2 y[PB], vn[PB];
+        d2 tau[PB];
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            y[c] = qr_row ? conjd(x[c]) : (d2){0.0, 0.0};
+            vn[c] = (d2){0.0, 0.0};
+            tau[c] = (d2){0.0, 0.0};
+        }
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            if (c <= m - 2) {  // uniform: a row below the diagonal exists
+                const bool below = qr_row && i_row >= s + c;
+                double pv[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pv[k] = 0.0;
+                if (below) {
+                    pv[0] = y[c][0] * y[c][0] + y[c][1] * y[c][1];
+#pragma unroll
+                    for (int cp = c + 1; cp < PB; ++cp) {
+                        const d2 t = cmulc(y[cp], y[c]);  // conj(y_c) y_cp
+                        pv[1 + 2 * (cp - c - 1)] = t[0];
+                        pv[2 + 2 * (cp - c - 1)] = t[1];
+                    }
+                }
+                d2* row_buf = sRow + (c & 1) * PB;  // (a fast thread writes row c + 1 while a slow one still reads row c)
+                if (i_row == s + c) {
+#pragma unroll
+                    for (int cp = 0; cp < PB; ++cp) row_buf[cp] = y[cp];
+                }
+#pragma unroll
+                for (int k4 = 0; k4 < 16; k4 += 4) wave_partial4(k4, pv[k4], pv[k4 + 1], pv[k4 + 2], pv[k4 + 3], sPart, lane, wave);
+                wg_finish<NW>(16, sPart, sTot, tid);
+                const double gcc = sTot[0];
+                const d2 alpha = row_buf[c];
+                const double sigma = gcc - (alpha[0] * alpha[0] + alpha[1] * alpha[1]);
+                if (!(gcc == 0.0 || (sigma == 0.0 && alpha[1] == 0.0))) {  // uniform
+                    const double beta = -copysign(sqrt(gcc), alpha[0]);
+                    const double rbeta = 1.0 / beta;
+                    tau[c] = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                    const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+                    const double qn = 1.0 / (qr_ * qr_ + qi_ * qi_);
+                    const d2 scale = (d2){qr_ * qn, -qi_ * qn};  // 1 / (alpha - beta)
+                    d2 v = (d2){0.0, 0.0};
+                    if (below) v = (i_row == s + c) ? (d2){1.0, 0.0} : cmul(y[c], scale);
+                    vn[c] = v;
+                    const d2 ctau = conjd(tau[c]);
+#pragma unroll
+                    for (int cp = c + 1; cp < PB; ++cp) {
+                        const d2 g = (d2){sTot[1 + 2 * (cp - c - 1)], sTot[2 + 2 * (cp - c - 1)]};
+                        const d2 rowv = row_buf[cp];
+                        // z = conj(scale) (g - conj(alpha) row) + row
+                        d2 t = g;
+                        cfnmac(t, rowv, alpha);  // g - row conj(alpha)
+                        d2 z = cmulc(t, scale);  // t conj(scale)
+                        z[0] += rowv[0];
+                        z[1] += rowv[1];
+                        const d2 f = cmul(ctau, z);
+                        if (below) {
+                            y[cp][0] -= v[0] * f[0] - v[1] * f[1];
+                            y[cp][1] -= v[0] * f[1] + v[1] * f[0];
+                        }
+                    }
+                    if (below) y[c] = (i_row == s + c) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                }
+            }
+        }
+        // thread s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
+        if (qr_row && i_row < s + PB) {
+            const int c = i_row - s;
+#pragma unroll
+            for (int r = 0; r < PB; ++r)
+                if (g0 + r < n) *Hat(g0 + r, i_row) = (r >= c) ? conjd(y[r]) : (d2){0.0, 0.0};
+        }
+        // ---- T of the compact WY form from the Gram matrix of V (model: t_factor); kept in LDS over the big pass ----
+        {
+            // G[c2][c] = sum_i conj(v_c2) v_c for c2 < c: 28 complex sums, pair (c, c2) at slot 2 (c (c - 1) / 2 + c2)
+            double hold[4];
+            int k = 0;
+#pragma unroll
+            for (int c = 1; c < PB; ++c) {
+#pragma unroll
+                for (int c2 = 0; c2 < c; ++c2) {
+                    const d2 t = cmulc(vn[c], vn[c2]);
+                    hold[k & 3] = t[0];
+                    hold[(k + 1) & 3] = t[1];
+                    k += 2;
+                    if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
+                }
+            }
+            wg_finish<NW>(56, sPart, sTot, tid);
+            if (tid < PB) sTau[tid] = (d2){0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (tid == c) sTau[c] = tau[c];
+            lds_fence();
+            // lane a of the first wave builds row a of T: T[a][c] = -tau_c sum_{c2 = a}^{c - 1} T[a][c2] G[c2][c]
+            if (tid < PB) {
+                const int a = tid;
+                d2 trow[PB];
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    d2 acc = (d2){0.0, 0.0};
+#pragma unroll
+                    for (int c2 = 0; c2 < c; ++c2) {
+                        const int slot = 2 * (c * (c - 1) / 2 + c2);
+                        const d2 g = (d2){sTot[slot], sTot[slot + 1]};
+                        if (c2 >= a) cfma(acc, trow[c2], g);
+                    }
+                    const d2 t = cmul(tau[c], acc);
+                    trow[c] = (c == a) ? tau[c] : (c > a ? (d2){-t[0], -t[1]} : (d2){0.0, 0.0});
+                    sT[a * PB + c] = trow[c];
+                }
+            }
+        }
+        // ---- hand over: Vn to LDS, X cleared, the consumed pending rows zeroed ----
+        if (i_row < npad) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                sVn[(size_t)i_row * PB + c] = vn[c];
+                sX[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
+            }
+        }
+        if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
+        wg_sync();
+        big_pass(s, have_update, true);
+        // ---- W = X T - V S / 2,  S = T^H (V^H X) T  (model: stage1_band) ----
+        d2 xr[PB], vr[PB];  // this thread's rows of A V and of V, back from LDS (nothing lives in registers over the pass)
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            xr[c] = (qr_row) ? sX[(size_t)i_row * PB + c] : (d2){0.0, 0.0};
+            vr[c] = (qr_row) ? sVn[(size_t)i_row * PB + c] : (d2){0.0, 0.0};
+        }
+        {
+            // M = V^H (A V) is Hermitian: upper triangle, row a at slot a (16 - a): the real diagonal entry, then
+            // (re, im) of M[a][b] for b > a -- 64 values
+            double hold[4];
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < PB; ++a) {
+#pragma unroll
+                for (int b = a; b < PB; ++b) {
+                    if (b == a) {
+                        hold[k & 3] = vr[a][0] * xr[a][0] + vr[a][1] * xr[a][1];
+                        k += 1;
+                        if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
+                    } else {
+                        const d2 t = cmulc(xr[b], vr[a]);  // conj(v_a) x_b
+                        hold[k & 3] = t[0];
+                        k += 1;
+                        if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
+                        hold[k & 3] = t[1];
+                        k += 1;
+                        if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
+                    }
+                }
+            }
+            wg_finish<NW>(64, sPart, sTot, tid);
+            // 64 threads: S[i][j] = sum_ab conj(T[a][i]) M[a][b] T[b][j]
+            if (tid < 64) {
+                const int si = tid >> 3, sj = tid & 7;
+                d2 acc = (d2){0.0, 0.0};
+#pragma unroll
+                for (int a = 0; a < PB; ++a) {
+                    d2 inner = (d2){0.0, 0.0};  // (M T)[a][sj]
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        d2 mab;
+                        if (b == a) {
+                            mab = (d2){sTot[a * (16 - a)], 0.0};
+                        } else if (b > a) {
+                            const int at = a * (16 - a) + 1 + 2 * (b - a - 1);
+                            mab = (d2){sTot[at], sTot[at + 1]};
+                        } else {
+                            const int at = b * (16 - b) + 1 + 2 * (a - b - 1);
+                            mab = (d2){sTot[at], -sTot[at + 1]};
+                        }
+                        cfma(inner, mab, sT[b * PB + sj]);
+                    }
+                    cfmac(acc, inner, sT[a * PB + si]);  // conj(T[a][si]) inner
+                }
+                sS[tid] = acc;
+            }
+            wg_sync();
+        }
+        if (qr_row) {
+            d2 xt[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                d2 acc = (d2){0.0, 0.0};
+#pragma unroll
+                for (int c2 = 0; c2 <= c; ++c2) cfma(acc, xr[c2], sT[c2 * PB + c]);
+                xt[c] = acc;
+            }
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                d2 acc = (d2){0.0, 0.0};
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) cfma(acc, vr[c2], sS[c2 * PB + c]);
+                const d2 w = (d2){xt[c][0] - 0.5 * acc[0], xt[c][1] - 0.5 * acc[1]};
+                VW[vw_index(i_row, c)] = vr[c];
+                VW[vw_index(i_row, PB + c)] = w;
+            }
+        }
+        have_update = true;
+        wg_sync();
+    }
+    // the last pending update (no look-ahead consumed any of its rows)
+    if (have_update) big_pass(PB * p, true, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2
+// ------------------------------------------------------------------------------------------------
+// The band as LOWER diagonals in LDS: element (i, j), 0 <= i - j < 16, at sL[(i - j) * NP + j]; NP % 16 == 9 makes the
+// 8 x 8 block accesses of a wave (lane = row a + 8 column b) conflict-free for ds_read_b128.
+template <int CTRL>
+__device__ __forceinline__ d2 dpp_mov2(d2 v) { return (d2){dpp_mov<CTRL>(v[0]), dpp_mov<CTRL>(v[1])}; }
+
+// sum over the row index a = lane & 7 (lanes that share b): every lane ends with the total
+__device__ __forceinline__ double sum_a(double v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
+    return v;
+}
+// sum over the column index b = lane >> 3 (lanes that share a)
+__device__ __forceinline__ double sum_b(double v) {
+    v += dpp_mov<0x128>(v);  // row_ror 8: b ^ 1
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ d2 sum_a2(d2 v) { return (d2){sum_a(v[0]), sum_a(v[1])}; }
+__device__ __forceinline__ d2 sum_b2(d2 v) { return (d2){sum_b(v[0]), sum_b(v[1])}; }
+
+__device__ __forceinline__ double shfl_d(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
+    return __hiloint2double(hi, lo);
+}
+
+// zlarfg on a vector every lane knows through (x_a, x_b): returns beta, tau and this lane's v_a, v_b
+struct Reflector {
+    d2 va, vb, tau;
+    double beta;
+};
+__device__ __forceinline__ Reflector make_reflector(d2 xa, d2 xb, int a, int b) {
+    Reflector h;
+    const double sigma = sum_a(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
+    // alpha = x[0]: lane 0 holds it as xa
+    d2 alpha;
+    alpha[0] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[0])), __builtin_amdgcn_readfirstlane(__double2loint(xa[0])));
+    alpha[1] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[1])), __builtin_amdgcn_readfirstlane(__double2loint(xa[1])));
+    h.tau = (d2){0.0, 0.0};
+    h.beta = alpha[0];
+    h.va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+    h.vb = (b == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+    if (!(sigma == 0.0 && alpha[1] == 0.0)) {
+        const double beta = -copysign(sqrt(alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma), alpha[0]);
+        const double rbeta = 1.0 / beta;
+        h.tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+        const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+        const double qn = 1.0 / (qr_ * qr_ + qi_ * qi_);
+        const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+        if (a != 0) h.va = cmul(xa, scale);
+        if (b != 0) h.vb = cmul(xb, scale);
+        h.beta = beta;
+    }
+    return h;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+band_chase_kernel(const double* __restrict__ Hall, int n, int np, double* __restrict__ D, double* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
+    d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
+    int* sStart = reinterpret_cast<int*>(sL + (size_t)16 * np);     // [n] first tick of every sweep
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 7, b = lane >> 3;
+    const size_t mat = blockIdx.x;
+    const double* H = Hall + mat * (size_t)n * n * 2;
+
+    auto L = [&](int i, int j) -> d2& { return sL[(size_t)(i - j) * np + j]; };
+
+    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
+    __syncthreads();
+    // lower band element (j + dd, j) = conj(H[j][j + dd])
+    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
+        const int j = i / (PB + 1), dd = i % (PB + 1);
+        if (j + dd < n) {
+            const d2 v = *reinterpret_cast<const d2*>(H + ((size_t)j * n + j + dd) * 2);
+            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
+        }
+    }
+    const int n_sweeps = n - 2;
+    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };  // ticks of sweep j
+    if (tid == 0) {
+        for (int s = 0; s < n_sweeps; ++s) {
+            int t0 = 0;
+            if (s > 0) t0 = sStart[s - 1] + 3;
+            if (s >= NW) t0 = max(t0, sStart[s - NW] + sweep_len(s - NW));
+            sStart[s] = t0;
+        }
+    }
+    wg_sync();
+    if (n_sweeps > 0) {
+        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
+        int sw = wave;  // this wave's current / next sweep
+        int k = -1;     // tick inside the sweep, -1 = waiting
+        int k_len = 0;
+        d2 va = (d2){0.0, 0.0}, vb = va, tau = va;
+        for (int tick = 0; tick < total_ticks; ++tick) {
+            if (k < 0 && sw < n_sweeps && tick == sStart[sw]) {
+                k = 0;
+                k_len = sweep_len(sw);
+                // first reflector of the sweep: column sw below the diagonal
+                const int j = sw;
+                const d2 xa = L(j + 1 + a, j), xb = L(j + 1 + b, j);
+                const Reflector h = make_reflector(xa, xb, a, b);
+                va = h.va;
+                vb = h.vb;
+                tau = h.tau;
+                lds_fence();
+                if (b == 0 && j + 1 + a < n) L(j + 1 + a, j) = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
+            }
+            if (k >= 0) {
+                const int r0 = sw + 1 + PB * k;
+                const int q0 = r0 + PB;
+                // all loads of the tick first
+                const int di = r0 + max(a, b), dj = r0 + min(a, b);
+                d2 dv = L(di, dj);
+                const d2 bk = L(q0 + a, r0 + b);
+                const d2 bk0a = L(q0 + a, r0), bk0b = L(q0 + b, r0);
+                if (a < b) dv = conjd(dv);
+                if (a == b) dv[1] = 0.0;
+                // y = D v (by rows and by columns), rho = v^H y
+                const d2 ya = sum_b2(cmul(dv, vb));
+                const d2 yb = sum_a2(cmulc(va, dv));  // conj(D[a][b]) v[a] summed over a = y[b]
+                const double rho = sum_a(va[0] * ya[0] + va[1] * ya[1]);
+                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
+                const d2 ctau = conjd(tau);
+                d2 dn = dv;
+                {
+                    const d2 t1 = cmul(ctau, cmulc(va, yb));
+                    const d2 t2 = cmul(tau, cmulc(ya, vb));
+                    const d2 t3 = cmulc(va, vb);
+                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+                    dn[0] += -t1[0] - t2[0] + f * t3[0];
+                    dn[1] += -t1[1] - t2[1] + f * t3[1];
+                }
+                if (a >= b && di < n) L(di, dj) = dn;
+                // block below: Bk' = Bk - tau u conj(v_b), u = Bk v
+                const d2 ua = sum_b2(cmul(bk, vb));
+                const d2 tu = cmul(tau, ua);
+                d2 bn = bk;
+                cfnmac(bn, tu, vb);
+                // its first column is the next reflector's vector: x[a] = Bk[a][0] - tau u[a] (v[0] = 1 when tau != 0)
+                d2 ub;
+                ub[0] = shfl_d(ua[0], b);
+                ub[1] = shfl_d(ua[1], b);
+                const d2 tub = cmul(tau, ub);
+                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};
+                const d2 xb = (d2){bk0b[0] - tub[0], bk0b[1] - tub[1]};
+                const Reflector h = make_reflector(xa, xb, a, b);
+                // left-apply to the remaining columns: Bk'' = Bk' - conj(tau2) v2_a z_b, z = v2^H Bk'
+                const d2 zb = sum_a2(cmulc(bn, h.va));  // conj(v2_a) Bk'[a][b] summed over a
+                const d2 f2 = cmul(conjd(h.tau), zb);
+                cfma(bn, (d2){-h.va[0], -h.va[1]}, f2);
+                if (b == 0) bn = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
+                if (q0 + a < n && r0 + b < n) L(q0 + a, r0 + b) = bn;
+                va = h.va;
+                vb = h.vb;
+                tau = h.tau;
+                if (++k == k_len) {
+                    k = -1;
+                    sw += NW;
+                }
+            }
+            wg_sync();
+        }
+    }
+    for (int j = tid; j < n; j += NW * 64) {
+        D[mat * n + j] = L(j, j)[0];
+        double e = 0.0;
+        if (j + 1 < n) {
+            const d2 v = L(j + 1, j);
+            e = sqrt(v[0] * v[0] + v[1] * v[1]);
+        }
+        E[mat * n + j] = e;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+size_t tbk_band_scratch_per_matrix(int n) { return (size_t)((n + TS - 1) / TS) * 256 * sizeof(d2); }
+
+static int chase_pitch(int n) {
+    int np = n + PB;
+    while (np % 16 != 9) ++np;
+    return np;
+}
+
+bool tbk_eig_band_supported(int n) { return n > 64 && n <= 512; }
+
+// d_de: d[nk][n] followed by e[nk][n]; the upper triangle of every d_H matrix is overwritten; d_vw: scratch of
+// tbk_band_scratch_per_matrix(n) bytes per matrix
+int tbk_launch_tridiag_band(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, void* d_vw) {
+    const int n = m->n_orb;
+    if (nk == 0) return TBK_OK;
+    double* d_D = d_de;
+    double* d_E = d_de + (size_t)nk * n;
+    StageTimer t(m, TBK_T_EIG, s);
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    {
+        const bool small = n <= 256;
+        const int nw = small ? 4 : 8;
+        const size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 128 + 64 + 64 + 8) * 16;
+        static bool raised_a[TBK_MAX_DEVICES] = {}, raised_b[TBK_MAX_DEVICES] = {};
+        if (small) {
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<256>), (int)lds, raised_a));
+            hipLaunchKernelGGL(band_reduce_kernel<256>, dim3((unsigned)nk), dim3(256), lds, s, d_H, n, static_cast<d2*>(d_vw),
+                               m->ws_flag.as<int>());
+        } else {
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<512>), (int)lds, raised_b));
+            hipLaunchKernelGGL(band_reduce_kernel<512>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, static_cast<d2*>(d_vw),
+                               m->ws_flag.as<int>());
+        }
+        TBK_HIP(hipGetLastError());
+    }
+    {
+        const int np = chase_pitch(n);
+        const size_t lds = (size_t)16 * np * 16 + (size_t)n * sizeof(int) + 16;
+        static bool raised_c[TBK_MAX_DEVICES] = {}, raised_d[TBK_MAX_DEVICES] = {};
+        if (n <= 256) {
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<8>), (int)lds, raised_c));
+            hipLaunchKernelGGL(band_chase_kernel<8>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, np, d_D, d_E);
+        } else {
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<16>), (int)lds, raised_d));
+            hipLaunchKernelGGL(band_chase_kernel<16>, dim3((unsigned)nk), dim3(1024), lds, s, d_H, n, np, d_D, d_E);
+        }
+        TBK_HIP(hipGetLastError());
+    }
+    return TBK_OK;
+}

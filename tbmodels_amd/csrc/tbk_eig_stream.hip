@@ -610,6 +610,17 @@ bool tbk_eig_stream_supported(int n) { return n > 64 && n <= ST_MAXN; }
 int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
+    {
+        // two-stage reduction (tbk_eig_band.hip) unless TBK_BAND=0 asks for the one-stage kernel below
+        static const bool band = [] {
+            const char* v = getenv("TBK_BAND");
+            return v == nullptr || atoi(v) != 0;
+        }();
+        if (band && tbk_eig_band_supported(n)) {
+            TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
+            return tbk_launch_tridiag_band(m, s, d_H, nk, d_de, m->ws_band.ptr);
+        }
+    }
     double* d_D = d_de;
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);

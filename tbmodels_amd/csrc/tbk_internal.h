@@ -194,6 +194,7 @@ struct tbk_model {
     DevBuf ws_part;   // split-K partial tiles of the dense H(k) kernel (small k batches)
     DevBuf ws_kfold;  // k-points of a folded run without the folded component
     DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
+    DevBuf ws_band;   // two-stage reduction: pending [V | W] panel of every matrix of a chunk
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};
@@ -253,6 +254,11 @@ bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk);  // tbk_hk_dense.hip
 bool tbk_hk_gemv_path(const tbk_model* m, int64_t nk);
 int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E);
 size_t tbk_eig_scratch_per_k(const tbk_model* m);
+
+// tbk_eig_band.hip: two-stage reduction (dense -> band on the matrix pipe, band -> tridiagonal in LDS)
+bool tbk_eig_band_supported(int n);
+size_t tbk_band_scratch_per_matrix(int n);
+int tbk_launch_tridiag_band(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, void* d_vw);
 
 // tbk_eig_small.hip
 bool tbk_eig_small_supported(int n);
