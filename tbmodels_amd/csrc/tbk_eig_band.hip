@@ -27,6 +27,22 @@ namespace {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Phase clock for tools/band_phase_clock.hip (compiled out of the library): cycles per phase, accumulated by
+// thread 0 of workgroup 0.
+#ifdef TBK_PHASE_CLOCK
+__device__ unsigned long long tbk_band_clock[32];
+#define TBK_CLK(k)                                              \
+    do {                                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {              \
+            const unsigned long long now_ = clock64();          \
+            tbk_band_clock[k] += now_ - clk_prev_;              \
+            clk_prev_ = now_;                                   \
+        }                                                       \
+    } while (0)
+#else
+#define TBK_CLK(k)
+#endif
+
 constexpr int PB = 8;    // panel height = band half-width
 constexpr int TS = 16;   // MFMA tile edge
 
@@ -129,7 +145,7 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 };
 
 template <int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int* __restrict__ flags) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double br_smem[];
@@ -157,11 +173,17 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
     // the pending-update buffer starts out empty
     for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
     bool have_update = false;
+#ifdef TBK_PHASE_CLOCK
+    unsigned long long clk_prev_ = clock64();
+#endif
 
     auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
 
     // ---- one pass over the tiles of the trailing triangle (model: big_pass) ----
-    // s: rows / columns below s are finished (their V / W / Vn rows are zero);  with_hemm: accumulate X = A Vn
+    // s: rows / columns below s are finished (their V / W / Vn rows are zero);  with_hemm: accumulate X = A Vn.
+    // A wave walks its visits (own block a = wave + NW q, step t: partner block a + t, cyclically) with the tile and
+    // the partner's [V | W] block of the NEXT visit already requested while it works on the current one; the
+    // workgroup meets once per step because the partner blocks of different steps overlap in sX.
     auto big_pass = [&](int s, bool with_update, bool with_hemm) {
         const int I0 = s / TS;
         const int na = nbk - I0;
@@ -169,146 +191,178 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
         double* tr = sTr + wave * (16 * 17);
         const int n_q = (na + NW - 1) / NW;
         const int n_t = na / 2;
-        for (int q = 0; q < n_q; ++q) {
-            const int a = wave + NW * q;
-            const bool own_valid = a < na;
-            const int I = I0 + a;
-            Frag own;
-            double own_b[4];
-            d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = (d4){0.0, 0.0, 0.0, 0.0};
-            if (own_valid) {
+        const int n_visits = n_q * (n_t + 1);
+
+        struct Visit {
+            bool active, diag, own_is_row;
+            int I, I2, Ir, Jc;
+            d4 tre, tim;
+            Frag par;
+        };
+        auto request = [&](int v, Visit& o) {  // issues the global loads of visit v: no waits, and no branches around
+            // the loads (the compiler's wait-count tracking gives up at a merge: it then waits for everything in flight);
+            // a record that is not `active` loads some valid tile and is ignored
+            const int vq = min(v, n_visits - 1);
+            const int q = vq / (n_t + 1), t = vq - q * (n_t + 1);
+            const int a_raw = wave + NW * q;
+            const int a = min(a_raw, na - 1);
+            o.active = v < n_visits && a_raw < na && !((na & 1) == 0 && t == n_t && t > 0 && a_raw >= n_t);
+            int a2 = a + t;
+            if (a2 >= na) a2 -= na;
+            o.I = I0 + a;
+            o.I2 = I0 + a2;
+            o.diag = (t == 0);
+            o.own_is_row = o.I <= o.I2;
+            o.Ir = o.own_is_row ? o.I : o.I2;
+            o.Jc = o.own_is_row ? o.I2 : o.I;
 #pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
-                    const d2 v = VW[((size_t)I * 4 + sg) * 64 + lane];
-                    own.re[sg] = v[0];
-                    own.im[sg] = v[1];
-                    own_b[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(I * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
-                }
+            for (int sg = 0; sg < 4; ++sg) {
+                const d2 v2 = VW[((size_t)o.I2 * 4 + sg) * 64 + lane];
+                o.par.re[sg] = v2[0];
+                o.par.im[sg] = v2[1];
             }
-            for (int t = 0; t <= n_t; ++t) {
-                bool active = own_valid && !((na & 1) == 0 && t == n_t && t > 0 && a >= n_t);
-                if (active) {
-                    int a2 = a + t;
-                    if (a2 >= na) a2 -= na;
-                    const int I2 = I0 + a2;
-                    const bool diag = (t == 0);
-                    const bool own_is_row = I <= I2;
-                    const int Ir = own_is_row ? I : I2, Jc = own_is_row ? I2 : I;
-                    // partner operands
-                    Frag par;
-                    double par_b[4];
+            // clamped addresses; rows / columns beyond n are masked when the tile is used
+            const int gc = o.Jc * TS + lrow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = o.Ir * TS + lq + 4 * r;
+                const d2 v2 = *Hat(min(gr, n - 1), min(gc, n - 1));
+                o.tre[r] = v2[0];
+                o.tim[r] = v2[1];
+            }
+        };
+
+        Visit va, vb;
+        Frag own;
+        double own_b[4];
+        d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = own1;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) own.re[sg] = own.im[sg] = own_b[sg] = 0.0;
+        // one visit: everything between the arrival of its operands and the step's meeting point
+        auto visit = [&](const Visit& cur, int v) {
+            const int q = v / (n_t + 1), t = v - q * (n_t + 1);
+            TBK_CLK(10);
+            if (cur.active) {
+                const bool diag = cur.diag, own_is_row = cur.own_is_row;
+                const int I2 = cur.I2, Ir = cur.Ir, Jc = cur.Jc;
+                if (diag) {  // first visit of an own block: its operands are this visit's "partner" loads
+                    own = cur.par;
+                    own1 = (d4){0.0, 0.0, 0.0, 0.0};
+                    own2 = own1;
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg)
+                        own_b[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(cur.I * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                }
+                double par_b[4];
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg)
+                    par_b[sg] = diag ? own_b[sg]
+                                     : reinterpret_cast<const double*>(sVn)[(size_t)(I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                d4 tre = cur.tre, tim = cur.tim;
+                const int gc = Jc * TS + lrow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool inside = Ir * TS + lq + 4 * r < n && gc < n;
+                    tre[r] = inside ? tre[r] : 0.0;
+                    tim[r] = inside ? tim[r] : 0.0;
+                }
+                if (with_update) {
+                    // tile -= [V | W]_row . ([W | V]_col)^H : A = row block, k-step sg; B = conj(col block, k-step (sg + 2) % 4)
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg) {
-                        if (with_update && !diag) {
-                            const d2 v = VW[((size_t)I2 * 4 + sg) * 64 + lane];
-                            par.re[sg] = v[0];
-                            par.im[sg] = v[1];
-                        } else {
-                            par.re[sg] = own.re[sg];
-                            par.im[sg] = own.im[sg];
-                        }
-                        par_b[sg] = diag ? own_b[sg]
-                                         : reinterpret_cast<const double*>(sVn)[(size_t)(I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                        const int sb = (sg + 2) & 3;
+                        const double ar = own_is_row ? own.re[sg] : cur.par.re[sg], ai = own_is_row ? own.im[sg] : cur.par.im[sg];
+                        const double br = own_is_row ? cur.par.re[sb] : own.re[sb], bi = own_is_row ? cur.par.im[sb] : own.im[sb];
+                        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, tre, 0, 0, 1);  // -ar br
+                        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, tre, 0, 0, 1);  // -ai bi
+                        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, tim, 0, 0, 1);  // -ai br
+                        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, tim, 0, 0, 0);  // +ar bi
                     }
-                    // the tile, accumulator layout: lane l holds (row lq + 4 r, column lrow)
-                    d4 tre, tim;
-                    const int gc = Jc * TS + lrow;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gr = Ir * TS + lq + 4 * r;
-                        d2 v = (d2){0.0, 0.0};
-                        if (gr < n && gc < n) v = *Hat(gr, gc);
-                        tre[r] = v[0];
-                        tim[r] = v[1];
+                        if (gr < n && gc < n) *Hat(gr, gc) = (d2){tre[r], tim[r]};
                     }
-                    if (with_update) {
-                        // tile -= [V | W]_row . ([W | V]_col)^H : A = row block, k-step sg; B = conj(col block, k-step (sg + 2) % 4)
+                }
+                TBK_CLK(11);
+                if (with_hemm) {
+                    // transposed copy [lrow][lq + 4 sg] through this wave's LDS plane, real part then imaginary part: a
+                    // wave's LDS operations execute in order, so the plane is reused without waiting in between
+                    // (compiler fences only: no hardware wait between the groups; `volatile` accesses would each get an
+                    // s_waitcnt vmcnt(0), i.e. wait for this visit's tile stores)
+                    double ttre[4], ttim[4];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tre[r];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) ttre[sg] = tr[lrow * 17 + lq + 4 * sg];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tim[r];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
+                    asm volatile("" ::: "memory");
+                    TBK_CLK(12);
+                    d4 p1 = (d4){0.0, 0.0, 0.0, 0.0}, p2 = p1, q1 = p1, q2 = p1;
+                    if (diag) {
+                        // Hermitian tile of which only the upper part is valid: operand element [i = lrow][j = lq + 4 sg]
+                        // is the transposed copy where i <= j, the conjugate of the accumulator element otherwise
 #pragma unroll
                         for (int sg = 0; sg < 4; ++sg) {
-                            const int sb = (sg + 2) & 3;
-                            const double ar = own_is_row ? own.re[sg] : par.re[sg], ai = own_is_row ? own.im[sg] : par.im[sg];
-                            const double br = own_is_row ? par.re[sb] : own.re[sb], bi = own_is_row ? par.im[sb] : own.im[sb];
-                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, tre, 0, 0, 1);  // -ar br
-                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, tre, 0, 0, 1);  // -ai bi
-                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, tim, 0, 0, 1);  // -ai br
-                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, tim, 0, 0, 0);  // +ar bi
+                            const bool upper = lrow <= lq + 4 * sg;
+                            const double ar = upper ? ttre[sg] : tre[sg];
+                            const double ai = upper ? ttim[sg] : -tim[sg];
+                            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, own_b[sg], p1, 0, 0, 0);
+                            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, own_b[sg], p2, 0, 0, 0);
                         }
+                        own1 += p1;
+                        own2 += p2;
+                    } else {
+                        // row part  X_Ir += tile Vn_Jc ;  column part  X_Jc += tile^H Vn_Ir
+                        const double* b_col = own_is_row ? par_b : own_b;  // Vn of the column block
+                        const double* b_row = own_is_row ? own_b : par_b;  // Vn of the row block
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int gr = Ir * TS + lq + 4 * r;
-                            if (gr < n && gc < n) *Hat(gr, gc) = (d2){tre[r], tim[r]};
+                        for (int sg = 0; sg < 4; ++sg) {
+                            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], b_col[sg], p1, 0, 0, 0);
+                            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], b_col[sg], p2, 0, 0, 0);
+                            q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], b_row[sg], q1, 0, 0, 0);
+                            q2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], b_row[sg], q2, 0, 0, 1);  // conj
                         }
-                    }
-                    if (with_hemm) {
-                        // transposed copy through this wave's LDS plane: element [lrow][lq + 4 sg]
-                        double ttre[4], ttim[4];
-                        asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tre[r];
-                        lds_fence();
-#pragma unroll
-                        for (int sg = 0; sg < 4; ++sg) ttre[sg] = tr[lrow * 17 + lq + 4 * sg];
-                        lds_fence();
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tim[r];
-                        lds_fence();
-#pragma unroll
-                        for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
-                        lds_fence();
-                        d4 p1 = (d4){0.0, 0.0, 0.0, 0.0}, p2 = p1, q1 = p1, q2 = p1;
-                        if (diag) {
-                            // Hermitian tile of which only the upper part is valid: operand element [i = lrow][j = lq + 4 sg]
-                            // is the transposed copy where i <= j, the conjugate of the accumulator element otherwise
-#pragma unroll
-                            for (int sg = 0; sg < 4; ++sg) {
-                                const bool upper = lrow <= lq + 4 * sg;
-                                const double ar = upper ? ttre[sg] : tre[sg];
-                                const double ai = upper ? ttim[sg] : -tim[sg];
-                                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, own_b[sg], p1, 0, 0, 0);
-                                p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, own_b[sg], p2, 0, 0, 0);
-                            }
+                        d4 o1, o2;
+                        if (own_is_row) {
                             own1 += p1;
                             own2 += p2;
+                            o1 = q1;
+                            o2 = q2;
                         } else {
-                            // row part  X_Ir += tile Vn_Jc ;  column part  X_Jc += tile^H Vn_Ir
-                            const double* b_col = own_is_row ? par_b : own_b;  // Vn of the column block
-                            const double* b_row = own_is_row ? own_b : par_b;  // Vn of the row block
+                            own1 += q1;
+                            own2 += q2;
+                            o1 = p1;
+                            o2 = p2;
+                        }
+                        // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
+                        double* xs = reinterpret_cast<double*>(sX);
 #pragma unroll
-                            for (int sg = 0; sg < 4; ++sg) {
-                                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], b_col[sg], p1, 0, 0, 0);
-                                p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], b_col[sg], p2, 0, 0, 0);
-                                q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], b_row[sg], q1, 0, 0, 0);
-                                q2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], b_row[sg], q2, 0, 0, 1);  // conj
-                            }
-                            d4 o1, o2;
-                            if (own_is_row) {
-                                own1 += p1;
-                                own2 += p2;
-                                o1 = q1;
-                                o2 = q2;
-                            } else {
-                                own1 += q1;
-                                own2 += q2;
-                                o1 = p1;
-                                o2 = p2;
-                            }
-                            // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
-                            double* xs = reinterpret_cast<double*>(sX);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const double rot = dpp_mov<0x128>(o2[r]);  // the other half of the 16-lane row
-                                const double val = (lrow < 8) ? o1[r] - rot : o1[r] + rot;
-                                const size_t at = (size_t)(I2 * TS + lq + 4 * r) * 16 + 2 * (lrow & 7) + (lrow >> 3);
-                                xs[at] += val;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const double rot = dpp_mov<0x128>(o2[r]);  // the other half of the 16-lane row
+                            const double val = (lrow < 8) ? o1[r] - rot : o1[r] + rot;
+                            const size_t at = (size_t)(I2 * TS + lq + 4 * r) * 16 + 2 * (lrow & 7) + (lrow >> 3);
+                            xs[at] += val;
                         }
                     }
                 }
-                wg_sync();  // partner blocks of different steps overlap
             }
-            if (with_hemm) {
-                if (own_valid) {
+            TBK_CLK(13);
+            // the step's meeting point: LDS only (this wave's tile stores drain in the background)
+            lds_fence();
+            __syncthreads();
+            TBK_CLK(14);
+            if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
+                if (wave + NW * q < na) {
                     double* xs = reinterpret_cast<double*>(sX);
+                    const int I = I0 + wave + NW * q;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double rot = dpp_mov<0x128>(own2[r]);
@@ -317,9 +371,21 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                         xs[at] += val;
                     }
                 }
-                wg_sync();
+                lds_fence();
+                __syncthreads();
+            }
+        };
+        // two visit records in turn (no register copies: a copy of a record waits for its loads where it stands)
+        request(0, va);
+        for (int v = 0; v < n_visits; v += 2) {
+            request(v + 1, vb);
+            visit(va, v);
+            if (v + 1 < n_visits) {
+                request(v + 2, va);
+                visit(vb, v + 1);
             }
         }
+        wg_sync();  // tile stores complete before anybody re-reads the matrix
     };
 
     const int i_row = tid;  // thread <-> global row / column index in the thread-per-row phases
@@ -329,6 +395,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
         const int s = g0 + PB;       // start of the trailing matrix behind it
         const int m = n - s;
         if (m < 2) break;
+        TBK_CLK(6);
         // ---- look-ahead: block row p (8 rows, columns >= 8 p) brought up to date with the pending (V, W) ----
         if (have_update && tid < 128) sG[tid] = VW[vw_index(g0 + (tid >> 4), tid & 15)];
         wg_sync();
@@ -340,12 +407,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
 #pragma unroll
             for (int r = 0; r < PB; ++r) {
                 const int g = g0 + r;
-                if (g < n) {
-                    if (i_row >= g) {
-                        x[r] = *Hat(g, i_row);
-                    } else {
-                        x[r] = conjd(*Hat(i_row, g));
-                    }
+                if (g < n) {  // uniform; one unconditional load of the stored (upper) element either way
+                    const bool upper = i_row >= g;
+                    const d2 v = *Hat(upper ? g : i_row, upper ? i_row : g);
+                    x[r] = upper ? v : conjd(v);
                 }
             }
             if (have_update) {
@@ -368,6 +433,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                     if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[r];
             }
         }
+        TBK_CLK(0);
         // ---- Householder QR of the panel on threads i >= s: y = conj(x) (model: panel_qr) ----
         const bool qr_row = i_row >= s && i_row < n;
         d2 y[PB], vn[PB];
@@ -443,6 +509,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
             for (int r = 0; r < PB; ++r)
                 if (g0 + r < n) *Hat(g0 + r, i_row) = (r >= c) ? conjd(y[r]) : (d2){0.0, 0.0};
         }
+        TBK_CLK(1);
         // ---- T of the compact WY form from the Gram matrix of V (model: t_factor); kept in LDS over the big pass ----
         {
             // G[c2][c] = sum_i conj(v_c2) v_c for c2 < c: 28 complex sums, pair (c, c2) at slot 2 (c (c - 1) / 2 + c2)
@@ -484,6 +551,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                 }
             }
         }
+        TBK_CLK(2);
         // ---- hand over: Vn to LDS, X cleared, the consumed pending rows zeroed ----
         if (i_row < npad) {
 #pragma unroll
@@ -494,7 +562,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
         }
         if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
         wg_sync();
+        TBK_CLK(3);
         big_pass(s, have_update, true);
+        TBK_CLK(4);
         // ---- W = X T - V S / 2,  S = T^H (V^H X) T  (model: stage1_band) ----
         d2 xr[PB], vr[PB];  // this thread's rows of A V and of V, back from LDS (nothing lives in registers over the pass)
 #pragma unroll
@@ -575,6 +645,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
         }
         have_update = true;
         wg_sync();
+        TBK_CLK(5);
     }
     // the last pending update (no look-ahead consumed any of its rows)
     if (have_update) big_pass(PB * p, true, false);

@@ -1,0 +1,72 @@
+// Cycles per phase of band_reduce_kernel (workgroup 0, while the whole grid runs) and the time of both kernels of
+// the two-stage reduction without PCIe in the way.  Build here, run on the GPU box:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DTBK_PHASE_CLOCK -Iinclude -Itbmodels_amd/csrc \
+//         tools/band_phase_clock.hip -o tools/band_phase_clock -lrocblas && tools/band_phase_clock 256 4096
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../tbmodels_amd/csrc/tbk_eig_band.hip"
+
+void tbk_set_error(const char*, ...) {}
+int DevBuf::reserve(size_t) { return 0; }
+void DevBuf::release() {}
+StageTimer::StageTimer(tbk_model* m_, int, hipStream_t s) : m(m_), on(false), stream(s) {}
+StageTimer::~StageTimer() {}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 256;
+    const int nk = argc > 2 ? atoi(argv[2]) : 4096;
+    std::vector<double> h((size_t)n * n * 2);
+    srand(1);
+    for (auto& x : h) x = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < n; ++i) h[((size_t)i * n + i) * 2 + 1] = 0.0;
+    double *d_H0, *d_H, *d_de;
+    void* d_vw;
+    hipMalloc(&d_H0, (size_t)nk * n * n * 16);
+    hipMalloc(&d_H, (size_t)nk * n * n * 16);
+    hipMalloc(&d_de, (size_t)nk * n * 16);
+    hipMalloc(&d_vw, (size_t)nk * tbk_band_scratch_per_matrix(n));
+    for (int k = 0; k < nk; ++k) hipMemcpy(d_H0 + (size_t)k * n * n * 2, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    tbk_model m;
+    m.n_orb = n;
+    unsigned long long zero[32] = {0};
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(d_H, d_H0, (size_t)nk * n * n * 16, hipMemcpyDeviceToDevice);
+#ifdef TBK_PHASE_CLOCK
+        hipMemcpyToSymbol(HIP_SYMBOL(tbk_band_clock), zero, sizeof(zero));
+#endif
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipDeviceSynchronize();
+        hipEventRecord(a, nullptr);
+        tbk_launch_tridiag_band(&m, nullptr, d_H, nk, d_de, d_vw);
+        hipEventRecord(b, nullptr);
+        hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        unsigned long long clk[32] = {0};
+#ifdef TBK_PHASE_CLOCK
+        hipMemcpyFromSymbol(clk, HIP_SYMBOL(tbk_band_clock), sizeof(clk));
+#endif
+        printf("n=%d nk=%d  both kernels %.2f ms  (%.3f us per matrix)\n", n, nk, ms, ms * 1e3 / nk);
+#ifndef TBK_PHASE_CLOCK
+        (void)zero;
+        continue;
+#endif
+        if (rep == 2) {
+            const char* name[16] = {"0 look-ahead", "1 panel QR", "2 T factor", "3 hand-over", "4 big pass (whole)", "5 W", "6 loop top",
+                                    "", "", "", "10 pass: loads issued", "11 pass: update + store", "12 pass: transposition",
+                                    "13 pass: products + X", "14 pass: barrier", ""};
+            double total = 0;
+            for (int k = 0; k <= 6; ++k) total += (double)clk[k];
+            double inner = 0;
+            for (int k = 10; k <= 14; ++k) inner += (double)clk[k];
+            for (int k = 0; k <= 14; ++k)
+                if (name[k][0]) printf("   %-28s %12.0f cycles  %5.1f %%\n", name[k], (double)clk[k], 100.0 * clk[k] / total);
+            printf("   (phases 10-14 are inside phase 4; their sum %.0f; the clock runs at 100 MHz: x%.0f for shader cycles)\n", inner, 24.0);
+        }
+    }
+    return 0;
+}
