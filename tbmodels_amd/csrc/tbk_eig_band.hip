@@ -31,13 +31,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // thread 0 of workgroup 0.
 #ifdef TBK_PHASE_CLOCK
 __device__ unsigned long long tbk_band_clock[32];
+// (accumulated in registers and written once at the end: a global update per point would wait for every load in flight)
 #define TBK_CLK(k)                                              \
     do {                                                        \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {              \
-            const unsigned long long now_ = clock64();          \
-            tbk_band_clock[k] += now_ - clk_prev_;              \
-            clk_prev_ = now_;                                   \
-        }                                                       \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        clk_acc_[k] += now_ - clk_prev_;                        \
+        clk_prev_ = now_;                                       \
     } while (0)
 #else
 #define TBK_CLK(k)
@@ -174,7 +173,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
     for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
     bool have_update = false;
 #ifdef TBK_PHASE_CLOCK
-    unsigned long long clk_prev_ = clock64();
+    unsigned long long clk_acc_[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) clk_acc_[k] = 0;
+    unsigned long long clk_prev_ = __builtin_readcyclecounter();
 #endif
 
     auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
@@ -241,7 +243,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
         // one visit: everything between the arrival of its operands and the step's meeting point
         auto visit = [&](const Visit& cur, int v) {
             const int q = v / (n_t + 1), t = v - q * (n_t + 1);
-            TBK_CLK(10);
+            TBK_CLK(7);
             if (cur.active) {
                 const bool diag = cur.diag, own_is_row = cur.own_is_row;
                 const int I2 = cur.I2, Ir = cur.Ir, Jc = cur.Jc;
@@ -284,7 +286,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                         if (gr < n && gc < n) *Hat(gr, gc) = (d2){tre[r], tim[r]};
                     }
                 }
-                TBK_CLK(11);
+                TBK_CLK(8);
                 if (with_hemm) {
                     // transposed copy [lrow][lq + 4 sg] through this wave's LDS plane, real part then imaginary part: a
                     // wave's LDS operations execute in order, so the plane is reused without waiting in between
@@ -304,7 +306,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
                     asm volatile("" ::: "memory");
-                    TBK_CLK(12);
+                    TBK_CLK(9);
                     d4 p1 = (d4){0.0, 0.0, 0.0, 0.0}, p2 = p1, q1 = p1, q2 = p1;
                     if (diag) {
                         // Hermitian tile of which only the upper part is valid: operand element [i = lrow][j = lq + 4 sg]
@@ -354,11 +356,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                     }
                 }
             }
-            TBK_CLK(13);
+            TBK_CLK(10);
             // the step's meeting point: LDS only (this wave's tile stores drain in the background)
             lds_fence();
             __syncthreads();
-            TBK_CLK(14);
+            TBK_CLK(11);
             if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
                 if (wave + NW * q < na) {
                     double* xs = reinterpret_cast<double*>(sX);
@@ -649,6 +651,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
     }
     // the last pending update (no look-ahead consumed any of its rows)
     if (have_update) big_pass(PB * p, true, false);
+#ifdef TBK_PHASE_CLOCK
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 16; ++k) tbk_band_clock[k] = clk_acc_[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
