@@ -340,7 +340,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1]};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);
     delete m;
@@ -471,8 +471,11 @@ constexpr int64_t TBK_SMALL_CALL = 4096;
 // (Up to 12 orbitals the QL chain used to be the shorter one -- 61 us at n = 8 -- until small matrices got the idle
 // lanes of their wave for multisection: 1000 silicon k-points 59 -> 20 us, so small calls bisect at every size now.)
 
-static int launch_tridiag_eigenvalues(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E,
-                                      bool beside_ql = false, bool small_call = false) {
+static int launch_tridiag_eigenvalues(tbk_model* m, hipStream_t s, double* d_de, int64_t nk, double* d_E,
+                                      bool beside_ql = false, bool small_call = false, const void* d_band = nullptr) {
+    // two-stage reduction: the second stage (band -> tridiagonal) of this chunk runs here, in front of its bisection --
+    // on the tridiagonal stream, i.e. next to the first stage of the following chunk
+    if (d_band) TBK_CHECK(tbk_launch_band_chase(m, s, d_band, nk, d_de));
     if (tbk_eig_small_supported(m->n_orb) && !small_call) return tbk_launch_ql(m, s, d_de, nk, d_E, beside_ql);
     return tbk_launch_bisect(m, s, d_de, nk, d_E);
 }
@@ -529,6 +532,11 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
     double* d_H = m->ws_H.as<double>();
+    const bool two_stage = !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m) && n_chunks > 1;
+    if (two_stage) {
+        TBK_CHECK(m->ws_band.reserve((size_t)max_chunk * tbk_band_scratch_per_matrix(m->n_orb)));
+        for (int b = 0; b < 2; ++b) TBK_CHECK(m->ws_bandmat[b].reserve((size_t)max_chunk * tbk_band_bytes_per_matrix(m->n_orb)));
+    }
     if (n_chunks == 1) {
         // one chunk has nothing to overlap: everything in order on the main stream, no cross-stream events (they
         // cost more than the kernels of a single-k call)
@@ -556,14 +564,17 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_hk[b], 0));
         if (tbk_eig_small_supported(m->n_orb))
             TBK_CHECK(tbk_launch_tridiag(m, m->stream_eig, d_H, nkc, d_de));
+        else if (two_stage)
+            TBK_CHECK(tbk_launch_band_reduce(m, m->stream_eig, d_H, nkc, m->ws_band.ptr, m->ws_bandmat[b].ptr));
         else
             TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream_eig, d_H, nkc, d_de));
         TBK_HIP(hipEventRecord(m->ev_tri[b], m->stream_eig));
 
-        if (c >= 1) {  // QL of the previous chunk, alongside this chunk's reduction
+        if (c >= 1) {  // tridiagonal stage of the previous chunk, alongside this chunk's reduction
             TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
             TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
-                                                 d_E + (size_t)prev_c0 * n, false, small_call));
+                                                 d_E + (size_t)prev_c0 * n, false, small_call,
+                                                 two_stage ? m->ws_bandmat[b ^ 1].ptr : nullptr));
             TBK_HIP(hipEventRecord(m->ev_ql[b ^ 1], m->stream_ql));
         }
         prev_c0 = c0;
@@ -576,7 +587,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         const int b = (int)((n_chunks - 1) & 1);
         TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_eig, debuf[b]->as<double>(), prev_nkc,
                                              d_E + (size_t)prev_c0 * n, n_chunks > 1,
-                                             small_call || n_chunks > 1));
+                                             small_call || n_chunks > 1, two_stage ? m->ws_bandmat[b].ptr : nullptr));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_eig));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues

@@ -111,6 +111,32 @@ __device__ __forceinline__ void wg_sync() {
 }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// 1 / x and (sqrt(x), 1 / sqrt(x)) from the hardware estimates plus Newton steps: a dozen instructions less per call
+// than IEEE division / sqrt, on the serial path of every Householder step.  x > 0 and well inside the double range
+// (the callers' x are squared norms: matrices scaled below 1e-150 would have underflowed there already).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& root, double& rroot) {
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    root = fma(d, h, g);
+    rroot = 2.0 * h;
+    e = fma(-root, rroot, 1.0);  // one more step for the reciprocal
+    rroot = fma(rroot, e, rroot);
+}
+
 // Workgroup sums of up to 64 per-thread values, fixed order (transposed butterflies inside a wave, then the waves in
 // index order).  Values are handed over four at a time -- wave_partial4(slot, ...) for slots 0, 4, 8, ... -- so that
 // a caller never holds more than four of them in registers; wg_finish(nv) makes the totals readable in s_tot[0 .. nv).
@@ -145,7 +171,7 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 
 template <int NT>
 __global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
-band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int* __restrict__ flags) {
+band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ band_all) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double br_smem[];
     const int tid = threadIdx.x;
@@ -159,15 +185,17 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
     double* sPart = sTr + NW * 16 * 17;                    // [NW][64]
     double* sTot = sPart + NW * 64;                        // [64]
     d2* sRow = reinterpret_cast<d2*>(sTot + 64);           // [2][8] row c of the panel (QR), broadcast; alternating
-    d2* sG = sRow + 16;                                    // [8][16] the pending [V | W] rows of the look-ahead
-    d2* sS = sG + 128;                                     // [64]  S = T^H M T
+    // [8][16] the pending [V | W] rows of the look-ahead: only alive between two barriers before the panel's first
+    // reduction, so it shares the partial-sum area (2 KiB: with it apart, two workgroups of the 256-orbital kernel
+    // left no room on a CU for a bisection workgroup of the previous chunk)
+    d2* sG = reinterpret_cast<d2*>(sPart);
+    d2* sS = sRow + 16;                                    // [64]  S = T^H M T
     d2* sT = sS + 64;                                      // [8][8] T of the current panel
     d2* sTau = sT + 64;                                    // [8]
 
     const size_t mat = blockIdx.x;
     double* H = Hall + mat * (size_t)n * n * 2;
     d2* VW = VWall + mat * (size_t)nbk * 256;
-    (void)flags;
 
     // the pending-update buffer starts out empty
     for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
@@ -435,6 +463,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                     if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[r];
             }
         }
+        if (have_update) {  // the pending rows (sG) share their LDS with the partial sums of the reductions below
+            lds_fence();
+            __syncthreads();
+        }
         TBK_CLK(0);
         // ---- Householder QR of the panel on threads i >= s: y = conj(x) (model: panel_qr) ----
         const bool qr_row = i_row >= s && i_row < n;
@@ -467,18 +499,33 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
 #pragma unroll
                     for (int cp = 0; cp < PB; ++cp) row_buf[cp] = y[cp];
                 }
+                TBK_CLK(12);  // QR: products
+                // ONE meeting per step: every wave leaves its 16 partial sums (alternating halves of its row of the
+                // partial-sum area), and every thread adds the waves' partials itself, in wave order
+                double* part = sPart + (c & 1) * 16;
 #pragma unroll
-                for (int k4 = 0; k4 < 16; k4 += 4) wave_partial4(k4, pv[k4], pv[k4 + 1], pv[k4 + 2], pv[k4 + 3], sPart, lane, wave);
-                wg_finish<NW>(16, sPart, sTot, tid);
-                const double gcc = sTot[0];
+                for (int k4 = 0; k4 < 16; k4 += 4) wave_partial4(k4, pv[k4], pv[k4 + 1], pv[k4 + 2], pv[k4 + 3], part, lane, wave);
+                TBK_CLK(13);  // QR: wave sums
+                lds_fence();
+                __syncthreads();
+                TBK_CLK(14);  // QR: barrier
+                auto total = [&](int k) {  // (summed where it is used: sixteen totals held at once spilled at 8 waves)
+                    double acc = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) acc += part[w * 64 + k];
+                    return acc;
+                };
+                const double gcc = total(0);
                 const d2 alpha = row_buf[c];
                 const double sigma = gcc - (alpha[0] * alpha[0] + alpha[1] * alpha[1]);
                 if (!(gcc == 0.0 || (sigma == 0.0 && alpha[1] == 0.0))) {  // uniform
-                    const double beta = -copysign(sqrt(gcc), alpha[0]);
-                    const double rbeta = 1.0 / beta;
+                    double root, rroot;
+                    fast_sqrt_rsqrt(gcc, root, rroot);
+                    const double beta = -copysign(root, alpha[0]);
+                    const double rbeta = -copysign(rroot, alpha[0]);
                     tau[c] = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
                     const double qr_ = alpha[0] - beta, qi_ = alpha[1];
-                    const double qn = 1.0 / (qr_ * qr_ + qi_ * qi_);
+                    const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
                     const d2 scale = (d2){qr_ * qn, -qi_ * qn};  // 1 / (alpha - beta)
                     d2 v = (d2){0.0, 0.0};
                     if (below) v = (i_row == s + c) ? (d2){1.0, 0.0} : cmul(y[c], scale);
@@ -486,7 +533,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                     const d2 ctau = conjd(tau[c]);
 #pragma unroll
                     for (int cp = c + 1; cp < PB; ++cp) {
-                        const d2 g = (d2){sTot[1 + 2 * (cp - c - 1)], sTot[2 + 2 * (cp - c - 1)]};
+                        const d2 g = (d2){total(1 + 2 * (cp - c - 1)), total(2 + 2 * (cp - c - 1))};
                         const d2 rowv = row_buf[cp];
                         // z = conj(scale) (g - conj(alpha) row) + row
                         d2 t = g;
@@ -504,6 +551,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
                 }
             }
         }
+        TBK_CLK(15);  // QR: reflector + update (and whatever follows the last step)
         // thread s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
         if (qr_row && i_row < s + PB) {
             const int c = i_row - s;
@@ -651,8 +699,19 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, int
     }
     // the last pending update (no look-ahead consumed any of its rows)
     if (have_update) big_pass(PB * p, true, false);
+    // the band leaves in compact form -- band[i][dd] = H[i][i + dd], dd = 0..8 -- so that the matrix buffer is free for
+    // the next chunk's H(k) while the second stage still works on this one
+    wg_sync();
+    {
+        d2* band = band_all + mat * (size_t)n * (PB + 1);
+        for (int idx = tid; idx < n * (PB + 1); idx += NT) {
+            const int i = idx / (PB + 1), dd = idx - i * (PB + 1);
+            band[idx] = (i + dd < n) ? *Hat(i, i + dd) : (d2){0.0, 0.0};
+        }
+    }
 #ifdef TBK_PHASE_CLOCK
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    // (the last wave: its rows stay in the trailing matrix until the end, wave 0 idles at the barriers from panel 8 on)
+    if (blockIdx.x == 0 && threadIdx.x == NT - 64)
         for (int k = 0; k < 16; ++k) tbk_band_clock[k] = clk_acc_[k];
 #endif
 }
@@ -716,11 +775,13 @@ __device__ __forceinline__ Reflector make_reflector(d2 xa, d2 xb, int a, int b) 
     h.va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
     h.vb = (b == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
     if (!(sigma == 0.0 && alpha[1] == 0.0)) {
-        const double beta = -copysign(sqrt(alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma), alpha[0]);
-        const double rbeta = 1.0 / beta;
+        double root, rroot;
+        fast_sqrt_rsqrt(alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma, root, rroot);
+        const double beta = -copysign(root, alpha[0]);
+        const double rbeta = -copysign(rroot, alpha[0]);
         h.tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
         const double qr_ = alpha[0] - beta, qi_ = alpha[1];
-        const double qn = 1.0 / (qr_ * qr_ + qi_ * qi_);
+        const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
         const d2 scale = (d2){qr_ * qn, -qi_ * qn};
         if (a != 0) h.va = cmul(xa, scale);
         if (b != 0) h.vb = cmul(xb, scale);
@@ -731,7 +792,7 @@ __device__ __forceinline__ Reflector make_reflector(d2 xa, d2 xb, int a, int b) 
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
-band_chase_kernel(const double* __restrict__ Hall, int n, int np, double* __restrict__ D, double* __restrict__ E) {
+band_chase_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
     extern __shared__ __attribute__((aligned(16))) double bc_smem[];
     d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
     int* sStart = reinterpret_cast<int*>(sL + (size_t)16 * np);     // [n] first tick of every sweep
@@ -740,7 +801,7 @@ band_chase_kernel(const double* __restrict__ Hall, int n, int np, double* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 7, b = lane >> 3;
     const size_t mat = blockIdx.x;
-    const double* H = Hall + mat * (size_t)n * n * 2;
+    const d2* band = band_all + mat * (size_t)n * (PB + 1);
 
     auto L = [&](int i, int j) -> d2& { return sL[(size_t)(i - j) * np + j]; };
 
@@ -750,7 +811,7 @@ band_chase_kernel(const double* __restrict__ Hall, int n, int np, double* __rest
     for (int i = tid; i < n * (PB + 1); i += NW * 64) {
         const int j = i / (PB + 1), dd = i % (PB + 1);
         if (j + dd < n) {
-            const d2 v = *reinterpret_cast<const d2*>(H + ((size_t)j * n + j + dd) * 2);
+            const d2 v = band[i];
             sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
         }
     }
@@ -759,7 +820,7 @@ band_chase_kernel(const double* __restrict__ Hall, int n, int np, double* __rest
     if (tid == 0) {
         for (int s = 0; s < n_sweeps; ++s) {
             int t0 = 0;
-            if (s > 0) t0 = sStart[s - 1] + 3;
+            if (s > 0) t0 = sStart[s - 1] + stagger;
             if (s >= NW) t0 = max(t0, sStart[s - NW] + sweep_len(s - NW));
             sStart[s] = t0;
         }
@@ -867,42 +928,62 @@ static int chase_pitch(int n) {
 
 bool tbk_eig_band_supported(int n) { return n > 64 && n <= 512; }
 
-// d_de: d[nk][n] followed by e[nk][n]; the upper triangle of every d_H matrix is overwritten; d_vw: scratch of
-// tbk_band_scratch_per_matrix(n) bytes per matrix
-int tbk_launch_tridiag_band(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, void* d_vw) {
+size_t tbk_band_bytes_per_matrix(int n) { return (size_t)n * (PB + 1) * sizeof(d2); }
+
+// Stage one: the upper triangle of every d_H matrix is overwritten; d_vw: scratch of tbk_band_scratch_per_matrix(n)
+// bytes per matrix; d_band receives the band, tbk_band_bytes_per_matrix(n) bytes per matrix.
+int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band) {
+    const int n = m->n_orb;
+    if (nk == 0) return TBK_OK;
+    StageTimer t(m, TBK_T_EIG, s);
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const bool small = n <= 256;
+    const int nw = small ? 4 : 8;
+    const size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+    static bool raised_a[TBK_MAX_DEVICES] = {}, raised_b[TBK_MAX_DEVICES] = {};
+    if (small) {
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<256>), (int)lds, raised_a));
+        hipLaunchKernelGGL(band_reduce_kernel<256>, dim3((unsigned)nk), dim3(256), lds, s, d_H, n, static_cast<d2*>(d_vw),
+                           static_cast<d2*>(d_band));
+    } else {
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<512>), (int)lds, raised_b));
+        hipLaunchKernelGGL(band_reduce_kernel<512>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, static_cast<d2*>(d_vw),
+                           static_cast<d2*>(d_band));
+    }
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
+// Stage two: d_band -> d_de = d[nk][n] followed by e[nk][n]
+int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     double* d_D = d_de;
     double* d_E = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
-    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
-    {
-        const bool small = n <= 256;
-        const int nw = small ? 4 : 8;
-        const size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 128 + 64 + 64 + 8) * 16;
-        static bool raised_a[TBK_MAX_DEVICES] = {}, raised_b[TBK_MAX_DEVICES] = {};
-        if (small) {
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<256>), (int)lds, raised_a));
-            hipLaunchKernelGGL(band_reduce_kernel<256>, dim3((unsigned)nk), dim3(256), lds, s, d_H, n, static_cast<d2*>(d_vw),
-                               m->ws_flag.as<int>());
-        } else {
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<512>), (int)lds, raised_b));
-            hipLaunchKernelGGL(band_reduce_kernel<512>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, static_cast<d2*>(d_vw),
-                               m->ws_flag.as<int>());
-        }
-        TBK_HIP(hipGetLastError());
-    }
     {
         const int np = chase_pitch(n);
         const size_t lds = (size_t)16 * np * 16 + (size_t)n * sizeof(int) + 16;
-        static bool raised_c[TBK_MAX_DEVICES] = {}, raised_d[TBK_MAX_DEVICES] = {};
-        if (n <= 256) {
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<8>), (int)lds, raised_c));
-            hipLaunchKernelGGL(band_chase_kernel<8>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, np, d_D, d_E);
-        } else {
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<16>), (int)lds, raised_d));
-            hipLaunchKernelGGL(band_chase_kernel<16>, dim3((unsigned)nk), dim3(1024), lds, s, d_H, n, np, d_D, d_E);
-        }
+        // Consecutive sweeps run `stagger` chase steps apart: 2 is the closest that keeps the steps of one tick on
+        // disjoint cells (tools/two_stage_model.py: check_pipeline).  Waves per workgroup: enough sweeps in flight to
+        // fill that pipeline (a sweep is ~n / 8 steps long).  TBK_CHASE_NW / TBK_CHASE_STAGGER: measurements only.
+        static const int env_nw = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
+        static const int env_stagger = getenv("TBK_CHASE_STAGGER") ? atoi(getenv("TBK_CHASE_STAGGER")) : 0;
+        const int stagger = env_stagger >= 2 ? env_stagger : 2;
+        int nw = env_nw ? env_nw : (n <= 128 ? 4 : n <= 256 ? 8 : 16);
+        static bool raised[3][TBK_MAX_DEVICES] = {};
+#define TBK_CHASE(NWV, SLOT)                                                                                              \
+    do {                                                                                                                  \
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<NWV>), (int)lds, raised[SLOT]));      \
+        hipLaunchKernelGGL(band_chase_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
+    } while (0)
+        if (nw <= 4)
+            TBK_CHASE(4, 0);
+        else if (nw <= 8)
+            TBK_CHASE(8, 1);
+        else
+            TBK_CHASE(16, 2);
+#undef TBK_CHASE
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;

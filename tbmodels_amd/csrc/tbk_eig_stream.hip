@@ -606,20 +606,24 @@ hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double*
 
 bool tbk_eig_stream_supported(int n) { return n > 64 && n <= ST_MAXN; }
 
+// two-stage reduction (tbk_eig_band.hip) unless TBK_BAND=0 asks for the one-stage kernel of this file
+bool tbk_eig_two_stage(const tbk_model* m) {
+    static const bool band = [] {
+        const char* v = getenv("TBK_BAND");
+        return v == nullptr || atoi(v) != 0;
+    }();
+    return band && tbk_eig_band_supported(m->n_orb);
+}
+
 // d_de: d[nk][n] followed by e[nk][n]; d_H (upper triangle of the row-major H) is overwritten
 int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
-    {
-        // two-stage reduction (tbk_eig_band.hip) unless TBK_BAND=0 asks for the one-stage kernel below
-        static const bool band = [] {
-            const char* v = getenv("TBK_BAND");
-            return v == nullptr || atoi(v) != 0;
-        }();
-        if (band && tbk_eig_band_supported(n)) {
-            TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
-            return tbk_launch_tridiag_band(m, s, d_H, nk, d_de, m->ws_band.ptr);
-        }
+    if (tbk_eig_two_stage(m)) {  // both stages in order on this stream (single-chunk calls, tbk_tridiagonal_reduce)
+        TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
+        TBK_CHECK(m->ws_bandmat[0].reserve((size_t)nk * tbk_band_bytes_per_matrix(n)));
+        TBK_CHECK(tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, m->ws_bandmat[0].ptr));
+        return tbk_launch_band_chase(m, s, m->ws_bandmat[0].ptr, nk, d_de);
     }
     double* d_D = d_de;
     double* d_Eo = d_de + (size_t)nk * n;

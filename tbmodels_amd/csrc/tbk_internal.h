@@ -195,6 +195,7 @@ struct tbk_model {
     DevBuf ws_kfold;  // k-points of a folded run without the folded component
     DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
     DevBuf ws_band;   // two-stage reduction: pending [V | W] panel of every matrix of a chunk
+    DevBuf ws_bandmat[2];  // ... and the band matrices between its stages (one per chunk in flight)
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};
@@ -258,7 +259,10 @@ size_t tbk_eig_scratch_per_k(const tbk_model* m);
 // tbk_eig_band.hip: two-stage reduction (dense -> band on the matrix pipe, band -> tridiagonal in LDS)
 bool tbk_eig_band_supported(int n);
 size_t tbk_band_scratch_per_matrix(int n);
-int tbk_launch_tridiag_band(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, void* d_vw);
+size_t tbk_band_bytes_per_matrix(int n);
+bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this model (64 < n_orb <= 512, not TBK_BAND=0)
+int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band);
+int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de);
 
 // tbk_eig_small.hip
 bool tbk_eig_small_supported(int n);

@@ -22,11 +22,12 @@ int main(int argc, char** argv) {
     for (auto& x : h) x = rand() / (double)RAND_MAX - 0.5;
     for (int i = 0; i < n; ++i) h[((size_t)i * n + i) * 2 + 1] = 0.0;
     double *d_H0, *d_H, *d_de;
-    void* d_vw;
+    void *d_vw, *d_band;
     hipMalloc(&d_H0, (size_t)nk * n * n * 16);
     hipMalloc(&d_H, (size_t)nk * n * n * 16);
     hipMalloc(&d_de, (size_t)nk * n * 16);
     hipMalloc(&d_vw, (size_t)nk * tbk_band_scratch_per_matrix(n));
+    hipMalloc(&d_band, (size_t)nk * tbk_band_bytes_per_matrix(n));
     for (int k = 0; k < nk; ++k) hipMemcpy(d_H0 + (size_t)k * n * n * 2, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     tbk_model m;
     m.n_orb = n;
@@ -41,7 +42,8 @@ int main(int argc, char** argv) {
         hipEventCreate(&b);
         hipDeviceSynchronize();
         hipEventRecord(a, nullptr);
-        tbk_launch_tridiag_band(&m, nullptr, d_H, nk, d_de, d_vw);
+        tbk_launch_band_reduce(&m, nullptr, d_H, nk, d_vw, d_band);
+        tbk_launch_band_chase(&m, nullptr, d_band, nk, d_de);
         hipEventRecord(b, nullptr);
         hipDeviceSynchronize();
         float ms = 0;
@@ -58,10 +60,11 @@ int main(int argc, char** argv) {
         if (rep == 2) {
             const char* name[16] = {"0 look-ahead", "1 panel QR", "2 T factor", "3 hand-over", "4 big pass (rest)", "5 W", "6 loop top",
                                     "7 pass: request + wait", "8 pass: update + store", "9 pass: transposition",
-                                    "10 pass: products + X", "11 pass: barrier", "", "", "", ""};
+                                    "10 pass: products + X", "11 pass: barrier", "12 QR: products", "13 QR: wave sums", "14 QR: barrier",
+                                    "15 QR: reflector + update"};
             double total = 0;
-            for (int k = 0; k <= 11; ++k) total += (double)clk[k];
-            for (int k = 0; k <= 11; ++k)
+            for (int k = 0; k <= 15; ++k) total += (double)clk[k];
+            for (int k = 0; k <= 15; ++k)
                 if (name[k][0]) printf("   %-28s %12.0f cycles  %5.1f %%\n", name[k], (double)clk[k], 100.0 * clk[k] / total);
             printf("   total %.0f\n", total);
         }

@@ -308,3 +308,113 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 2 as the kernel schedules it: sweeps pipelined `stagger` ticks apart, the steps of one tick concurrent
+# ------------------------------------------------------------------------------------------------
+def stage2_pipelined(band, stagger, n_waves=10 ** 6):
+    """Runs the chase in lockstep ticks; the steps of a tick read the state the tick started from.  Asserts that no
+    step of a tick touches (reads or writes) a cell another step of the same tick writes."""
+    n = band.shape[0]
+    NPAD = n + 2 * B
+    L = np.zeros((NPAD, 2 * B), dtype=complex)
+    L[:n, :B + 1] = band.conj()
+
+    class View:  # cell access with read / write sets, on a snapshot
+        def __init__(self, snap):
+            self.snap, self.reads, self.writes = snap, set(), {}
+
+        def get(self, i, j):
+            if i >= n or j >= n:
+                return 0.0
+            self.reads.add((i, j))
+            return self.writes.get((i, j), self.snap[j, i - j])
+
+        def put(self, i, j, v):
+            if i < n and j < n:
+                self.writes[(i, j)] = v
+
+    def chase_tick(view, j, k, state):
+        """Tick k of sweep j (band_chase_kernel): returns the reflector for the next tick."""
+        if k == 0:
+            x = np.array([view.get(j + 1 + a, j) for a in range(B)])
+            beta, v, tau = larfg(x)
+            view.put(j + 1, j, beta)
+            for a in range(1, B):
+                view.put(j + 1 + a, j, 0.0)
+        else:
+            v, tau = state
+        r0 = j + 1 + B * k
+        q0 = r0 + B
+        D = np.zeros((B, B), dtype=complex)
+        for a in range(B):
+            for b_ in range(a + 1):
+                D[a, b_] = view.get(r0 + a, r0 + b_)
+                D[b_, a] = np.conj(D[a, b_])
+        for a in range(B):
+            D[a, a] = D[a, a].real
+        y = D @ v
+        rho = np.vdot(v, y).real
+        D = D - np.conj(tau) * np.outer(v, y.conj()) - tau * np.outer(y, v.conj()) + abs(tau) ** 2 * rho * np.outer(v, v.conj())
+        for a in range(B):
+            for b_ in range(a + 1):
+                view.put(r0 + a, r0 + b_, D[a, b_])
+        Bk = np.array([[view.get(q0 + a, r0 + b_) for b_ in range(B)] for a in range(B)])
+        Bk = Bk - tau * np.outer(Bk @ v, v.conj())
+        beta, v2, tau2 = larfg(Bk[:, 0].copy())
+        z = v2.conj() @ Bk
+        Bk = Bk - np.conj(tau2) * np.outer(v2, z)
+        Bk[0, 0] = beta
+        Bk[1:, 0] = 0.0
+        for a in range(B):
+            for b_ in range(B):
+                view.put(q0 + a, r0 + b_, Bk[a, b_])
+        return v2, tau2
+
+    n_sweeps = n - 2
+    length = [(n - 1 - j + B - 1) // B for j in range(n_sweeps)]
+    start = []
+    for s in range(n_sweeps):
+        t0 = 0 if s == 0 else start[s - 1] + stagger
+        if s >= n_waves:
+            t0 = max(t0, start[s - n_waves] + length[s - n_waves])
+        start.append(t0)
+    total = start[-1] + length[-1] if n_sweeps > 0 else 0
+    states = {}
+    for tick in range(total):
+        active = [s for s in range(n_sweeps) if start[s] <= tick < start[s] + length[s]]
+        snap = L.copy()
+        views = []
+        for s in active:
+            view = View(snap)
+            states[s] = chase_tick(view, s, tick - start[s], states.get(s))
+            views.append(view)
+        for i_, va in enumerate(views):
+            for j_, vb in enumerate(views):
+                if i_ != j_:
+                    clash = (va.reads | set(va.writes)) & set(vb.writes)
+                    assert not clash, "tick %d: sweeps %d and %d share cells %s" % (tick, active[i_], active[j_], sorted(clash)[:4])
+        for view in views:
+            for (i, j), val in view.writes.items():
+                L[j, i - j] = val
+    return L[:n, 0].real.copy(), np.abs(L[:n - 1, 1]), total
+
+
+def check_pipeline():
+    rng = np.random.default_rng(3)
+    for n in (40, 67, 100):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        H = (M + M.conj().T) / 2
+        band, _ = stage1_band(H)
+        ref = np.linalg.eigvalsh(H)
+        for stagger, waves in ((3, 10 ** 6), (2, 10 ** 6), (2, 4), (3, 2)):
+            d, e, ticks = stage2_pipelined(band, stagger, waves)
+            err = np.abs(tridiag_eigvals(d, e) - ref).max()
+            print("n=%3d stagger %d waves %7d: %4d ticks, eig err %.2e" % (n, stagger, waves, ticks, err))
+            assert err < 1e-12 * n
+        try:
+            stage2_pipelined(band, 1)
+            print("n=%3d stagger 1: no clash (unexpected)" % n)
+        except AssertionError as exc:
+            print("n=%3d stagger 1 clashes as expected: %s" % (n, str(exc)[:60]))
