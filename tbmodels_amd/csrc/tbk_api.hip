@@ -391,7 +391,10 @@ static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
     if (per_k < 64) per_k = 64;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
-    int64_t budget = std::min<int64_t>((int64_t)(free_b / 4), int64_t(6) << 30);
+    // above 64 orbitals a chunk is a few thousand matrices: every kernel of the eigensolver ends on a partly filled
+    // round of workgroups, and 2 - 3 times longer chunks were worth 3 - 4 % (cfg3 3846 -> 12500 matrices per chunk,
+    // cfg5 1250 -> 5000)
+    int64_t budget = std::min<int64_t>((int64_t)(free_b / 4), int64_t(n > 64 ? 24 : 6) << 30);
     int64_t chunk = budget / per_k / TBK_BM * TBK_BM;
     // 32768 k-points per chunk at 64 orbitals and above; small matrices take proportionally more (up to 1 M at 8
     // orbitals): a chunk is ~6 launches and one QL latency chain whatever its size, and 20 M k-points of an
