@@ -481,6 +481,90 @@ def test_eigensolver_structured_matrices(solver, n):
             assert err <= 1e-12 * scale * n, (name, "large batch", err)
 
 
+@pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512])
+def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
+    """``tbk_tridiagonal_reduce``: the reduction stage of the eigensolver alone (scipy's eigvalsh at _tb_model.py:1149 is
+    this plus the tridiagonal stage) on random Hermitian batches whose lower triangle is poisoned with NaN -- only the
+    upper triangle may be read.  Above 64 orbitals (two-stage reduction, csrc/tbk_eig_band.hip) the work copy must be
+    a band matrix of half-width 8 with the same spectrum, and equal the NumPy model of the algorithm
+    (tools/two_stage_model.py) entry by entry."""
+    import os
+    import sys
+
+    import scipy.linalg as la
+
+    from tbmodels_amd import _lib
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import two_stage_model as model
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(1000 + n)
+    nk = 9
+    m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = (m + m.conj().transpose(0, 2, 1)) / 2
+    h[1] *= 1e-30  # no absolute thresholds
+    h[2] *= 1e30
+    h[3] = np.diag(np.diagonal(h[3]))  # already reduced: zero reflectors throughout
+    poisoned = np.ascontiguousarray(h.copy())
+    il = np.tril_indices(n, -1)
+    poisoned[:, il[0], il[1]] = np.nan
+    d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(poisoned)
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
+    assert np.isfinite(d).all() and np.isfinite(e).all() and np.all(e[:, n - 1] == 0.0)
+    for i in range(nk):
+        ref = np.linalg.eigvalsh(h[i])
+        scale = np.abs(ref).max()
+        got = la.eigvalsh_tridiagonal(d[i], e[i, :-1]) if n > 1 else d[i]
+        assert np.abs(got - ref).max() <= 1e-13 * n * scale, i
+        if n > 64:
+            up = np.triu(red[i])
+            band = up - np.triu(up, model.B + 1)
+            hb = band + np.triu(band, 1).conj().T
+            assert np.abs(np.linalg.eigvalsh(hb) - ref).max() <= 1e-13 * n * scale, i
+    if 64 < n <= 130:
+        mband, _ = model.stage1_band(h[0])
+        gband = np.array([[red[0][r, r + dd] if r + dd < n else 0.0 for dd in range(model.B + 1)] for r in range(n)])
+        assert np.abs(gband - mband).max() < 1e-12 * n
+    # repeated calls give the same bits; bad sizes are refused before any device work
+    d2, e2 = np.empty_like(d), np.empty_like(e)
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), _lib.ptr(d2), _lib.ptr(e2), None))
+    assert np.array_equal(d, d2) and np.array_equal(e, e2)
+    assert lib.tbk_tridiagonal_reduce(0, 513, 1, _lib.ptr(poisoned), _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
+
+
+def test_two_stage_and_one_stage_reductions_agree():
+    """TBK_BAND=0 (read once per process) selects the one-stage streaming reduction of tbk_eig_stream.hip: same
+    eigenvalues to rounding as the default two-stage path, on a multi-chunk call."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r_vec, hop, pos = syn.dense_model_arrays(100, 6, syn.MODEL_SEED + 321)
+    k = syn.random_kpoints(2600, seed=5)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    from tbmodels_amd import _lib
+
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 1024)  # three chunks: the stages of neighbouring chunks overlap
+    here = model.eigenval_array(k)
+    _close(here[:40], np.array(oracle.eigenval(r_vec, hop, k[:40])))
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import tbmodels_amd; from tbmodels_amd import synthetic as syn, _lib\n"
+        "r, h, p = syn.dense_model_arrays(100, 6, syn.MODEL_SEED + 321)\n"
+        "m = tbmodels_amd.Model.from_packed(r, h, pos=p); m.set_option(_lib.TBK_OPT_K_CHUNK, 1024)\n"
+        "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(2600, seed=5)))\n" % root
+    )
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "e.npy")
+        env = dict(os.environ, TBK_BAND="0")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=300)
+        other = np.load(out)
+    assert 0.0 < np.abs(other - here).max() < 1e-11  # a different algorithm, the same spectrum
+
+
 def test_wave_solver_rejects_large_n():
     from tbmodels_amd import _lib
 
