@@ -517,19 +517,15 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const double scale = fmax(fabs(gl), fabs(gu));  // in [1, 2), or 0 for the zero matrix
     const double slack = 4.0 * 2.220446049250313e-16 * scale * n + 1e-300;
     double lo = gl - slack, hi = gu + slack;
-    const double tol = 2.0 * 2.220446049250313e-16 * scale + 1e-300;
-    // same trip count for every lane: cut the Gershgorin interval by LPE + 1 per sweep down to `tol`
-    int iters = 2;
-    for (double w = hi - lo; w > tol && iters < 1100; w *= 1.0 / (LPE + 1)) ++iters;
+    // Brackets are halved down to 2 ulp of the spectrum's scale up to 64 orbitals (the QL kernel of those sizes and this
+    // one must agree to 1e-13); above, down to n / 16 ulp -- the reduction in front of this kernel has rounded the
+    // matrix by more than that already, and the last four or five halvings of 57 bought nothing.
+    const double tol = (n > 64 ? 0.0625 * n : 2.0) * 2.220446049250313e-16 * scale + 1e-300;
 
-    const int m = tid / LPE;    // this lane's eigenvalue index
-    const int sub = tid % LPE;  // ... and which interior point of the bracket it tests
-    for (int it = 0; it < iters; ++it) {
-        const double width = hi - lo;
-        const double x = (LPE == 1) ? 0.5 * (lo + hi) : lo + width * ((sub + 1) * (1.0 / (LPE + 1)));
-        // Sturm count at x: sign changes along p_0 = 1, p_1, ..., p_n, a zero taking the sign opposite to its
-        // predecessor.  Signs are carried as integer bits (11 VALU issues per step; the bool / select form compiled
-        // to 37 and made the single-k eigenval call 0.34 ms at n = 64).
+    // Sturm count at x: sign changes along p_0 = 1, p_1, ..., p_n, a zero taking the sign opposite to its
+    // predecessor.  Signs are carried as integer bits (11 VALU issues per step; the bool / select form compiled
+    // to 37 and made the single-k eigenval call 0.34 ms at n = 64).
+    auto sturm_count = [&](double x) -> int {
         double pp = 1.0, p = sd[0] - x;
         int sgn = (p <= 0.0) ? 1 : 0;  // p_1 against p_0 = 1 > 0
         int cnt = sgn;
@@ -565,7 +561,44 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
             rescale();
         }
         for (; i0 < n; ++i0) step(sd[i0], se2[i0 - 1]);  // ragged tail (< 8 steps)
-        rescale();
+        return cnt;
+    };
+
+    const int m = tid / LPE;    // this lane's eigenvalue index
+    const int sub = tid % LPE;  // ... and which interior point of the bracket it tests
+    if (LPE == 1 && n > 64) {
+        // First round shared by the whole matrix: the n lanes count at n evenly spaced points of the Gershgorin
+        // interval, and every lane reads ITS bracket off the (monotone) counts -- log2(n + 1) halvings for one sweep.
+        int* scnt = reinterpret_cast<int*>(se2 + n_pad);
+        const double width = hi - lo;
+        const double step_w = width / (n + 1);
+        if (tid < n) scnt[tid] = sturm_count(lo + (tid + 1) * step_w);
+        __syncthreads();
+        // smallest point index t with count(x_t) > m: the m-th eigenvalue lies in (x_{t-1}, x_t]
+        int first = 0, len = n;  // binary search over t in [0, n): first t with scnt[t] > m, n if none
+        while (len > 0) {
+            const int half = len >> 1;
+            const int probe = min(first + half, n - 1);
+            const bool go_right = scnt[probe] <= m;
+            first = go_right ? probe + 1 : first;
+            len = go_right ? len - half - 1 : half;
+        }
+        const double new_lo = (first == 0) ? lo : lo + first * step_w;
+        const double new_hi = (first >= n) ? hi : lo + (first + 1) * step_w;
+        lo = new_lo;
+        hi = new_hi;
+    }
+    // same trip count for every lane: cut the bracket by LPE + 1 per sweep down to `tol`
+    int iters = 2;
+    {
+        const double w0 = (LPE == 1 && n > 64) ? (gu - gl + 2.0 * slack) / (n + 1) : hi - lo;
+        for (double w = w0; w > tol && iters < 1100; w *= 1.0 / (LPE + 1)) ++iters;
+    }
+
+    for (int it = 0; it < iters; ++it) {
+        const double width = hi - lo;
+        const double x = (LPE == 1) ? 0.5 * (lo + hi) : lo + width * ((sub + 1) * (1.0 / (LPE + 1)));
+        const int cnt = sturm_count(x);
         if (LPE == 1) {
             if (cnt > m)
                 hi = x;  // more than m eigenvalues below x: the m-th lies left of x
@@ -650,7 +683,7 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_QL, s);
     const int n_pad = (n + 63) / 64 * 64;
-    const size_t lds = 2 * (size_t)n_pad * sizeof(double);
+    const size_t lds = 2 * (size_t)n_pad * sizeof(double) + (size_t)n_pad * sizeof(int);  // (d, e^2) + the shared round's counts
     const double* d_e = d_de + (size_t)nk * n;
     // a few matrices cannot fill the chip with one lane per eigenvalue: spend lanes on shorter chains instead.  By the
     // size of the CALL, not of this chunk: TBK_OPT_K_CHUNK must not change results, and the variants differ in the

@@ -18,14 +18,26 @@ __global__ void __launch_bounds__(256) mfma_f64_loop(double* out, int iters, dou
     for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
     double a = seed == 0.0 ? 0.0 : seed + threadIdx.x * 1e-3;
     double b = seed == 0.0 ? 0.0 : seed - threadIdx.x * 1e-3;
-    // The accumulators are pinned to VGPRs by the constraint: written with the builtin, hipcc moved all 64
-    // accumulator registers between VGPRs and AGPRs on every trip (128 v_accvgpr moves per 8 MFMAs: the loop
-    // reported 47 TFLOP/s while the H(k) kernel sustained 68).
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
-    }
+    // The whole loop is ONE asm block with the eight accumulators in AGPRs: written with the builtin, hipcc moved all
+    // 64 accumulator registers between VGPRs and AGPRs on every trip (128 v_accvgpr moves per 8 MFMAs), and with the
+    // accumulators in VGPRs the loop reported 47 TFLOP/s while the H(k) kernel (AGPR accumulators) sustained 68.
+    asm volatile(
+        "s_mov_b32 s20, %10\n"
+        "1:\n"
+        "v_mfma_f64_16x16x4_f64 %0, %8, %9, %0\n"
+        "v_mfma_f64_16x16x4_f64 %1, %8, %9, %1\n"
+        "v_mfma_f64_16x16x4_f64 %2, %8, %9, %2\n"
+        "v_mfma_f64_16x16x4_f64 %3, %8, %9, %3\n"
+        "v_mfma_f64_16x16x4_f64 %4, %8, %9, %4\n"
+        "v_mfma_f64_16x16x4_f64 %5, %8, %9, %5\n"
+        "v_mfma_f64_16x16x4_f64 %6, %8, %9, %6\n"
+        "v_mfma_f64_16x16x4_f64 %7, %8, %9, %7\n"
+        "s_sub_u32 s20, s20, 1\n"
+        "s_cmp_lg_u32 s20, 0\n"
+        "s_cbranch_scc1 1b\n"
+        : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7])
+        : "v"(a), "v"(b), "s"(iters)
+        : "s20", "scc");
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];

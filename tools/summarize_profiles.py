@@ -96,7 +96,7 @@ def main():
             handle.write("\n".join(lines) + "\n")
         if cfg == "cfg2":
             if "hk_dense" in traffic:
-                traffic["hk_dense"]["kpoints_per_launch"] = 25000  # 100 000 k-points in 4 launches
+                traffic["hk_dense"]["kpoints_per_launch"] = 32768  # the averaged launches are the full 32768-k chunks
             with open(os.path.join(out_dir, "%s_traffic.json" % tag), "w") as handle:
                 json.dump(traffic, handle, indent=1, sort_keys=True)
         print("\n".join(lines))
