@@ -125,10 +125,14 @@ int tbk_synchronize(tbk_model* m);
 /* ---- the eigensolver's reduction stage alone (scipy.linalg.eigvalsh of _tb_model.py:1149 = this + the tridiagonal stage)
  * nk Hermitian matrices H[nk][n_orb][n_orb][2] (row-major; only the upper triangle i <= j is read) are reduced to real
  * symmetric tridiagonal form with the same eigenvalues: d[nk][n_orb] diagonals, e[nk][n_orb] off-diagonals (e[.][n-1] = 0).
- * n_orb <= 512.  H_reduced (may be NULL) receives the work copy of the matrices as the reduction left it: for
- * 64 < n_orb <= 512 (two-stage reduction) its upper triangle holds the band form of half-width 8 after stage one.
+ * n_orb <= 512.  method: TBK_REDUCE_AUTO = what tbk_eigenval takes for this size (register-resident reduction up to 64
+ * orbitals, one-stage streaming reduction up to 128, two-stage reduction -- dense -> band of half-width 8 on the matrix
+ * pipe, band -> tridiagonal by bulge chasing -- from 129 to 512); _ONE_STAGE / _TWO_STAGE force one of them (two-stage:
+ * 64 < n_orb <= 512 only).  H_reduced (may be NULL) receives the work copy of the matrices as the reduction left it:
+ * after the two-stage reduction its upper triangle holds the band form of stage one.
  * Host buffers; synchronous.  For tests and for callers that bring their own matrices. */
-int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, double* d, double* e,
+enum { TBK_REDUCE_AUTO = 0, TBK_REDUCE_ONE_STAGE = 1, TBK_REDUCE_TWO_STAGE = 2 };
+int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, int method, double* d, double* e,
                            double* H_reduced);
 
 /* ---- k.p models (kdotp.py:51-100): H(k) = sum_p prod_d k_d^powers[p][d] * coeffs[p] ------- */

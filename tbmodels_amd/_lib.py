@@ -24,6 +24,7 @@ TBK_ERR_NO_CONVERGENCE = 5
 
 TBK_EIG_AUTO, TBK_EIG_WAVE, TBK_EIG_ROCSOLVER = 0, 1, 2
 TBK_OPT_EIGENSOLVER, TBK_OPT_K_CHUNK, TBK_OPT_TIMING, TBK_OPT_FOLD = 1, 2, 3, 4
+TBK_REDUCE_AUTO, TBK_REDUCE_ONE_STAGE, TBK_REDUCE_TWO_STAGE = 0, 1, 2
 TBK_CNT_EIGENVAL_CALLS, TBK_CNT_FOLDED_CALLS, TBK_CNT_FOLDED_KPOINTS = 0, 1, 2
 TBK_T_PHASE, TBK_T_HK, TBK_T_EIG, TBK_T_QL, TBK_T_COUNT = 0, 1, 2, 3, 4
 STAGE_NAMES = ("phase", "hk", "eig", "ql")
@@ -55,7 +56,7 @@ SIGNATURES = {
     "tbk_model_counter": (_c_int, [_vp, _c_int, ctypes.POINTER(_c_i64)]),
     "tbk_eigenval_check": (_c_int, [_vp]),
     "tbk_synchronize": (_c_int, [_vp]),
-    "tbk_tridiagonal_reduce": (_c_int, [_c_int, _c_int, _c_i64, _vp, _vp, _vp, _vp]),
+    "tbk_tridiagonal_reduce": (_c_int, [_c_int, _c_int, _c_i64, _vp, _c_int, _vp, _vp, _vp]),
     "tbk_kdotp_create": (_c_int, [_c_int, _c_int, _c_int, _c_i64, _vp, _vp, _pp]),
     "tbk_kdotp_destroy": (None, [_vp]),
     "tbk_kdotp_hamilton": (_c_int, [_vp, _vp, _c_i64, _vp]),

@@ -911,10 +911,12 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
 // ------------------------------------------------------------------------------------------------
 // the reduction stage alone, on caller-supplied matrices
 // ------------------------------------------------------------------------------------------------
-extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, double* d, double* e,
+extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, int method, double* d, double* e,
                                       double* H_reduced) {
     TBK_ARG(nk >= 0, "nk < 0");
     TBK_ARG(n_orb >= 1 && n_orb <= 512, "n_orb must be in [1, 512] (larger matrices go through rocSOLVER as a whole)");
+    TBK_ARG(method >= TBK_REDUCE_AUTO && method <= TBK_REDUCE_TWO_STAGE, "unknown reduction method");
+    TBK_ARG(method != TBK_REDUCE_TWO_STAGE || tbk_eig_band_supported(n_orb), "the two-stage reduction handles 64 < n_orb <= 512");
     if (nk == 0) return TBK_OK;
     TBK_ARG(H && d && e, "H / d / e is NULL");
     tbk_model* m = nullptr;
@@ -929,7 +931,7 @@ extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const d
         if (tbk_eig_small_supported(n_orb))
             TBK_CHECK(tbk_launch_tridiag(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>()));
         else
-            TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>()));
+            TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>(), method));
         TBK_HIP(hipMemcpyAsync(d, m->ws_E.ptr, (size_t)nk * n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
         TBK_HIP(hipMemcpyAsync(e, m->ws_E.as<double>() + (size_t)nk * n, (size_t)nk * n * sizeof(double), hipMemcpyDeviceToHost,
                                m->stream));

@@ -926,7 +926,14 @@ static int chase_pitch(int n) {
     return np;
 }
 
+// The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 129 orbitals on: up to 128 the one-stage kernel of
+// tbk_eig_stream.hip (four waves per matrix, rows of two 64-column chunks) is faster -- 0.65 vs 0.84 us per matrix at 65
+// orbitals, 1.73 vs 2.14 at 128; from 129 on the one-stage rows grow a third chunk and the order flips (3.8 vs 3.3 us at 160).
 bool tbk_eig_band_supported(int n) { return n > 64 && n <= 512; }
+bool tbk_eig_band_preferred(int n) {
+    static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 129;  // measurements only
+    return n >= from && n <= 512;
+}
 
 size_t tbk_band_bytes_per_matrix(int n) { return (size_t)n * (PB + 1) * sizeof(d2); }
 

@@ -645,14 +645,14 @@ bool tbk_eig_two_stage(const tbk_model* m) {
         const char* v = getenv("TBK_BAND");
         return v == nullptr || atoi(v) != 0;
     }();
-    return band && tbk_eig_band_supported(m->n_orb);
+    return band && tbk_eig_band_preferred(m->n_orb);
 }
 
 // d_de: d[nk][n] followed by e[nk][n]; d_H (upper triangle of the row-major H) is overwritten
-int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de) {
+int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, int method) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
-    if (tbk_eig_two_stage(m)) {  // both stages in order on this stream (single-chunk calls, tbk_tridiagonal_reduce)
+    if (method == TBK_REDUCE_TWO_STAGE || (method == TBK_REDUCE_AUTO && tbk_eig_two_stage(m))) {  // both stages in order on this stream (single-chunk calls, tbk_tridiagonal_reduce)
         TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
         TBK_CHECK(m->ws_bandmat[0].reserve((size_t)nk * tbk_band_bytes_per_matrix(n)));
         TBK_CHECK(tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, m->ws_bandmat[0].ptr));

@@ -250,7 +250,8 @@ int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);    // f
 
 // tbk_eig_stream.hip
 bool tbk_eig_stream_supported(int n);
-int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
+// method: TBK_REDUCE_AUTO (what eigenval takes), _ONE_STAGE, _TWO_STAGE (tbk.h)
+int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, int method = 0);
 bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk);  // tbk_hk_dense.hip
 bool tbk_hk_gemv_path(const tbk_model* m, int64_t nk);
 int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E);
@@ -258,6 +259,7 @@ size_t tbk_eig_scratch_per_k(const tbk_model* m);
 
 // tbk_eig_band.hip: two-stage reduction (dense -> band on the matrix pipe, band -> tridiagonal in LDS)
 bool tbk_eig_band_supported(int n);
+bool tbk_eig_band_preferred(int n);
 size_t tbk_band_scratch_per_matrix(int n);
 size_t tbk_band_bytes_per_matrix(int n);
 bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this model (64 < n_orb <= 512, not TBK_BAND=0)

@@ -510,7 +510,10 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     il = np.tril_indices(n, -1)
     poisoned[:, il[0], il[1]] = np.nan
     d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(poisoned)
-    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
+    # the two-stage kernels at every size they handle (eigenval itself takes them from 129 orbitals on); the
+    # production choice and the forced one-stage path are compared below
+    method = _lib.TBK_REDUCE_TWO_STAGE if n > 64 else _lib.TBK_REDUCE_AUTO
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), method, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
     assert np.isfinite(d).all() and np.isfinite(e).all() and np.all(e[:, n - 1] == 0.0)
     for i in range(nk):
         ref = np.linalg.eigvalsh(h[i])
@@ -528,9 +531,18 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
         assert np.abs(gband - mband).max() < 1e-12 * n
     # repeated calls give the same bits; bad sizes are refused before any device work
     d2, e2 = np.empty_like(d), np.empty_like(e)
-    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), _lib.ptr(d2), _lib.ptr(e2), None))
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), method, _lib.ptr(d2), _lib.ptr(e2), None))
     assert np.array_equal(d, d2) and np.array_equal(e, e2)
-    assert lib.tbk_tridiagonal_reduce(0, 513, 1, _lib.ptr(poisoned), _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
+    for other in (_lib.TBK_REDUCE_AUTO, _lib.TBK_REDUCE_ONE_STAGE):  # every path: the same spectrum
+        _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), other, _lib.ptr(d2), _lib.ptr(e2), None))
+        for i in range(nk):
+            ref = np.linalg.eigvalsh(h[i])
+            got = la.eigvalsh_tridiagonal(d2[i], e2[i, :-1]) if n > 1 else d2[i]
+            assert np.abs(got - ref).max() <= 1e-13 * n * np.abs(ref).max(), (other, i)
+    bad = lib.tbk_tridiagonal_reduce(0, 513, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
+    assert bad == _lib.TBK_ERR_ARGUMENT
+    if n <= 64:
+        assert lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(poisoned), 2, _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
 
 
 def test_two_stage_and_one_stage_reductions_agree():
@@ -542,7 +554,7 @@ def test_two_stage_and_one_stage_reductions_agree():
     import tempfile
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r_vec, hop, pos = syn.dense_model_arrays(100, 6, syn.MODEL_SEED + 321)
+    r_vec, hop, pos = syn.dense_model_arrays(150, 6, syn.MODEL_SEED + 321)
     k = syn.random_kpoints(2600, seed=5)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     from tbmodels_amd import _lib
@@ -553,7 +565,7 @@ def test_two_stage_and_one_stage_reductions_agree():
     script = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "import tbmodels_amd; from tbmodels_amd import synthetic as syn, _lib\n"
-        "r, h, p = syn.dense_model_arrays(100, 6, syn.MODEL_SEED + 321)\n"
+        "r, h, p = syn.dense_model_arrays(150, 6, syn.MODEL_SEED + 321)\n"
         "m = tbmodels_amd.Model.from_packed(r, h, pos=p); m.set_option(_lib.TBK_OPT_K_CHUNK, 1024)\n"
         "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(2600, seed=5)))\n" % root
     )

@@ -30,7 +30,8 @@ def reduce_gpu(h, want_reduced=True):
     e = np.empty((nk, n))
     red = np.empty_like(h) if want_reduced else None
     t0 = time.perf_counter()
-    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(h), _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
+    method = _lib.TBK_REDUCE_TWO_STAGE if (n > 64 and os.environ.get("TBK_BAND", "1") != "0") else _lib.TBK_REDUCE_ONE_STAGE
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(h), method, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
     return d, e, red, time.perf_counter() - t0
 
 
