@@ -913,6 +913,231 @@ band_chase_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, d
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage 2, packed: FOUR sweeps per wave.  A chase step works on 8 x 8 blocks; with a whole wave per step most of the
+// ~350 instructions are cross-lane reductions and scalar work replicated 64 times.  Here a sweep gets 16 lanes -- lane
+// (a = l & 7, h = (l >> 3) & 1) holds row a, columns 4 h .. 4 h + 3 of a block -- so row sums are four local terms plus
+// one exchange, the vectors that are needed by column (y, x) cross over through a wave-private LDS scratch, and every
+// instruction advances four sweeps at once (~115 instructions per chase step).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sum_a8(double v) { return sum_a(v); }  // over the 8 lanes that share (slot, h)
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+band_chase4_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
+    constexpr int NSLOT = 4 * NW;
+    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
+    d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
+    d2* sScr = sL + (size_t)16 * np;                                // [NW][4 slots][16]: y (8) and x (8) by row
+    int* sStart = reinterpret_cast<int*>(sScr + NW * 64);           // [n] first tick of every sweep
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 7, h = (lane >> 3) & 1, g = lane >> 4;
+    const size_t mat = blockIdx.x;
+    const d2* band = band_all + mat * (size_t)n * (PB + 1);
+    d2* scr = sScr + (wave * 4 + g) * 16;
+
+    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
+    __syncthreads();
+    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
+        const int j = i / (PB + 1), dd = i % (PB + 1);
+        if (j + dd < n) {
+            const d2 v = band[i];
+            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
+        }
+    }
+    const int n_sweeps = n - 2;
+    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };
+    if (tid == 0) {
+        for (int s = 0; s < n_sweeps; ++s) {
+            int t0 = 0;
+            if (s > 0) t0 = sStart[s - 1] + stagger;
+            if (s >= NSLOT) t0 = max(t0, sStart[s - NSLOT] + sweep_len(s - NSLOT));
+            sStart[s] = t0;
+        }
+    }
+    wg_sync();
+    if (n_sweeps > 0) {
+        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
+        // element (i, j) of the band lives at (i - j) np + j: per lane and column c the part that does not depend on
+        // the block position r0
+        int dstat[4], bstat[4];
+        bool d_conj[4], d_diag[4], d_low[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int b = 4 * h + c;
+            dstat[c] = abs(a - b) * np + min(a, b);
+            bstat[c] = (PB + a - b) * np + b;
+            d_conj[c] = a < b;
+            d_diag[c] = a == b;
+            d_low[c] = a >= b;
+        }
+        const int xstat = (PB + a) * np;  // first column of the block below, row a
+        int sw = wave * 4 + g;  // this slot's current / next sweep
+        int k = -1, k_len = 0;
+        d2 va = (d2){0.0, 0.0}, tau = va;
+        d2 vb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vb[c] = va;
+
+        // zlarfg from x_a (own row), x_b (the four rows named by this lane's columns) and alpha = x[0]
+        auto reflector = [&](d2 xa, const d2 (&xb)[4], d2 alpha, d2& o_va, d2 (&o_vb)[4], d2& o_tau, double& o_beta) {
+            const double sigma = sum_a8(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
+            o_tau = (d2){0.0, 0.0};
+            o_beta = alpha[0];
+            o_va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o_vb[c] = (4 * h + c == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+            const bool trivial = (sigma == 0.0 && alpha[1] == 0.0);  // uniform over the slot
+            const double norm2 = trivial ? 1.0 : alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma;
+            double root, rroot;
+            fast_sqrt_rsqrt(norm2, root, rroot);
+            const double beta = -copysign(root, alpha[0]);
+            const double rbeta = -copysign(rroot, alpha[0]);
+            const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+            const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+            const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+            if (!trivial) {
+                o_tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                o_beta = beta;
+                if (a != 0) o_va = cmul(xa, scale);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * h + c != 0) o_vb[c] = cmul(xb[c], scale);
+            }
+        };
+
+        for (int tick = 0; tick < total_ticks; ++tick) {
+            const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
+            if (__any(starting)) {
+                // first reflector of a sweep: column sw below the diagonal (slots that do not start read a valid column
+                // and drop the result)
+                const int j = starting ? sw : 0;
+                const d2 xa = sL[(size_t)(1 + a) * np + j];
+                d2 xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[c] = sL[(size_t)(1 + 4 * h + c) * np + j];
+                const d2 alpha = sL[(size_t)np + j];
+                d2 n_va, n_vb[4], n_tau;
+                double beta;
+                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
+                lds_fence();
+                if (starting) {
+                    va = n_va;
+                    tau = n_tau;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                    k = 0;
+                    k_len = sweep_len(sw);
+                    if (h == 0 && j + 1 + a < n) sL[(size_t)(1 + a) * np + j] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                }
+            }
+            const bool active = k >= 0;
+            if (__any(active)) {
+                const int r0 = active ? sw + 1 + PB * k : 0;
+                // all loads of the tick first
+                d2 dv[4], bk[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dv[c] = sL[dstat[c] + r0];
+                    bk[c] = sL[bstat[c] + r0];
+                }
+                const d2 bk0a = sL[xstat + r0];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (d_conj[c]) dv[c][1] = -dv[c][1];
+                    if (d_diag[c]) dv[c][1] = 0.0;
+                }
+                // row sums: y = D v and u = Bk v (four local terms, then the other half of the row)
+                d2 ya = (d2){0.0, 0.0}, ua = ya;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    cfma(ya, dv[c], vb[c]);
+                    cfma(ua, bk[c], vb[c]);
+                }
+                ya[0] += dpp_mov<0x128>(ya[0]);
+                ya[1] += dpp_mov<0x128>(ya[1]);
+                ua[0] += dpp_mov<0x128>(ua[0]);
+                ua[1] += dpp_mov<0x128>(ua[1]);
+                const d2 tu = cmul(tau, ua);
+                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};  // first column of Bk' (v[0] = 1 when tau != 0)
+                // y and x are needed by column too: through the slot's scratch (one wave: its LDS traffic is ordered)
+                asm volatile("" ::: "memory");
+                if (h == 0) {
+                    scr[a] = ya;
+                    scr[8 + a] = xa;
+                }
+                asm volatile("" ::: "memory");
+                d2 yb[4], xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    yb[c] = scr[4 * h + c];
+                    xb[c] = scr[8 + 4 * h + c];
+                }
+                const d2 alpha = scr[8];
+                asm volatile("" ::: "memory");
+                const double rho = sum_a8(va[0] * ya[0] + va[1] * ya[1]);
+                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
+                {
+                    const d2 ctau = conjd(tau);
+                    const d2 cva = cmul(ctau, va);   // conj(tau) v_a
+                    const d2 tya = cmul(tau, ya);    // tau y_a
+                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+                    const d2 fva = (d2){f * va[0], f * va[1]};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        d2 dn = dv[c];
+                        cfnmac(dn, cva, yb[c]);
+                        cfnmac(dn, tya, vb[c]);
+                        cfmac(dn, fva, vb[c]);
+                        if (active && d_low[c] && r0 + a < n) sL[dstat[c] + r0] = dn;
+                    }
+                }
+                // Bk' = Bk - tau u conj(v_b); next reflector from its first column; Bk'' = Bk' - conj(tau2) v2_a z_b
+                d2 bn[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bn[c] = bk[c];
+                    cfnmac(bn[c], tu, vb[c]);
+                }
+                d2 n_va, n_vb[4], n_tau;
+                double beta;
+                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
+                const d2 ctau2 = conjd(n_tau);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const d2 zc = sum_a2(cmulc(bn[c], n_va));  // conj(v2_a) Bk'[a][b] summed over the rows
+                    const d2 f2 = cmul(ctau2, zc);
+                    cfma(bn[c], (d2){-n_va[0], -n_va[1]}, f2);
+                    if (4 * h + c == 0) bn[c] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                    if (active && r0 + PB + a < n && r0 + 4 * h + c < n) sL[bstat[c] + r0] = bn[c];
+                }
+                if (active) {
+                    va = n_va;
+                    tau = n_tau;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                    if (++k == k_len) {
+                        k = -1;
+                        sw += NSLOT;
+                    }
+                }
+            }
+            wg_sync();
+        }
+    }
+    for (int j = tid; j < n; j += NW * 64) {
+        D[mat * n + j] = sL[j][0];
+        double e = 0.0;
+        if (j + 1 < n) {
+            const d2 v = sL[(size_t)np + j];
+            e = sqrt(v[0] * v[0] + v[1] * v[1]);
+        }
+        E[mat * n + j] = e;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -977,6 +1202,27 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
         static const int env_nw = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
         static const int env_stagger = getenv("TBK_CHASE_STAGGER") ? atoi(getenv("TBK_CHASE_STAGGER")) : 0;
         const int stagger = env_stagger >= 2 ? env_stagger : 2;
+        static const bool packed = getenv("TBK_CHASE_PACK") == nullptr || atoi(getenv("TBK_CHASE_PACK")) != 0;
+        if (packed) {
+            // four sweeps per wave: a sweep is ~n / 8 steps long and sweeps start two ticks apart
+            const int nw4 = env_nw ? env_nw : (n <= 128 ? 2 : n <= 256 ? 4 : 8);
+            const size_t lds4 = (size_t)16 * np * 16 + (size_t)nw4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
+            static bool raised4[3][TBK_MAX_DEVICES] = {};
+#define TBK_CHASE4(NWV, SLOT)                                                                                             \
+    do {                                                                                                                  \
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4_kernel<NWV>), (int)lds4, raised4[SLOT]));   \
+        hipLaunchKernelGGL(band_chase4_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds4, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
+    } while (0)
+            if (nw4 <= 2)
+                TBK_CHASE4(2, 0);
+            else if (nw4 <= 4)
+                TBK_CHASE4(4, 1);
+            else
+                TBK_CHASE4(8, 2);
+#undef TBK_CHASE4
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
         int nw = env_nw ? env_nw : (n <= 128 ? 4 : n <= 256 ? 8 : 16);
         static bool raised[3][TBK_MAX_DEVICES] = {};
 #define TBK_CHASE(NWV, SLOT)                                                                                              \
