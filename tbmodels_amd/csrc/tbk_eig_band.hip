@@ -42,6 +42,12 @@ __device__ unsigned long long tbk_band_clock[32];
 #define TBK_CLK(k)
 #endif
 
+// Non-temporal tile loads / stores (so that the streaming tiles do not push the re-read [V | W] blocks out of L2) were
+// measured: 4.51 -> 4.78 us per matrix at 256 orbitals, 31.5 -> 31.0 at 512 -- nothing either way; off.
+#ifndef TBK_TILE_NT
+#define TBK_TILE_NT 0
+#endif
+
 constexpr int PB = 8;    // panel height = band half-width
 constexpr int TS = 16;   // MFMA tile edge
 
@@ -256,7 +262,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gr = o.Ir * TS + lq + 4 * r;
-                const d2 v2 = *Hat(min(gr, n - 1), min(gc, n - 1));
+                // (tiles stream through once per pass: non-temporal, so that they do not push the [V | W] blocks, which every
+                // visit re-reads, out of L2)
+                const d2 v2 = TBK_TILE_NT ? __builtin_nontemporal_load(Hat(min(gr, n - 1), min(gc, n - 1)))
+                                          : *Hat(min(gr, n - 1), min(gc, n - 1));
                 o.tre[r] = v2[0];
                 o.tim[r] = v2[1];
             }
@@ -311,7 +320,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gr = Ir * TS + lq + 4 * r;
-                        if (gr < n && gc < n) *Hat(gr, gc) = (d2){tre[r], tim[r]};
+                        if (gr < n && gc < n) {
+                            if (TBK_TILE_NT)
+                                __builtin_nontemporal_store((d2){tre[r], tim[r]}, Hat(gr, gc));
+                            else
+                                *Hat(gr, gc) = (d2){tre[r], tim[r]};
+                        }
                     }
                 }
                 TBK_CLK(8);
@@ -1169,7 +1183,8 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_EIG, s);
     const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
-    const bool small = n <= 256;
+    static const int big_from = getenv("TBK_BAND_NT512_FROM") ? atoi(getenv("TBK_BAND_NT512_FROM")) : 257;  // measurements only
+    const bool small = n <= 256 && n < big_from;
     const int nw = small ? 4 : 8;
     const size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
     static bool raised_a[TBK_MAX_DEVICES] = {}, raised_b[TBK_MAX_DEVICES] = {};
