@@ -546,7 +546,9 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
     double* d_H = m->ws_H.as<double>();
-    const bool two_stage = !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m) && n_chunks > 1;
+    // two-stage reduction in two launches (TBK_BAND_FUSE=0): stage two of a chunk goes to the tridiagonal stream; fused
+    // (default) it is part of the reduction kernel and this flag stays off
+    const bool two_stage = !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m) && n_chunks > 1 && !tbk_band_fused(m->n_orb);
     if (two_stage) {
         TBK_CHECK(m->ws_band.reserve((size_t)max_chunk * tbk_band_scratch_per_matrix(m->n_orb)));
         for (int b = 0; b < 2; ++b) TBK_CHECK(m->ws_bandmat[b].reserve((size_t)max_chunk * tbk_band_bytes_per_matrix(m->n_orb)));

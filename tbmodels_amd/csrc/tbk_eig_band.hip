@@ -163,6 +163,436 @@ __device__ __forceinline__ void wg_finish(int nv, double* s_part, double* s_tot,
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage 2
+// ------------------------------------------------------------------------------------------------
+// The band as LOWER diagonals in LDS: element (i, j), 0 <= i - j < 16, at sL[(i - j) * NP + j]; NP % 16 == 9 makes the
+// 8 x 8 block accesses of a wave (lane = row a + 8 column b) conflict-free for ds_read_b128.
+template <int CTRL>
+__device__ __forceinline__ d2 dpp_mov2(d2 v) { return (d2){dpp_mov<CTRL>(v[0]), dpp_mov<CTRL>(v[1])}; }
+
+// sum over the row index a = lane & 7 (lanes that share b): every lane ends with the total
+__device__ __forceinline__ double sum_a(double v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
+    return v;
+}
+// sum over the column index b = lane >> 3 (lanes that share a)
+__device__ __forceinline__ double sum_b(double v) {
+    v += dpp_mov<0x128>(v);  // row_ror 8: b ^ 1
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ d2 sum_a2(d2 v) { return (d2){sum_a(v[0]), sum_a(v[1])}; }
+__device__ __forceinline__ d2 sum_b2(d2 v) { return (d2){sum_b(v[0]), sum_b(v[1])}; }
+
+__device__ __forceinline__ double shfl_d(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
+    return __hiloint2double(hi, lo);
+}
+
+// zlarfg on a vector every lane knows through (x_a, x_b): returns beta, tau and this lane's v_a, v_b
+struct Reflector {
+    d2 va, vb, tau;
+    double beta;
+};
+__device__ __forceinline__ Reflector make_reflector(d2 xa, d2 xb, int a, int b) {
+    Reflector h;
+    const double sigma = sum_a(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
+    // alpha = x[0]: lane 0 holds it as xa
+    d2 alpha;
+    alpha[0] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[0])), __builtin_amdgcn_readfirstlane(__double2loint(xa[0])));
+    alpha[1] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[1])), __builtin_amdgcn_readfirstlane(__double2loint(xa[1])));
+    h.tau = (d2){0.0, 0.0};
+    h.beta = alpha[0];
+    h.va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+    h.vb = (b == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+    if (!(sigma == 0.0 && alpha[1] == 0.0)) {
+        double root, rroot;
+        fast_sqrt_rsqrt(alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma, root, rroot);
+        const double beta = -copysign(root, alpha[0]);
+        const double rbeta = -copysign(rroot, alpha[0]);
+        h.tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+        const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+        const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+        const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+        if (a != 0) h.va = cmul(xa, scale);
+        if (b != 0) h.vb = cmul(xb, scale);
+        h.beta = beta;
+    }
+    return h;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+band_chase_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
+    d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
+    int* sStart = reinterpret_cast<int*>(sL + (size_t)16 * np);     // [n] first tick of every sweep
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 7, b = lane >> 3;
+    const size_t mat = blockIdx.x;
+    const d2* band = band_all + mat * (size_t)n * (PB + 1);
+
+    auto L = [&](int i, int j) -> d2& { return sL[(size_t)(i - j) * np + j]; };
+
+    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
+    __syncthreads();
+    // lower band element (j + dd, j) = conj(H[j][j + dd])
+    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
+        const int j = i / (PB + 1), dd = i % (PB + 1);
+        if (j + dd < n) {
+            const d2 v = band[i];
+            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
+        }
+    }
+    const int n_sweeps = n - 2;
+    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };  // ticks of sweep j
+    if (tid == 0) {
+        for (int s = 0; s < n_sweeps; ++s) {
+            int t0 = 0;
+            if (s > 0) t0 = sStart[s - 1] + stagger;
+            if (s >= NW) t0 = max(t0, sStart[s - NW] + sweep_len(s - NW));
+            sStart[s] = t0;
+        }
+    }
+    wg_sync();
+    if (n_sweeps > 0) {
+        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
+        int sw = wave;  // this wave's current / next sweep
+        int k = -1;     // tick inside the sweep, -1 = waiting
+        int k_len = 0;
+        d2 va = (d2){0.0, 0.0}, vb = va, tau = va;
+        for (int tick = 0; tick < total_ticks; ++tick) {
+            if (k < 0 && sw < n_sweeps && tick == sStart[sw]) {
+                k = 0;
+                k_len = sweep_len(sw);
+                // first reflector of the sweep: column sw below the diagonal
+                const int j = sw;
+                const d2 xa = L(j + 1 + a, j), xb = L(j + 1 + b, j);
+                const Reflector h = make_reflector(xa, xb, a, b);
+                va = h.va;
+                vb = h.vb;
+                tau = h.tau;
+                lds_fence();
+                if (b == 0 && j + 1 + a < n) L(j + 1 + a, j) = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
+            }
+            if (k >= 0) {
+                const int r0 = sw + 1 + PB * k;
+                const int q0 = r0 + PB;
+                // all loads of the tick first
+                const int di = r0 + max(a, b), dj = r0 + min(a, b);
+                d2 dv = L(di, dj);
+                const d2 bk = L(q0 + a, r0 + b);
+                const d2 bk0a = L(q0 + a, r0), bk0b = L(q0 + b, r0);
+                if (a < b) dv = conjd(dv);
+                if (a == b) dv[1] = 0.0;
+                // y = D v (by rows and by columns), rho = v^H y
+                const d2 ya = sum_b2(cmul(dv, vb));
+                const d2 yb = sum_a2(cmulc(va, dv));  // conj(D[a][b]) v[a] summed over a = y[b]
+                const double rho = sum_a(va[0] * ya[0] + va[1] * ya[1]);
+                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
+                const d2 ctau = conjd(tau);
+                d2 dn = dv;
+                {
+                    const d2 t1 = cmul(ctau, cmulc(va, yb));
+                    const d2 t2 = cmul(tau, cmulc(ya, vb));
+                    const d2 t3 = cmulc(va, vb);
+                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+                    dn[0] += -t1[0] - t2[0] + f * t3[0];
+                    dn[1] += -t1[1] - t2[1] + f * t3[1];
+                }
+                if (a >= b && di < n) L(di, dj) = dn;
+                // block below: Bk' = Bk - tau u conj(v_b), u = Bk v
+                const d2 ua = sum_b2(cmul(bk, vb));
+                const d2 tu = cmul(tau, ua);
+                d2 bn = bk;
+                cfnmac(bn, tu, vb);
+                // its first column is the next reflector's vector: x[a] = Bk[a][0] - tau u[a] (v[0] = 1 when tau != 0)
+                d2 ub;
+                ub[0] = shfl_d(ua[0], b);
+                ub[1] = shfl_d(ua[1], b);
+                const d2 tub = cmul(tau, ub);
+                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};
+                const d2 xb = (d2){bk0b[0] - tub[0], bk0b[1] - tub[1]};
+                const Reflector h = make_reflector(xa, xb, a, b);
+                // left-apply to the remaining columns: Bk'' = Bk' - conj(tau2) v2_a z_b, z = v2^H Bk'
+                const d2 zb = sum_a2(cmulc(bn, h.va));  // conj(v2_a) Bk'[a][b] summed over a
+                const d2 f2 = cmul(conjd(h.tau), zb);
+                cfma(bn, (d2){-h.va[0], -h.va[1]}, f2);
+                if (b == 0) bn = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
+                if (q0 + a < n && r0 + b < n) L(q0 + a, r0 + b) = bn;
+                va = h.va;
+                vb = h.vb;
+                tau = h.tau;
+                if (++k == k_len) {
+                    k = -1;
+                    sw += NW;
+                }
+            }
+            wg_sync();
+        }
+    }
+    for (int j = tid; j < n; j += NW * 64) {
+        D[mat * n + j] = L(j, j)[0];
+        double e = 0.0;
+        if (j + 1 < n) {
+            const d2 v = L(j + 1, j);
+            e = sqrt(v[0] * v[0] + v[1] * v[1]);
+        }
+        E[mat * n + j] = e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2, packed: FOUR sweeps per wave.  A chase step works on 8 x 8 blocks; with a whole wave per step most of the
+// ~350 instructions are cross-lane reductions and scalar work replicated 64 times.  Here a sweep gets 16 lanes -- lane
+// (a = l & 7, h = (l >> 3) & 1) holds row a, columns 4 h .. 4 h + 3 of a block -- so row sums are four local terms plus
+// one exchange, the vectors that are needed by column (y, x) cross over through a wave-private LDS scratch, and every
+// instruction advances four sweeps at once (~115 instructions per chase step).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sum_a8(double v) { return sum_a(v); }  // over the 8 lanes that share (slot, h)
+
+// The body of the second stage for the calling workgroup's matrix: `band` = compact band (9 complex per row), or, when
+// it is null, the band is read from the upper triangle of the row-major matrix Hm itself (the fused kernel).  `smem` is
+// the workgroup's dynamic LDS (16 np complex + NW * 64 complex + n ints); Dm / Em receive the tridiagonal.
+template <int NW, bool FROM_H>  // (one instantiation per caller: each is inlined into its kernel)
+__device__ inline void chase4_body(const d2* __restrict__ band, const double* __restrict__ Hm, double* smem, int n, int np,
+                                            int stagger, double* __restrict__ Dm, double* __restrict__ Em) {
+    constexpr int NSLOT = 4 * NW;
+    d2* sL = reinterpret_cast<d2*>(smem);                           // [16][np]
+    d2* sScr = sL + (size_t)16 * np;                                // [NW][4 slots][16]: y (8) and x (8) by row
+    int* sStart = reinterpret_cast<int*>(sScr + NW * 64);           // [n] first tick of every sweep
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 7, h = (lane >> 3) & 1, g = lane >> 4;
+    d2* scr = sScr + (wave * 4 + g) * 16;
+
+    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
+    __syncthreads();
+    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
+        const int j = i / (PB + 1), dd = i % (PB + 1);
+        if (j + dd < n) {
+            const d2 v = FROM_H ? *reinterpret_cast<const d2*>(Hm + ((size_t)j * n + j + dd) * 2) : band[i];
+            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
+        }
+    }
+    const int n_sweeps = n - 2;
+    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };
+    if (tid == 0) {
+        for (int s = 0; s < n_sweeps; ++s) {
+            int t0 = 0;
+            if (s > 0) t0 = sStart[s - 1] + stagger;
+            if (s >= NSLOT) t0 = max(t0, sStart[s - NSLOT] + sweep_len(s - NSLOT));
+            sStart[s] = t0;
+        }
+    }
+    wg_sync();
+    if (n_sweeps > 0) {
+        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
+        // element (i, j) of the band lives at (i - j) np + j: per lane and column c the part that does not depend on
+        // the block position r0
+        int dstat[4], bstat[4];
+        bool d_conj[4], d_diag[4], d_low[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int b = 4 * h + c;
+            dstat[c] = abs(a - b) * np + min(a, b);
+            bstat[c] = (PB + a - b) * np + b;
+            d_conj[c] = a < b;
+            d_diag[c] = a == b;
+            d_low[c] = a >= b;
+        }
+        const int xstat = (PB + a) * np;  // first column of the block below, row a
+        int sw = wave * 4 + g;  // this slot's current / next sweep
+        int k = -1, k_len = 0;
+        d2 va = (d2){0.0, 0.0}, tau = va;
+        d2 vb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vb[c] = va;
+
+        // zlarfg from x_a (own row), x_b (the four rows named by this lane's columns) and alpha = x[0]
+        auto reflector = [&](d2 xa, const d2 (&xb)[4], d2 alpha, d2& o_va, d2 (&o_vb)[4], d2& o_tau, double& o_beta) {
+            const double sigma = sum_a8(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
+            o_tau = (d2){0.0, 0.0};
+            o_beta = alpha[0];
+            o_va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o_vb[c] = (4 * h + c == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+            const bool trivial = (sigma == 0.0 && alpha[1] == 0.0);  // uniform over the slot
+            const double norm2 = trivial ? 1.0 : alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma;
+            double root, rroot;
+            fast_sqrt_rsqrt(norm2, root, rroot);
+            const double beta = -copysign(root, alpha[0]);
+            const double rbeta = -copysign(rroot, alpha[0]);
+            const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+            const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+            const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+            if (!trivial) {
+                o_tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                o_beta = beta;
+                if (a != 0) o_va = cmul(xa, scale);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * h + c != 0) o_vb[c] = cmul(xb[c], scale);
+            }
+        };
+
+        for (int tick = 0; tick < total_ticks; ++tick) {
+            const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
+            if (__any(starting)) {
+                // first reflector of a sweep: column sw below the diagonal (slots that do not start read a valid column
+                // and drop the result)
+                const int j = starting ? sw : 0;
+                const d2 xa = sL[(size_t)(1 + a) * np + j];
+                d2 xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[c] = sL[(size_t)(1 + 4 * h + c) * np + j];
+                const d2 alpha = sL[(size_t)np + j];
+                d2 n_va, n_vb[4], n_tau;
+                double beta;
+                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
+                lds_fence();
+                if (starting) {
+                    va = n_va;
+                    tau = n_tau;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                    k = 0;
+                    k_len = sweep_len(sw);
+                    if (h == 0 && j + 1 + a < n) sL[(size_t)(1 + a) * np + j] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                }
+            }
+            const bool active = k >= 0;
+            if (__any(active)) {
+                const int r0 = active ? sw + 1 + PB * k : 0;
+                // all loads of the tick first
+                d2 dv[4], bk[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dv[c] = sL[dstat[c] + r0];
+                    bk[c] = sL[bstat[c] + r0];
+                }
+                const d2 bk0a = sL[xstat + r0];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (d_conj[c]) dv[c][1] = -dv[c][1];
+                    if (d_diag[c]) dv[c][1] = 0.0;
+                }
+                // row sums: y = D v and u = Bk v (four local terms, then the other half of the row)
+                d2 ya = (d2){0.0, 0.0}, ua = ya;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    cfma(ya, dv[c], vb[c]);
+                    cfma(ua, bk[c], vb[c]);
+                }
+                ya[0] += dpp_mov<0x128>(ya[0]);
+                ya[1] += dpp_mov<0x128>(ya[1]);
+                ua[0] += dpp_mov<0x128>(ua[0]);
+                ua[1] += dpp_mov<0x128>(ua[1]);
+                const d2 tu = cmul(tau, ua);
+                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};  // first column of Bk' (v[0] = 1 when tau != 0)
+                // y and x are needed by column too: through the slot's scratch (one wave: its LDS traffic is ordered)
+                asm volatile("" ::: "memory");
+                if (h == 0) {
+                    scr[a] = ya;
+                    scr[8 + a] = xa;
+                }
+                asm volatile("" ::: "memory");
+                d2 yb[4], xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    yb[c] = scr[4 * h + c];
+                    xb[c] = scr[8 + 4 * h + c];
+                }
+                const d2 alpha = scr[8];
+                asm volatile("" ::: "memory");
+                const double rho = sum_a8(va[0] * ya[0] + va[1] * ya[1]);
+                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
+                {
+                    const d2 ctau = conjd(tau);
+                    const d2 cva = cmul(ctau, va);   // conj(tau) v_a
+                    const d2 tya = cmul(tau, ya);    // tau y_a
+                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+                    const d2 fva = (d2){f * va[0], f * va[1]};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        d2 dn = dv[c];
+                        cfnmac(dn, cva, yb[c]);
+                        cfnmac(dn, tya, vb[c]);
+                        cfmac(dn, fva, vb[c]);
+                        if (active && d_low[c] && r0 + a < n) sL[dstat[c] + r0] = dn;
+                    }
+                }
+                // Bk' = Bk - tau u conj(v_b); next reflector from its first column; Bk'' = Bk' - conj(tau2) v2_a z_b
+                d2 bn[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bn[c] = bk[c];
+                    cfnmac(bn[c], tu, vb[c]);
+                }
+                d2 n_va, n_vb[4], n_tau;
+                double beta;
+                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
+                const d2 ctau2 = conjd(n_tau);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const d2 zc = sum_a2(cmulc(bn[c], n_va));  // conj(v2_a) Bk'[a][b] summed over the rows
+                    const d2 f2 = cmul(ctau2, zc);
+                    cfma(bn[c], (d2){-n_va[0], -n_va[1]}, f2);
+                    if (4 * h + c == 0) bn[c] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                    if (active && r0 + PB + a < n && r0 + 4 * h + c < n) sL[bstat[c] + r0] = bn[c];
+                }
+                if (active) {
+                    va = n_va;
+                    tau = n_tau;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                    if (++k == k_len) {
+                        k = -1;
+                        sw += NSLOT;
+                    }
+                }
+            }
+            wg_sync();
+        }
+    }
+    for (int j = tid; j < n; j += NW * 64) {
+        Dm[j] = sL[j][0];
+        double e = 0.0;
+        if (j + 1 < n) {
+            const d2 v = sL[(size_t)np + j];
+            e = sqrt(v[0] * v[0] + v[1] * v[1]);
+        }
+        Em[j] = e;
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+band_chase4_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
+    const size_t mat = blockIdx.x;
+    chase4_body<NW, false>(band_all + mat * (size_t)n * (PB + 1), nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
 // The previous panel's [V | W] rows live in global memory in MFMA-fragment order, so that a 16-row block is four
@@ -177,7 +607,8 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 
 template <int NT>
 __global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
-band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ band_all) {
+band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ band_all, int np, int stagger,
+                   double* __restrict__ D, double* __restrict__ E) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double br_smem[];
     const int tid = threadIdx.x;
@@ -716,6 +1147,13 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     // the band leaves in compact form -- band[i][dd] = H[i][i + dd], dd = 0..8 -- so that the matrix buffer is free for
     // the next chunk's H(k) while the second stage still works on this one
     wg_sync();
+    if (band_all == nullptr) {
+        // fused: this workgroup goes straight on to the second stage of its matrix, in the same LDS -- on a CU the
+        // other workgroup is then in some phase of ITS matrix, and the matrix-pipe, memory and vector-issue phases of
+        // the two overlap (two chase workgroups side by side are both limited by instruction issue)
+        chase4_body<NW, true>(nullptr, H, br_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
+        return;
+    }
     {
         d2* band = band_all + mat * (size_t)n * (PB + 1);
         for (int idx = tid; idx < n * (PB + 1); idx += NT) {
@@ -728,428 +1166,6 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     if (blockIdx.x == 0 && threadIdx.x == NT - 64)
         for (int k = 0; k < 16; ++k) tbk_band_clock[k] = clk_acc_[k];
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// stage 2
-// ------------------------------------------------------------------------------------------------
-// The band as LOWER diagonals in LDS: element (i, j), 0 <= i - j < 16, at sL[(i - j) * NP + j]; NP % 16 == 9 makes the
-// 8 x 8 block accesses of a wave (lane = row a + 8 column b) conflict-free for ds_read_b128.
-template <int CTRL>
-__device__ __forceinline__ d2 dpp_mov2(d2 v) { return (d2){dpp_mov<CTRL>(v[0]), dpp_mov<CTRL>(v[1])}; }
-
-// sum over the row index a = lane & 7 (lanes that share b): every lane ends with the total
-__device__ __forceinline__ double sum_a(double v) {
-    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
-    return v;
-}
-// sum over the column index b = lane >> 3 (lanes that share a)
-__device__ __forceinline__ double sum_b(double v) {
-    v += dpp_mov<0x128>(v);  // row_ror 8: b ^ 1
-    {
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
-    }
-    {
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
-    }
-    return v;
-}
-__device__ __forceinline__ d2 sum_a2(d2 v) { return (d2){sum_a(v[0]), sum_a(v[1])}; }
-__device__ __forceinline__ d2 sum_b2(d2 v) { return (d2){sum_b(v[0]), sum_b(v[1])}; }
-
-__device__ __forceinline__ double shfl_d(double v, int src_lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
-    hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
-    return __hiloint2double(hi, lo);
-}
-
-// zlarfg on a vector every lane knows through (x_a, x_b): returns beta, tau and this lane's v_a, v_b
-struct Reflector {
-    d2 va, vb, tau;
-    double beta;
-};
-__device__ __forceinline__ Reflector make_reflector(d2 xa, d2 xb, int a, int b) {
-    Reflector h;
-    const double sigma = sum_a(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
-    // alpha = x[0]: lane 0 holds it as xa
-    d2 alpha;
-    alpha[0] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[0])), __builtin_amdgcn_readfirstlane(__double2loint(xa[0])));
-    alpha[1] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[1])), __builtin_amdgcn_readfirstlane(__double2loint(xa[1])));
-    h.tau = (d2){0.0, 0.0};
-    h.beta = alpha[0];
-    h.va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
-    h.vb = (b == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
-    if (!(sigma == 0.0 && alpha[1] == 0.0)) {
-        double root, rroot;
-        fast_sqrt_rsqrt(alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma, root, rroot);
-        const double beta = -copysign(root, alpha[0]);
-        const double rbeta = -copysign(rroot, alpha[0]);
-        h.tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
-        const double qr_ = alpha[0] - beta, qi_ = alpha[1];
-        const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
-        const d2 scale = (d2){qr_ * qn, -qi_ * qn};
-        if (a != 0) h.va = cmul(xa, scale);
-        if (b != 0) h.vb = cmul(xb, scale);
-        h.beta = beta;
-    }
-    return h;
-}
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-band_chase_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
-    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
-    d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
-    int* sStart = reinterpret_cast<int*>(sL + (size_t)16 * np);     // [n] first tick of every sweep
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int a = lane & 7, b = lane >> 3;
-    const size_t mat = blockIdx.x;
-    const d2* band = band_all + mat * (size_t)n * (PB + 1);
-
-    auto L = [&](int i, int j) -> d2& { return sL[(size_t)(i - j) * np + j]; };
-
-    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
-    __syncthreads();
-    // lower band element (j + dd, j) = conj(H[j][j + dd])
-    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
-        const int j = i / (PB + 1), dd = i % (PB + 1);
-        if (j + dd < n) {
-            const d2 v = band[i];
-            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
-        }
-    }
-    const int n_sweeps = n - 2;
-    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };  // ticks of sweep j
-    if (tid == 0) {
-        for (int s = 0; s < n_sweeps; ++s) {
-            int t0 = 0;
-            if (s > 0) t0 = sStart[s - 1] + stagger;
-            if (s >= NW) t0 = max(t0, sStart[s - NW] + sweep_len(s - NW));
-            sStart[s] = t0;
-        }
-    }
-    wg_sync();
-    if (n_sweeps > 0) {
-        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
-        int sw = wave;  // this wave's current / next sweep
-        int k = -1;     // tick inside the sweep, -1 = waiting
-        int k_len = 0;
-        d2 va = (d2){0.0, 0.0}, vb = va, tau = va;
-        for (int tick = 0; tick < total_ticks; ++tick) {
-            if (k < 0 && sw < n_sweeps && tick == sStart[sw]) {
-                k = 0;
-                k_len = sweep_len(sw);
-                // first reflector of the sweep: column sw below the diagonal
-                const int j = sw;
-                const d2 xa = L(j + 1 + a, j), xb = L(j + 1 + b, j);
-                const Reflector h = make_reflector(xa, xb, a, b);
-                va = h.va;
-                vb = h.vb;
-                tau = h.tau;
-                lds_fence();
-                if (b == 0 && j + 1 + a < n) L(j + 1 + a, j) = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
-            }
-            if (k >= 0) {
-                const int r0 = sw + 1 + PB * k;
-                const int q0 = r0 + PB;
-                // all loads of the tick first
-                const int di = r0 + max(a, b), dj = r0 + min(a, b);
-                d2 dv = L(di, dj);
-                const d2 bk = L(q0 + a, r0 + b);
-                const d2 bk0a = L(q0 + a, r0), bk0b = L(q0 + b, r0);
-                if (a < b) dv = conjd(dv);
-                if (a == b) dv[1] = 0.0;
-                // y = D v (by rows and by columns), rho = v^H y
-                const d2 ya = sum_b2(cmul(dv, vb));
-                const d2 yb = sum_a2(cmulc(va, dv));  // conj(D[a][b]) v[a] summed over a = y[b]
-                const double rho = sum_a(va[0] * ya[0] + va[1] * ya[1]);
-                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
-                const d2 ctau = conjd(tau);
-                d2 dn = dv;
-                {
-                    const d2 t1 = cmul(ctau, cmulc(va, yb));
-                    const d2 t2 = cmul(tau, cmulc(ya, vb));
-                    const d2 t3 = cmulc(va, vb);
-                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
-                    dn[0] += -t1[0] - t2[0] + f * t3[0];
-                    dn[1] += -t1[1] - t2[1] + f * t3[1];
-                }
-                if (a >= b && di < n) L(di, dj) = dn;
-                // block below: Bk' = Bk - tau u conj(v_b), u = Bk v
-                const d2 ua = sum_b2(cmul(bk, vb));
-                const d2 tu = cmul(tau, ua);
-                d2 bn = bk;
-                cfnmac(bn, tu, vb);
-                // its first column is the next reflector's vector: x[a] = Bk[a][0] - tau u[a] (v[0] = 1 when tau != 0)
-                d2 ub;
-                ub[0] = shfl_d(ua[0], b);
-                ub[1] = shfl_d(ua[1], b);
-                const d2 tub = cmul(tau, ub);
-                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};
-                const d2 xb = (d2){bk0b[0] - tub[0], bk0b[1] - tub[1]};
-                const Reflector h = make_reflector(xa, xb, a, b);
-                // left-apply to the remaining columns: Bk'' = Bk' - conj(tau2) v2_a z_b, z = v2^H Bk'
-                const d2 zb = sum_a2(cmulc(bn, h.va));  // conj(v2_a) Bk'[a][b] summed over a
-                const d2 f2 = cmul(conjd(h.tau), zb);
-                cfma(bn, (d2){-h.va[0], -h.va[1]}, f2);
-                if (b == 0) bn = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
-                if (q0 + a < n && r0 + b < n) L(q0 + a, r0 + b) = bn;
-                va = h.va;
-                vb = h.vb;
-                tau = h.tau;
-                if (++k == k_len) {
-                    k = -1;
-                    sw += NW;
-                }
-            }
-            wg_sync();
-        }
-    }
-    for (int j = tid; j < n; j += NW * 64) {
-        D[mat * n + j] = L(j, j)[0];
-        double e = 0.0;
-        if (j + 1 < n) {
-            const d2 v = L(j + 1, j);
-            e = sqrt(v[0] * v[0] + v[1] * v[1]);
-        }
-        E[mat * n + j] = e;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// stage 2, packed: FOUR sweeps per wave.  A chase step works on 8 x 8 blocks; with a whole wave per step most of the
-// ~350 instructions are cross-lane reductions and scalar work replicated 64 times.  Here a sweep gets 16 lanes -- lane
-// (a = l & 7, h = (l >> 3) & 1) holds row a, columns 4 h .. 4 h + 3 of a block -- so row sums are four local terms plus
-// one exchange, the vectors that are needed by column (y, x) cross over through a wave-private LDS scratch, and every
-// instruction advances four sweeps at once (~115 instructions per chase step).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sum_a8(double v) { return sum_a(v); }  // over the 8 lanes that share (slot, h)
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-band_chase4_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
-    constexpr int NSLOT = 4 * NW;
-    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
-    d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
-    d2* sScr = sL + (size_t)16 * np;                                // [NW][4 slots][16]: y (8) and x (8) by row
-    int* sStart = reinterpret_cast<int*>(sScr + NW * 64);           // [n] first tick of every sweep
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int a = lane & 7, h = (lane >> 3) & 1, g = lane >> 4;
-    const size_t mat = blockIdx.x;
-    const d2* band = band_all + mat * (size_t)n * (PB + 1);
-    d2* scr = sScr + (wave * 4 + g) * 16;
-
-    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
-    __syncthreads();
-    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
-        const int j = i / (PB + 1), dd = i % (PB + 1);
-        if (j + dd < n) {
-            const d2 v = band[i];
-            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
-        }
-    }
-    const int n_sweeps = n - 2;
-    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };
-    if (tid == 0) {
-        for (int s = 0; s < n_sweeps; ++s) {
-            int t0 = 0;
-            if (s > 0) t0 = sStart[s - 1] + stagger;
-            if (s >= NSLOT) t0 = max(t0, sStart[s - NSLOT] + sweep_len(s - NSLOT));
-            sStart[s] = t0;
-        }
-    }
-    wg_sync();
-    if (n_sweeps > 0) {
-        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
-        // element (i, j) of the band lives at (i - j) np + j: per lane and column c the part that does not depend on
-        // the block position r0
-        int dstat[4], bstat[4];
-        bool d_conj[4], d_diag[4], d_low[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int b = 4 * h + c;
-            dstat[c] = abs(a - b) * np + min(a, b);
-            bstat[c] = (PB + a - b) * np + b;
-            d_conj[c] = a < b;
-            d_diag[c] = a == b;
-            d_low[c] = a >= b;
-        }
-        const int xstat = (PB + a) * np;  // first column of the block below, row a
-        int sw = wave * 4 + g;  // this slot's current / next sweep
-        int k = -1, k_len = 0;
-        d2 va = (d2){0.0, 0.0}, tau = va;
-        d2 vb[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) vb[c] = va;
-
-        // zlarfg from x_a (own row), x_b (the four rows named by this lane's columns) and alpha = x[0]
-        auto reflector = [&](d2 xa, const d2 (&xb)[4], d2 alpha, d2& o_va, d2 (&o_vb)[4], d2& o_tau, double& o_beta) {
-            const double sigma = sum_a8(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
-            o_tau = (d2){0.0, 0.0};
-            o_beta = alpha[0];
-            o_va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o_vb[c] = (4 * h + c == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
-            const bool trivial = (sigma == 0.0 && alpha[1] == 0.0);  // uniform over the slot
-            const double norm2 = trivial ? 1.0 : alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma;
-            double root, rroot;
-            fast_sqrt_rsqrt(norm2, root, rroot);
-            const double beta = -copysign(root, alpha[0]);
-            const double rbeta = -copysign(rroot, alpha[0]);
-            const double qr_ = alpha[0] - beta, qi_ = alpha[1];
-            const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
-            const d2 scale = (d2){qr_ * qn, -qi_ * qn};
-            if (!trivial) {
-                o_tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
-                o_beta = beta;
-                if (a != 0) o_va = cmul(xa, scale);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (4 * h + c != 0) o_vb[c] = cmul(xb[c], scale);
-            }
-        };
-
-        for (int tick = 0; tick < total_ticks; ++tick) {
-            const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
-            if (__any(starting)) {
-                // first reflector of a sweep: column sw below the diagonal (slots that do not start read a valid column
-                // and drop the result)
-                const int j = starting ? sw : 0;
-                const d2 xa = sL[(size_t)(1 + a) * np + j];
-                d2 xb[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) xb[c] = sL[(size_t)(1 + 4 * h + c) * np + j];
-                const d2 alpha = sL[(size_t)np + j];
-                d2 n_va, n_vb[4], n_tau;
-                double beta;
-                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
-                lds_fence();
-                if (starting) {
-                    va = n_va;
-                    tau = n_tau;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
-                    k = 0;
-                    k_len = sweep_len(sw);
-                    if (h == 0 && j + 1 + a < n) sL[(size_t)(1 + a) * np + j] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
-                }
-            }
-            const bool active = k >= 0;
-            if (__any(active)) {
-                const int r0 = active ? sw + 1 + PB * k : 0;
-                // all loads of the tick first
-                d2 dv[4], bk[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    dv[c] = sL[dstat[c] + r0];
-                    bk[c] = sL[bstat[c] + r0];
-                }
-                const d2 bk0a = sL[xstat + r0];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (d_conj[c]) dv[c][1] = -dv[c][1];
-                    if (d_diag[c]) dv[c][1] = 0.0;
-                }
-                // row sums: y = D v and u = Bk v (four local terms, then the other half of the row)
-                d2 ya = (d2){0.0, 0.0}, ua = ya;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    cfma(ya, dv[c], vb[c]);
-                    cfma(ua, bk[c], vb[c]);
-                }
-                ya[0] += dpp_mov<0x128>(ya[0]);
-                ya[1] += dpp_mov<0x128>(ya[1]);
-                ua[0] += dpp_mov<0x128>(ua[0]);
-                ua[1] += dpp_mov<0x128>(ua[1]);
-                const d2 tu = cmul(tau, ua);
-                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};  // first column of Bk' (v[0] = 1 when tau != 0)
-                // y and x are needed by column too: through the slot's scratch (one wave: its LDS traffic is ordered)
-                asm volatile("" ::: "memory");
-                if (h == 0) {
-                    scr[a] = ya;
-                    scr[8 + a] = xa;
-                }
-                asm volatile("" ::: "memory");
-                d2 yb[4], xb[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    yb[c] = scr[4 * h + c];
-                    xb[c] = scr[8 + 4 * h + c];
-                }
-                const d2 alpha = scr[8];
-                asm volatile("" ::: "memory");
-                const double rho = sum_a8(va[0] * ya[0] + va[1] * ya[1]);
-                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
-                {
-                    const d2 ctau = conjd(tau);
-                    const d2 cva = cmul(ctau, va);   // conj(tau) v_a
-                    const d2 tya = cmul(tau, ya);    // tau y_a
-                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
-                    const d2 fva = (d2){f * va[0], f * va[1]};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        d2 dn = dv[c];
-                        cfnmac(dn, cva, yb[c]);
-                        cfnmac(dn, tya, vb[c]);
-                        cfmac(dn, fva, vb[c]);
-                        if (active && d_low[c] && r0 + a < n) sL[dstat[c] + r0] = dn;
-                    }
-                }
-                // Bk' = Bk - tau u conj(v_b); next reflector from its first column; Bk'' = Bk' - conj(tau2) v2_a z_b
-                d2 bn[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bn[c] = bk[c];
-                    cfnmac(bn[c], tu, vb[c]);
-                }
-                d2 n_va, n_vb[4], n_tau;
-                double beta;
-                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
-                const d2 ctau2 = conjd(n_tau);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const d2 zc = sum_a2(cmulc(bn[c], n_va));  // conj(v2_a) Bk'[a][b] summed over the rows
-                    const d2 f2 = cmul(ctau2, zc);
-                    cfma(bn[c], (d2){-n_va[0], -n_va[1]}, f2);
-                    if (4 * h + c == 0) bn[c] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
-                    if (active && r0 + PB + a < n && r0 + 4 * h + c < n) sL[bstat[c] + r0] = bn[c];
-                }
-                if (active) {
-                    va = n_va;
-                    tau = n_tau;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
-                    if (++k == k_len) {
-                        k = -1;
-                        sw += NSLOT;
-                    }
-                }
-            }
-            wg_sync();
-        }
-    }
-    for (int j = tid; j < n; j += NW * 64) {
-        D[mat * n + j] = sL[j][0];
-        double e = 0.0;
-        if (j + 1 < n) {
-            const d2 v = sL[(size_t)np + j];
-            e = sqrt(v[0] * v[0] + v[1] * v[1]);
-        }
-        E[mat * n + j] = e;
-    }
 }
 
 }  // namespace
@@ -1168,6 +1184,17 @@ static int chase_pitch(int n) {
 // The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 129 orbitals on: up to 128 the one-stage kernel of
 // tbk_eig_stream.hip (four waves per matrix, rows of two 64-column chunks) is faster -- 0.65 vs 0.84 us per matrix at 65
 // orbitals, 1.73 vs 2.14 at 128; from 129 on the one-stage rows grow a third chunk and the order flips (3.8 vs 3.3 us at 160).
+// Both stages in ONE kernel (the workgroup goes straight on to the bulge chasing of its matrix, in the same LDS) or in
+// two launches with the second one on the tridiagonal stream next to the following chunk's first stage.  Per matrix
+// the two cost the same -- a workgroup's critical path is the sum of its phases either way -- and in the chunk pipeline
+// fused is 1 % ahead at 256 orbitals (cfg3 134.1 vs 132.3 k k-points/s), 4 % behind at 512 (cfg5 13.5 vs 14.0 k: one
+// workgroup per CU there, and the separate launch fills the gaps of the next chunk's first stage).  TBK_BAND_FUSE=0 / 1
+// forces one (measurements).
+bool tbk_band_fused(int n) {
+    static const int forced = getenv("TBK_BAND_FUSE") ? atoi(getenv("TBK_BAND_FUSE")) : -1;
+    return forced >= 0 ? forced != 0 : n <= 256;
+}
+
 bool tbk_eig_band_supported(int n) { return n > 64 && n <= 512; }
 bool tbk_eig_band_preferred(int n) {
     static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 129;  // measurements only
@@ -1178,7 +1205,7 @@ size_t tbk_band_bytes_per_matrix(int n) { return (size_t)n * (PB + 1) * sizeof(d
 
 // Stage one: the upper triangle of every d_H matrix is overwritten; d_vw: scratch of tbk_band_scratch_per_matrix(n)
 // bytes per matrix; d_band receives the band, tbk_band_bytes_per_matrix(n) bytes per matrix.
-int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band) {
+int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band, double* d_de_fused) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_EIG, s);
@@ -1186,16 +1213,24 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     static const int big_from = getenv("TBK_BAND_NT512_FROM") ? atoi(getenv("TBK_BAND_NT512_FROM")) : 257;  // measurements only
     const bool small = n <= 256 && n < big_from;
     const int nw = small ? 4 : 8;
-    const size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+    size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+    // d_de_fused: the workgroup runs the second stage too (same LDS) and writes (d, e) itself; d_band is not used
+    const int np = chase_pitch(n);
+    double* d_D = d_de_fused;
+    double* d_E = d_de_fused ? d_de_fused + (size_t)nk * n : nullptr;
+    if (d_de_fused) {
+        lds = std::max(lds, (size_t)16 * np * 16 + (size_t)nw * 64 * 16 + (size_t)n * sizeof(int) + 16);
+        d_band = nullptr;
+    }
     static bool raised_a[TBK_MAX_DEVICES] = {}, raised_b[TBK_MAX_DEVICES] = {};
     if (small) {
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<256>), (int)lds, raised_a));
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<256>), 160 * 1024, raised_a));
         hipLaunchKernelGGL(band_reduce_kernel<256>, dim3((unsigned)nk), dim3(256), lds, s, d_H, n, static_cast<d2*>(d_vw),
-                           static_cast<d2*>(d_band));
+                           static_cast<d2*>(d_band), np, 2, d_D, d_E);
     } else {
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<512>), (int)lds, raised_b));
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<512>), 160 * 1024, raised_b));
         hipLaunchKernelGGL(band_reduce_kernel<512>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, static_cast<d2*>(d_vw),
-                           static_cast<d2*>(d_band));
+                           static_cast<d2*>(d_band), np, 2, d_D, d_E);
     }
     TBK_HIP(hipGetLastError());
     return TBK_OK;

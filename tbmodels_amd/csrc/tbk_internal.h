@@ -263,7 +263,10 @@ bool tbk_eig_band_preferred(int n);
 size_t tbk_band_scratch_per_matrix(int n);
 size_t tbk_band_bytes_per_matrix(int n);
 bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this model (64 < n_orb <= 512, not TBK_BAND=0)
-int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band);
+// d_de_fused != NULL: every workgroup runs the second stage for its matrix too and writes (d, e); d_band is not used
+int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band,
+                           double* d_de_fused = nullptr);
+bool tbk_band_fused(int n);  // both stages in one kernel (<= 256 orbitals) or two launches, the second one overlappable
 int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de);
 
 // tbk_eig_small.hip

@@ -42,8 +42,12 @@ int main(int argc, char** argv) {
         hipEventCreate(&b);
         hipDeviceSynchronize();
         hipEventRecord(a, nullptr);
-        tbk_launch_band_reduce(&m, nullptr, d_H, nk, d_vw, d_band);
-        tbk_launch_band_chase(&m, nullptr, d_band, nk, d_de);
+        if (tbk_band_fused(n)) {
+            tbk_launch_band_reduce(&m, nullptr, d_H, nk, d_vw, nullptr, d_de);
+        } else {
+            tbk_launch_band_reduce(&m, nullptr, d_H, nk, d_vw, d_band);
+            tbk_launch_band_chase(&m, nullptr, d_band, nk, d_de);
+        }
         hipEventRecord(b, nullptr);
         hipDeviceSynchronize();
         float ms = 0;
