@@ -996,6 +996,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 }
             }
         }
+        // The last step's totals are read from the partial-sum area as they are used; the Gram sums below write it
+        // again: without this meeting a wave that had run ahead overwrote partials another wave was still adding up
+        // (1 wrong matrix in ~250 000; tools/race_check2.py).
+        lds_fence();
+        __syncthreads();
         TBK_CLK(15);  // QR: reflector + update (and whatever follows the last step)
         // thread s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
         if (qr_row && i_row < s + PB) {

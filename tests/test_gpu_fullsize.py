@@ -241,3 +241,24 @@ def test_repeated_runs_are_bit_identical(n_orb, n_r, n_k, reps):
     for _ in range(reps):
         again = np.array(model.eigenval(k))
         assert np.array_equal(again, first)
+
+
+@pytest.mark.parametrize("n_orb,n_k,reps", [(256, 4096, 60), (150, 4096, 40), (130, 2048, 30), (400, 1024, 24), (512, 1024, 16)])
+def test_two_stage_reduction_is_race_free(n_orb, n_k, reps):
+    """The two-stage reduction (csrc/tbk_eig_band.hip) has a dozen phases per panel that meet at workgroup barriers and
+    share LDS; a missing meeting shows up as a WRONG matrix once in ~10^5 (round 2: the last QR step's partial sums
+    were overwritten by a wave that had run ahead -- 2 rows in 500 000, off by 1e-2).  Many repetitions of one call:
+    every row must come out bit-identical every time, and right."""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 16, syn.MODEL_SEED + n_orb)
+    k = syn.random_kpoints(n_k, seed=n_orb)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    first = model.eigenval_array(k).copy()
+    traces = np.einsum("rii->r", hop)
+    assert np.abs(first.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    ref = np.array(oracle.eigenval(r_vec, hop, k[:3]))
+    assert np.abs(first[:3] - ref).max() < 1e-10
+    for rep in range(reps):
+        again = model.eigenval_array(k)
+        bad = np.flatnonzero(np.any(again != first, axis=1))
+        assert len(bad) == 0, "repetition %d: rows %s differ by up to %.2e" % (
+            rep, bad[:5], np.abs(again[bad] - first[bad]).max())
