@@ -371,7 +371,8 @@ __device__ __forceinline__ double sum_a8(double v) { return sum_a(v); }  // over
 // The body of the second stage for the calling workgroup's matrix: `band` = compact band (9 complex per row), or, when
 // it is null, the band is read from the upper triangle of the row-major matrix Hm itself (the fused kernel).  `smem` is
 // the workgroup's dynamic LDS (16 np complex + NW * 64 complex + n ints); Dm / Em receive the tridiagonal.
-template <int NW, bool FROM_H>  // (one instantiation per caller: each is inlined into its kernel)
+template <int NW, bool FROM_H, int CALLER = 0>  // (one instantiation per calling kernel: each is inlined into it -- with two
+// callers of one instantiation hipcc keeps a real function call: 248 registers and a stack frame in both)
 __device__ inline void chase4_body(const d2* __restrict__ band, const double* __restrict__ Hm, double* smem, int n, int np,
                                             int stagger, double* __restrict__ Dm, double* __restrict__ Em) {
     constexpr int NSLOT = 4 * NW;
@@ -605,10 +606,14 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
     double re[4], im[4];
 };
 
-template <int NT>
+// NT threads per workgroup, ROWS rows of the matrix per thread in the thread-per-row phases (n <= NT * ROWS), VN_LDS: the
+// next panel's V in LDS beside X (up to 256 orbitals) or in global memory (above: X alone is 64 KiB at 512 orbitals, and
+// with V beside it only ONE workgroup fits a CU -- nothing then overlaps its serial phases; the 8-wave / one-row variant
+// <512, 1, true> is kept for comparison, TBK_BAND_NT512_FROM).
+template <int NT, int ROWS, bool VN_LDS>
 __global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
-band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ band_all, int np, int stagger,
-                   double* __restrict__ D, double* __restrict__ E) {
+band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all, int np,
+                   int stagger, double* __restrict__ D, double* __restrict__ E) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double br_smem[];
     const int tid = threadIdx.x;
@@ -616,9 +621,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbk = (n + TS - 1) / TS;
     const int npad = nbk * TS;
-    d2* sVn = reinterpret_cast<d2*>(br_smem);              // [npad][8]   next panel's V (rows < s are zero)
-    d2* sX = sVn + (size_t)npad * PB;                      // [npad][8]   A V of the next panel
-    double* sTr = reinterpret_cast<double*>(sX + (size_t)npad * PB);  // [NW][16][17] tile transposition, one plane per wave
+    d2* sX = reinterpret_cast<d2*>(br_smem);               // [npad][8]   A V of the next panel
+    d2* sVnL = sX + (size_t)npad * PB;                     // [npad][8]   next panel's V (rows < s are zero), VN_LDS only
+    double* sTr = reinterpret_cast<double*>(sVnL + (VN_LDS ? (size_t)npad * PB : 0));  // [NW][16][17] tile transposition planes
     double* sPart = sTr + NW * 16 * 17;                    // [NW][64]
     double* sTot = sPart + NW * 64;                        // [64]
     d2* sRow = reinterpret_cast<d2*>(sTot + 64);           // [2][8] row c of the panel (QR), broadcast; alternating
@@ -633,6 +638,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     const size_t mat = blockIdx.x;
     double* H = Hall + mat * (size_t)n * n * 2;
     d2* VW = VWall + mat * (size_t)nbk * 256;
+    d2* sVn = VN_LDS ? sVnL : VNall + mat * (size_t)npad * PB;  // the next panel's V, [npad][8], wherever it lives
 
     // the pending-update buffer starts out empty
     for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
@@ -665,6 +671,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             int I, I2, Ir, Jc;
             d4 tre, tim;
             Frag par;
+            double pb[4];  // the partner's Vn operand ([Re | Im] packed), requested with the rest when it is not in LDS
         };
         auto request = [&](int v, Visit& o) {  // issues the global loads of visit v: no waits, and no branches around
             // the loads (the compiler's wait-count tracking gives up at a merge: it then waits for everything in flight);
@@ -687,6 +694,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 const d2 v2 = VW[((size_t)o.I2 * 4 + sg) * 64 + lane];
                 o.par.re[sg] = v2[0];
                 o.par.im[sg] = v2[1];
+            }
+            if (!VN_LDS) {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg)
+                    o.pb[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(o.I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
             }
             // clamped addresses; rows / columns beyond n are masked when the tile is used
             const int gc = o.Jc * TS + lrow;
@@ -721,13 +733,15 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     own2 = own1;
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg)
-                        own_b[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(cur.I * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                        own_b[sg] = VN_LDS ? reinterpret_cast<const double*>(sVn)[(size_t)(cur.I * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)]
+                                           : cur.pb[sg];
                 }
                 double par_b[4];
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg)
                     par_b[sg] = diag ? own_b[sg]
-                                     : reinterpret_cast<const double*>(sVn)[(size_t)(I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                                     : (VN_LDS ? reinterpret_cast<const double*>(sVn)[(size_t)(I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)]
+                                               : cur.pb[sg]);
                 d4 tre = cur.tre, tim = cur.tim;
                 const int gc = Jc * TS + lrow;
 #pragma unroll
@@ -863,7 +877,8 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         wg_sync();  // tile stores complete before anybody re-reads the matrix
     };
 
-    const int i_row = tid;  // thread <-> global row / column index in the thread-per-row phases
+    // thread t <-> global rows / columns t + rr NT, rr < ROWS, in the thread-per-row phases
+    auto row_of = [&](int rr) { return tid + rr * NT; };
     int p = 0;
     for (;; ++p) {
         const int g0 = PB * p;       // first row of the panel
@@ -874,38 +889,42 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // ---- look-ahead: block row p (8 rows, columns >= 8 p) brought up to date with the pending (V, W) ----
         if (have_update && tid < 128) sG[tid] = VW[vw_index(g0 + (tid >> 4), tid & 15)];
         wg_sync();
-        d2 x[PB];
+        d2 x[ROWS][PB];
 #pragma unroll
-        for (int r = 0; r < PB; ++r) x[r] = (d2){0.0, 0.0};
-        const bool in_rows = i_row >= g0 && i_row < n;
-        if (in_rows) {
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int i_row = row_of(rr);
 #pragma unroll
-            for (int r = 0; r < PB; ++r) {
-                const int g = g0 + r;
-                if (g < n) {  // uniform; one unconditional load of the stored (upper) element either way
-                    const bool upper = i_row >= g;
-                    const d2 v = *Hat(upper ? g : i_row, upper ? i_row : g);
-                    x[r] = upper ? v : conjd(v);
-                }
-            }
-            if (have_update) {
-                d2 vw[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) vw[c] = VW[vw_index(i_row, c)];
+            for (int r = 0; r < PB; ++r) x[rr][r] = (d2){0.0, 0.0};
+            const bool in_rows = i_row >= g0 && i_row < n;
+            if (in_rows) {
 #pragma unroll
                 for (int r = 0; r < PB; ++r) {
-#pragma unroll
-                    for (int t = 0; t < PB; ++t) {
-                        cfnmac(x[r], sG[r * 16 + t], vw[PB + t]);      // - V[g][t] conj(W[i][t])
-                        cfnmac(x[r], sG[r * 16 + PB + t], vw[t]);      // - W[g][t] conj(V[i][t])
+                    const int g = g0 + r;
+                    if (g < n) {  // uniform; one unconditional load of the stored (upper) element either way
+                        const bool upper = i_row >= g;
+                        const d2 v = *Hat(upper ? g : i_row, upper ? i_row : g);
+                        x[rr][r] = upper ? v : conjd(v);
                     }
                 }
-            }
-            // the diagonal block is final
-            if (i_row < s) {
+                if (have_update) {
+                    d2 vw[16];
 #pragma unroll
-                for (int r = 0; r < PB; ++r)
-                    if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[r];
+                    for (int c = 0; c < 16; ++c) vw[c] = VW[vw_index(i_row, c)];
+#pragma unroll
+                    for (int r = 0; r < PB; ++r) {
+#pragma unroll
+                        for (int t = 0; t < PB; ++t) {
+                            cfnmac(x[rr][r], sG[r * 16 + t], vw[PB + t]);      // - V[g][t] conj(W[i][t])
+                            cfnmac(x[rr][r], sG[r * 16 + PB + t], vw[t]);      // - W[g][t] conj(V[i][t])
+                        }
+                    }
+                }
+                // the diagonal block is final
+                if (i_row < s) {
+#pragma unroll
+                    for (int r = 0; r < PB; ++r)
+                        if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[rr][r];
+                }
             }
         }
         if (have_update) {  // the pending rows (sG) share their LDS with the partial sums of the reductions below
@@ -913,36 +932,43 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             __syncthreads();
         }
         TBK_CLK(0);
-        // ---- Householder QR of the panel on threads i >= s: y = conj(x) (model: panel_qr) ----
-        const bool qr_row = i_row >= s && i_row < n;
-        d2 y[PB], vn[PB];
-        d2 tau[PB];
+        // ---- Householder QR of the panel on rows i >= s: y = conj(x) (model: panel_qr) ----
+        d2 y[ROWS][PB], vn[ROWS][PB];
+        bool qr_row[ROWS];
 #pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            y[c] = qr_row ? conjd(x[c]) : (d2){0.0, 0.0};
-            vn[c] = (d2){0.0, 0.0};
-            tau[c] = (d2){0.0, 0.0};
+        for (int rr = 0; rr < ROWS; ++rr) {
+            qr_row[rr] = row_of(rr) >= s && row_of(rr) < n;
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                y[rr][c] = qr_row[rr] ? conjd(x[rr][c]) : (d2){0.0, 0.0};
+                vn[rr][c] = (d2){0.0, 0.0};
+            }
         }
+        if (tid < PB) sTau[tid] = (d2){0.0, 0.0};  // (read after the barriers of the Gram sums below)
 #pragma unroll
         for (int c = 0; c < PB; ++c) {
             if (c <= m - 2) {  // uniform: a row below the diagonal exists
-                const bool below = qr_row && i_row >= s + c;
+                bool below[ROWS];
                 double pv[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) pv[k] = 0.0;
-                if (below) {
-                    pv[0] = y[c][0] * y[c][0] + y[c][1] * y[c][1];
-#pragma unroll
-                    for (int cp = c + 1; cp < PB; ++cp) {
-                        const d2 t = cmulc(y[cp], y[c]);  // conj(y_c) y_cp
-                        pv[1 + 2 * (cp - c - 1)] = t[0];
-                        pv[2 + 2 * (cp - c - 1)] = t[1];
-                    }
-                }
                 d2* row_buf = sRow + (c & 1) * PB;  // (a fast thread writes row c + 1 while a slow one still reads row c)
-                if (i_row == s + c) {
 #pragma unroll
-                    for (int cp = 0; cp < PB; ++cp) row_buf[cp] = y[cp];
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    below[rr] = qr_row[rr] && row_of(rr) >= s + c;
+                    if (below[rr]) {
+                        pv[0] += y[rr][c][0] * y[rr][c][0] + y[rr][c][1] * y[rr][c][1];
+#pragma unroll
+                        for (int cp = c + 1; cp < PB; ++cp) {
+                            const d2 t = cmulc(y[rr][cp], y[rr][c]);  // conj(y_c) y_cp
+                            pv[1 + 2 * (cp - c - 1)] += t[0];
+                            pv[2 + 2 * (cp - c - 1)] += t[1];
+                        }
+                    }
+                    if (row_of(rr) == s + c) {
+#pragma unroll
+                        for (int cp = 0; cp < PB; ++cp) row_buf[cp] = y[rr][cp];
+                    }
                 }
                 TBK_CLK(12);  // QR: products
                 // ONE meeting per step: every wave leaves its 16 partial sums (alternating halves of its row of the
@@ -968,14 +994,18 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     fast_sqrt_rsqrt(gcc, root, rroot);
                     const double beta = -copysign(root, alpha[0]);
                     const double rbeta = -copysign(rroot, alpha[0]);
-                    tau[c] = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                    const d2 tau_c = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                    if (tid == 0) sTau[c] = tau_c;
                     const double qr_ = alpha[0] - beta, qi_ = alpha[1];
                     const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
                     const d2 scale = (d2){qr_ * qn, -qi_ * qn};  // 1 / (alpha - beta)
-                    d2 v = (d2){0.0, 0.0};
-                    if (below) v = (i_row == s + c) ? (d2){1.0, 0.0} : cmul(y[c], scale);
-                    vn[c] = v;
-                    const d2 ctau = conjd(tau[c]);
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+                        d2 v = (d2){0.0, 0.0};
+                        if (below[rr]) v = (row_of(rr) == s + c) ? (d2){1.0, 0.0} : cmul(y[rr][c], scale);
+                        vn[rr][c] = v;
+                    }
+                    const d2 ctau = conjd(tau_c);
 #pragma unroll
                     for (int cp = c + 1; cp < PB; ++cp) {
                         const d2 g = (d2){total(1 + 2 * (cp - c - 1)), total(2 + 2 * (cp - c - 1))};
@@ -987,12 +1017,17 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         z[0] += rowv[0];
                         z[1] += rowv[1];
                         const d2 f = cmul(ctau, z);
-                        if (below) {
-                            y[cp][0] -= v[0] * f[0] - v[1] * f[1];
-                            y[cp][1] -= v[0] * f[1] + v[1] * f[0];
+#pragma unroll
+                        for (int rr = 0; rr < ROWS; ++rr) {
+                            if (below[rr]) {
+                                y[rr][cp][0] -= vn[rr][c][0] * f[0] - vn[rr][c][1] * f[1];
+                                y[rr][cp][1] -= vn[rr][c][0] * f[1] + vn[rr][c][1] * f[0];
+                            }
                         }
                     }
-                    if (below) y[c] = (i_row == s + c) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr)
+                        if (below[rr]) y[rr][c] = (row_of(rr) == s + c) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
                 }
             }
         }
@@ -1002,12 +1037,16 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         lds_fence();
         __syncthreads();
         TBK_CLK(15);  // QR: reflector + update (and whatever follows the last step)
-        // thread s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
-        if (qr_row && i_row < s + PB) {
-            const int c = i_row - s;
+        // the thread of row s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
 #pragma unroll
-            for (int r = 0; r < PB; ++r)
-                if (g0 + r < n) *Hat(g0 + r, i_row) = (r >= c) ? conjd(y[r]) : (d2){0.0, 0.0};
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int i_row = row_of(rr);
+            if (qr_row[rr] && i_row < s + PB) {
+                const int c = i_row - s;
+#pragma unroll
+                for (int r = 0; r < PB; ++r)
+                    if (g0 + r < n) *Hat(g0 + r, i_row) = (r >= c) ? conjd(y[rr][r]) : (d2){0.0, 0.0};
+            }
         }
         TBK_CLK(1);
         // ---- T of the compact WY form from the Gram matrix of V (model: t_factor); kept in LDS over the big pass ----
@@ -1019,7 +1058,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             for (int c = 1; c < PB; ++c) {
 #pragma unroll
                 for (int c2 = 0; c2 < c; ++c2) {
-                    const d2 t = cmulc(vn[c], vn[c2]);
+                    d2 t = (d2){0.0, 0.0};
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) cfmac(t, vn[rr][c], vn[rr][c2]);  // conj(v_c2) v_c
                     hold[k & 3] = t[0];
                     hold[(k + 1) & 3] = t[1];
                     k += 2;
@@ -1027,11 +1068,6 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 }
             }
             wg_finish<NW>(56, sPart, sTot, tid);
-            if (tid < PB) sTau[tid] = (d2){0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < PB; ++c)
-                if (tid == c) sTau[c] = tau[c];
-            lds_fence();
             // lane a of the first wave builds row a of T: T[a][c] = -tau_c sum_{c2 = a}^{c - 1} T[a][c2] G[c2][c]
             if (tid < PB) {
                 const int a = tid;
@@ -1045,19 +1081,24 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         const d2 g = (d2){sTot[slot], sTot[slot + 1]};
                         if (c2 >= a) cfma(acc, trow[c2], g);
                     }
-                    const d2 t = cmul(tau[c], acc);
-                    trow[c] = (c == a) ? tau[c] : (c > a ? (d2){-t[0], -t[1]} : (d2){0.0, 0.0});
+                    const d2 tau_c = sTau[c];
+                    const d2 t = cmul(tau_c, acc);
+                    trow[c] = (c == a) ? tau_c : (c > a ? (d2){-t[0], -t[1]} : (d2){0.0, 0.0});
                     sT[a * PB + c] = trow[c];
                 }
             }
         }
         TBK_CLK(2);
-        // ---- hand over: Vn to LDS, X cleared, the consumed pending rows zeroed ----
-        if (i_row < npad) {
+        // ---- hand over: Vn (LDS or global), X cleared, the consumed pending rows zeroed ----
 #pragma unroll
-            for (int c = 0; c < PB; ++c) {
-                sVn[(size_t)i_row * PB + c] = vn[c];
-                sX[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int i_row = row_of(rr);
+            if (i_row < npad) {
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    sVn[(size_t)i_row * PB + c] = vn[rr][c];
+                    sX[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
+                }
             }
         }
         if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
@@ -1066,11 +1107,15 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         big_pass(s, have_update, true);
         TBK_CLK(4);
         // ---- W = X T - V S / 2,  S = T^H (V^H X) T  (model: stage1_band) ----
-        d2 xr[PB], vr[PB];  // this thread's rows of A V and of V, back from LDS (nothing lives in registers over the pass)
+        d2 xr[ROWS][PB], vr[ROWS][PB];  // this thread's rows of A V and of V, read back (nothing lives in registers over the pass)
 #pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            xr[c] = (qr_row) ? sX[(size_t)i_row * PB + c] : (d2){0.0, 0.0};
-            vr[c] = (qr_row) ? sVn[(size_t)i_row * PB + c] : (d2){0.0, 0.0};
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int i_row = min(row_of(rr), npad - 1);
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                xr[rr][c] = qr_row[rr] ? sX[(size_t)i_row * PB + c] : (d2){0.0, 0.0};
+                vr[rr][c] = qr_row[rr] ? sVn[(size_t)i_row * PB + c] : (d2){0.0, 0.0};
+            }
         }
         {
             // M = V^H (A V) is Hermitian: upper triangle, row a at slot a (16 - a): the real diagonal entry, then
@@ -1082,11 +1127,16 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
                 for (int b = a; b < PB; ++b) {
                     if (b == a) {
-                        hold[k & 3] = vr[a][0] * xr[a][0] + vr[a][1] * xr[a][1];
+                        double t = 0.0;
+#pragma unroll
+                        for (int rr = 0; rr < ROWS; ++rr) t += vr[rr][a][0] * xr[rr][a][0] + vr[rr][a][1] * xr[rr][a][1];
+                        hold[k & 3] = t;
                         k += 1;
                         if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
                     } else {
-                        const d2 t = cmulc(xr[b], vr[a]);  // conj(v_a) x_b
+                        d2 t = (d2){0.0, 0.0};
+#pragma unroll
+                        for (int rr = 0; rr < ROWS; ++rr) cfmac(t, xr[rr][b], vr[rr][a]);  // conj(v_a) x_b
                         hold[k & 3] = t[0];
                         k += 1;
                         if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
@@ -1124,23 +1174,27 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
             wg_sync();
         }
-        if (qr_row) {
-            d2 xt[PB];
 #pragma unroll
-            for (int c = 0; c < PB; ++c) {
-                d2 acc = (d2){0.0, 0.0};
+        for (int rr = 0; rr < ROWS; ++rr) {
+            if (qr_row[rr]) {
+                const int i_row = row_of(rr);
+                d2 xt[PB];
 #pragma unroll
-                for (int c2 = 0; c2 <= c; ++c2) cfma(acc, xr[c2], sT[c2 * PB + c]);
-                xt[c] = acc;
-            }
+                for (int c = 0; c < PB; ++c) {
+                    d2 acc = (d2){0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < PB; ++c) {
-                d2 acc = (d2){0.0, 0.0};
+                    for (int c2 = 0; c2 <= c; ++c2) cfma(acc, xr[rr][c2], sT[c2 * PB + c]);
+                    xt[c] = acc;
+                }
 #pragma unroll
-                for (int c2 = 0; c2 < PB; ++c2) cfma(acc, vr[c2], sS[c2 * PB + c]);
-                const d2 w = (d2){xt[c][0] - 0.5 * acc[0], xt[c][1] - 0.5 * acc[1]};
-                VW[vw_index(i_row, c)] = vr[c];
-                VW[vw_index(i_row, PB + c)] = w;
+                for (int c = 0; c < PB; ++c) {
+                    d2 acc = (d2){0.0, 0.0};
+#pragma unroll
+                    for (int c2 = 0; c2 < PB; ++c2) cfma(acc, vr[rr][c2], sS[c2 * PB + c]);
+                    const d2 w = (d2){xt[c][0] - 0.5 * acc[0], xt[c][1] - 0.5 * acc[1]};
+                    VW[vw_index(i_row, c)] = vr[rr][c];
+                    VW[vw_index(i_row, PB + c)] = w;
+                }
             }
         }
         have_update = true;
@@ -1156,7 +1210,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // fused: this workgroup goes straight on to the second stage of its matrix, in the same LDS -- on a CU the
         // other workgroup is then in some phase of ITS matrix, and the matrix-pipe, memory and vector-issue phases of
         // the two overlap (two chase workgroups side by side are both limited by instruction issue)
-        chase4_body<NW, true>(nullptr, H, br_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
+        chase4_body<NW, true, NT * 8 + ROWS>(nullptr, H, br_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
         return;
     }
     {
@@ -1178,7 +1232,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-size_t tbk_band_scratch_per_matrix(int n) { return (size_t)((n + TS - 1) / TS) * 256 * sizeof(d2); }
+// per matrix: the pending [V | W] rows in fragment order (16 complex per row) + the next panel's V (8 complex per row; used
+// when it does not live in LDS)
+size_t tbk_band_scratch_per_matrix(int n) { return (size_t)((n + TS - 1) / TS) * (256 + TS * PB) * sizeof(d2); }
 
 static int chase_pitch(int n) {
     int np = n + PB;
@@ -1215,10 +1271,15 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_EIG, s);
     const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
-    static const int big_from = getenv("TBK_BAND_NT512_FROM") ? atoi(getenv("TBK_BAND_NT512_FROM")) : 257;  // measurements only
-    const bool small = n <= 256 && n < big_from;
-    const int nw = small ? 4 : 8;
-    size_t lds = (size_t)npad * PB * 16 * 2 + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+    // variant: up to 256 orbitals 256 threads, a row per thread, V and X in LDS (two workgroups per CU); above, 256 threads
+    // with TWO rows per thread and V in global memory, so that two workgroups still fit a CU (76 KiB each at 512 orbitals)
+    // -- with 512 threads / V in LDS only one did and nothing overlapped its serial phases.  TBK_BAND_NT512_FROM = n
+    // selects the 512-thread variant from n orbitals on (measurements only).
+    static const int big_from = getenv("TBK_BAND_NT512_FROM") ? atoi(getenv("TBK_BAND_NT512_FROM")) : 1 << 30;
+    const int variant = n >= big_from ? 1 : (n <= 256 ? 0 : 2);
+    const int nw = variant == 1 ? 8 : 4;
+    const bool vn_lds = variant != 2;
+    size_t lds = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
     // d_de_fused: the workgroup runs the second stage too (same LDS) and writes (d, e) itself; d_band is not used
     const int np = chase_pitch(n);
     double* d_D = d_de_fused;
@@ -1227,16 +1288,22 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
         lds = std::max(lds, (size_t)16 * np * 16 + (size_t)nw * 64 * 16 + (size_t)n * sizeof(int) + 16);
         d_band = nullptr;
     }
-    static bool raised_a[TBK_MAX_DEVICES] = {}, raised_b[TBK_MAX_DEVICES] = {};
-    if (small) {
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<256>), 160 * 1024, raised_a));
-        hipLaunchKernelGGL(band_reduce_kernel<256>, dim3((unsigned)nk), dim3(256), lds, s, d_H, n, static_cast<d2*>(d_vw),
-                           static_cast<d2*>(d_band), np, 2, d_D, d_E);
-    } else {
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<512>), 160 * 1024, raised_b));
-        hipLaunchKernelGGL(band_reduce_kernel<512>, dim3((unsigned)nk), dim3(512), lds, s, d_H, n, static_cast<d2*>(d_vw),
-                           static_cast<d2*>(d_band), np, 2, d_D, d_E);
-    }
+    d2* d_VW = static_cast<d2*>(d_vw);
+    d2* d_VN = d_VW + (size_t)nk * nbk * 256;
+    static bool raised[3][TBK_MAX_DEVICES] = {};
+#define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
+    do {                                                                                                                        \
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NTV, ROWSV, VNL>), 160 * 1024, raised[SLOT])); \
+        hipLaunchKernelGGL((band_reduce_kernel<NTV, ROWSV, VNL>), dim3((unsigned)nk), dim3(NTV), lds, s, d_H, n, d_VW, d_VN,      \
+                           static_cast<d2*>(d_band), np, 2, d_D, d_E);                                                          \
+    } while (0)
+    if (variant == 0)
+        TBK_REDUCE(256, 1, true, 0);
+    else if (variant == 1)
+        TBK_REDUCE(512, 1, true, 1);
+    else
+        TBK_REDUCE(256, 2, false, 2);
+#undef TBK_REDUCE
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
@@ -1265,7 +1332,7 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
             static bool raised4[3][TBK_MAX_DEVICES] = {};
 #define TBK_CHASE4(NWV, SLOT)                                                                                             \
     do {                                                                                                                  \
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4_kernel<NWV>), (int)lds4, raised4[SLOT]));   \
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4_kernel<NWV>), 160 * 1024, raised4[SLOT]));   \
         hipLaunchKernelGGL(band_chase4_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds4, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
     } while (0)
             if (nw4 <= 2)
@@ -1282,7 +1349,7 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
         static bool raised[3][TBK_MAX_DEVICES] = {};
 #define TBK_CHASE(NWV, SLOT)                                                                                              \
     do {                                                                                                                  \
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<NWV>), (int)lds, raised[SLOT]));      \
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<NWV>), 160 * 1024, raised[SLOT]));      \
         hipLaunchKernelGGL(band_chase_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
     } while (0)
         if (nw <= 4)
