@@ -71,6 +71,33 @@ __device__ __forceinline__ void wg_sync() {
 
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
+// 1 / x and (sqrt(x), 1 / sqrt(x)) from the hardware estimates plus Newton steps: the reflector scalars sit on the serial
+// path of every Householder step (the owner wave computes them while the other three wait), and IEEE division / sqrt
+// cost a dozen instructions more per call.  x > 0 and well inside the double range (squared norms).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& root, double& rroot) {
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    root = fma(d, h, g);
+    rroot = 2.0 * h;
+    e = fma(-root, rroot, 1.0);
+    rroot = fma(rroot, e, rroot);
+}
+
+
 // one wave writes and reads an LDS array: its LDS operations execute in order, the fence keeps the compiler from
 // moving them across each other
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -149,11 +176,13 @@ herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, doub
         const double sigma = seg_sum<NRP>(below ? (xr * xr + xi * xi) : 0.0);
         // zlarfg: tau = 0 (H = I) when the column is already reduced and its pivot real
         const bool done = (sigma == 0.0) && (ali == 0.0);
-        const double beta = done ? alr : -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
-        const double rbeta = done ? 0.0 : 1.0 / beta;
+        double root, rroot;
+        fast_sqrt_rsqrt(done ? 1.0 : alr * alr + ali * ali + sigma, root, rroot);
+        const double beta = done ? alr : -copysign(root, alr);
+        const double rbeta = done ? 0.0 : -copysign(rroot, alr);
         const double tr = (beta - alr) * rbeta, ti = -ali * rbeta;
         const double qr = alr - beta, qi = ali;
-        const double qn = done ? 0.0 : 1.0 / (qr * qr + qi * qi);
+        const double qn = done ? 0.0 : fast_rcp(qr * qr + qi * qi);
         const double scr = qr * qn, sci = -qi * qn;
         if (live && row == 0) Em[j] = beta;
 
@@ -334,10 +363,12 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             sc.flag = (d2){1.0, 0.0};
             e_out = alr;
         } else {
-            const double beta = -copysign(sqrt(alr * alr + ali * ali + sigma), alr);
-            const double rbeta = 1.0 / beta;
+            double root, rroot;
+            fast_sqrt_rsqrt(alr * alr + ali * ali + sigma, root, rroot);
+            const double beta = -copysign(root, alr);
+            const double rbeta = -copysign(rroot, alr);
             const double qr = alr - beta, qi = ali;
-            const double qn = 1.0 / (qr * qr + qi * qi);
+            const double qn = fast_rcp(qr * qr + qi * qi);
             sc.scale = (d2){qr * qn, -qi * qn};
             sc.tau = (d2){(beta - alr) * rbeta, -ali * rbeta};
             sc.flag = (d2){0.0, 0.0};
