@@ -293,6 +293,12 @@ def main():
         try:
             status = lib.tbk_comm_create(device, world, rank, _lib.ptr(uid), ctypes.byref(comm))
         finally:
+            # the banner sits in the C library's stdout buffer: flush it while fd 1 still points at stderr, or it comes
+            # out at exit, behind the JSON line
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except (OSError, AttributeError):
+                pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
         all_ok = (status == 0) if group is None else group.allreduce_min(1.0 if status == 0 else 0.0) == 1.0
