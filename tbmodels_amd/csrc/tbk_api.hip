@@ -340,7 +340,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1]};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1], &m->ws_H2};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);
     delete m;
@@ -546,6 +546,16 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));
     double* d_H = m->ws_H.as<double>();
+    // Folded H(k) (a mesh: ~30 small launches per chunk, 1.05 of the 5.5 ms a 32768-point chunk of cfg4 takes) is
+    // built BESIDE the reduction of the previous chunk, into a second H buffer; chunk c then waits for the reduction
+    // of chunk c - 2.  (Not for the direct contraction, which fills the chip and shares the FP64 pipe: see above.)
+    const bool h_overlap = builder != nullptr && tbk_eig_small_supported(m->n_orb) && n_chunks > 2 &&
+                           (getenv("TBK_H_OVERLAP") == nullptr || atoi(getenv("TBK_H_OVERLAP")) != 0);
+    double* d_Hbuf[2] = {d_H, d_H};
+    if (h_overlap) {
+        TBK_CHECK(m->ws_H2.reserve((size_t)max_chunk * nn2 * sizeof(double)));
+        d_Hbuf[1] = m->ws_H2.as<double>();
+    }
     // two-stage reduction in two launches (TBK_BAND_FUSE=0): stage two of a chunk goes to the tridiagonal stream; fused
     // (default) it is part of the reduction kernel and this flag stays off
     const bool two_stage = !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m) && n_chunks > 1 && !tbk_band_fused(m->n_orb);
@@ -569,10 +579,14 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         const int b = (int)(c & 1);
         const int64_t nkc = sched[c];
         double* d_de = debuf[b]->as<double>();
+        d_H = d_Hbuf[b];
         if (c >= 1) {
             if (!builder) TBK_CHECK(prepare_rows(c0, nkc));  // under the previous chunk's reduction
-            // H(c) overwrites the single H buffer and must not share the chip with the eigensolver
-            TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b ^ 1], 0));
+            // H(c) overwrites an H buffer; the direct contraction must not share the chip with the eigensolver either
+            if (!h_overlap)
+                TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b ^ 1], 0));
+            else if (c >= 2)
+                TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b], 0));
             if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
         }
         TBK_CHECK(build(c0, nkc, d_H));
@@ -589,6 +603,8 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
 
         if (c >= 1) {  // tridiagonal stage of the previous chunk, alongside this chunk's reduction
             TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
+            // (d, e) of the previous chunk: implied by ev_hk unless H(c) was built beside that reduction
+            if (h_overlap) TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b ^ 1], 0));
             TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
                                                  d_E + (size_t)prev_c0 * n, false, small_call,
                                                  two_stage ? m->ws_bandmat[b ^ 1].ptr : nullptr));

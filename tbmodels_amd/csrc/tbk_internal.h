@@ -182,6 +182,7 @@ struct tbk_model {
     rocblas_handle blas = nullptr;
     DevBuf ws_phase;  // [K2][nk_pad] cos/sin rows
     DevBuf ws_H;      // [chunk][n_orb][n_orb] complex
+    DevBuf ws_H2;     // second H buffer: folded H(k) of a chunk is built beside the previous chunk's reduction
     DevBuf ws_E;      // rocSOLVER: [chunk][n_orb] off-diagonal scratch; wave solver: (d, e) of buffer 0
     DevBuf ws_E2;     // wave solver: (d, e) of buffer 1
     DevBuf ws_info;   // [chunk] int
