@@ -70,6 +70,12 @@ __device__ __forceinline__ void wg_sync() {
 }
 
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
+// the same from a wave-uniform lane index: two v_readlane instead of an LDS round trip (ds_bpermute)
+__device__ __forceinline__ double bcast_uniform(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 
 // 1 / x and (sqrt(x), 1 / sqrt(x)) from the hardware estimates plus Newton steps: the reflector scalars sit on the serial
 // path of every Householder step (the owner wave computes them while the other three wait), and IEEE division / sqrt
@@ -290,7 +296,6 @@ herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, doub
 // Householder scalars of one step, computed ONCE per matrix by the wave that owns the column and passed to
 // the other three through LDS (the f64 sqrt / divisions and the norm reduction cost ~100 VALU issues).
 struct HhScalars {
-    d2 scale;  // 1 / (alpha - beta): v = x * scale below the pivot
     d2 tau;    // (beta - alpha) / beta
     d2 flag;   // [0] != 0: column already reduced (H = I), [1] unused
 };
@@ -304,13 +309,14 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     typedef double dcol __attribute__((ext_vector_type(NT)));  // register array with a (uniform) dynamic index
     // 7 KiB of LDS per matrix: four resident workgroups leave room for two 64 KiB QL workgroups on the CU
     // (the QL of the previous chunk runs beside this kernel and must fit in one round).
-    __shared__ d2 sx[NR];        // Householder column of step j: written after B2(j - 1), read after B1(j)
+    // reflector of step j in sx[j & 1]: written by the owner of column j after B2(j - 1), read by every wave between
+    // B1(j) and B1(j + 1) -- while the owner of column j + 1 may already be writing the other copy
+    __shared__ d2 sx[2][NR];
     __shared__ HhScalars ssc;    // its scalars
     __shared__ d2 sp[NW][NR];    // per-wave partial products
-    // v and w: every wave computes the same bits and stores them to the SAME slots, then reads back
-    // through its own LDS queue (ordered behind its own store) -- no barrier, one copy.  The next step's
-    // stores are behind B1 / B2, i.e. after every wave's reads of this step.
-    __shared__ d2 sv[NR];
+    // w: every wave computes the same bits and stores them to the SAME slots, then reads back through its own LDS
+    // queue (ordered behind its own store) -- no barrier, one copy.  The next step's stores are behind B1 / B2, i.e.
+    // after every wave's reads of this step.
     __shared__ d2 sw[NR];
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -341,24 +347,24 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         }
     }
 
-    // The owner of column jc publishes it (x, lane i = A[i][jc]) with the scalars of the reflector that
-    // annihilates it below the sub-diagonal, and stores d[jc], e[jc].
+    // The owner of column jc publishes the reflector that annihilates it below the sub-diagonal -- v (lane i = v[i]) and
+    // tau -- and stores d[jc], e[jc].  (It used to publish the column and the scale factor, and every wave formed v:
+    // ~15 VALU issues per wave and step that three of the four waves now skip.)
     auto publish = [&](int jc) {
         const int tsel = jc / NW;
         const double xr = ar[tsel], xi = ai[tsel];  // uniform dynamic index
-        if (lane < NR) sx[lane] = (d2){xr, xi};
         if (lane == jc) Dm[jc] = xr;
         if (jc >= n - 1) {
             if (lane == 0) Em[n - 1] = 0.0;
             return;
         }
-        const double alr = bcast(xr, jc + 1), ali = bcast(xi, jc + 1);
+        const double alr = bcast_uniform(xr, jc + 1), ali = bcast_uniform(xi, jc + 1);
         const bool below = (lane > jc + 1) && (lane < n);
         const double sigma = wave_sum(below ? (xr * xr + xi * xi) : 0.0);
         HhScalars sc;
         double e_out;
+        double vr = 0.0, vi = 0.0;
         if (sigma == 0.0 && ali == 0.0) {
-            sc.scale = (d2){0.0, 0.0};
             sc.tau = (d2){0.0, 0.0};
             sc.flag = (d2){1.0, 0.0};
             e_out = alr;
@@ -369,11 +375,18 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             const double rbeta = -copysign(rroot, alr);
             const double qr = alr - beta, qi = ali;
             const double qn = fast_rcp(qr * qr + qi * qi);
-            sc.scale = (d2){qr * qn, -qi * qn};
+            const double sr = qr * qn, si = -qi * qn;  // 1 / (alpha - beta)
             sc.tau = (d2){(beta - alr) * rbeta, -ali * rbeta};
             sc.flag = (d2){0.0, 0.0};
             e_out = beta;
+            if (below) {
+                vr = xr * sr - xi * si;
+                vi = xr * si + xi * sr;
+            } else if (lane == jc + 1) {
+                vr = 1.0;
+            }
         }
+        if (lane < NR) sx[jc & 1][lane] = (d2){vr, vi};
         if (lane == 0) {
             ssc = sc;
             Em[jc] = e_out;
@@ -382,8 +395,8 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     if (q == 0) publish(0);
 
     for (int j = 0; j < n - 1; ++j) {
-        wg_sync();  // B1: sx, ssc describe column j
-        const d2 xme = (lane < NR) ? sx[lane] : (d2){0.0, 0.0};
+        wg_sync();  // B1: sx, ssc describe the reflector of column j
+        const d2 vme = (lane < NR) ? sx[j & 1][lane] : (d2){0.0, 0.0};
         const HhScalars sc = ssc;
         const int jn = j + 1;  // next column, owned by wave jn % 4
         const bool own_next = (jn & (NW - 1)) == q;
@@ -392,17 +405,8 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             if (own_next) publish(jn);
             continue;
         }
-        const double xr = xme[0], xi = xme[1];
         const double tr = sc.tau[0], ti = sc.tau[1];
-        const bool below = (lane > j + 1) && (lane < n);
-        double vr = 0.0, vi = 0.0;
-        if (below) {
-            vr = xr * sc.scale[0] - xi * sc.scale[1];
-            vi = xr * sc.scale[1] + xi * sc.scale[0];
-        } else if (lane == j + 1) {
-            vr = 1.0;
-        }
-        if (lane < NR) sv[lane] = (d2){vr, vi};
+        const double vr = vme[0], vi = vme[1];
 
         // partial p = A v over this wave's columns.  (Retired columns carry v = w = 0, so skipping them is
         // only an optimisation: it is done per block of TB column groups so that the TB broadcast reads of v
@@ -413,7 +417,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             if (NW * (tb + TB) - 1 > j) {  // uniform: any column of this block still active
                 d2 vc[TB];
 #pragma unroll
-                for (int u = 0; u < TB; ++u) vc[u] = sv[NW * (tb + u) + q];
+                for (int u = 0; u < TB; ++u) vc[u] = sx[j & 1][NW * (tb + u) + q];
 #pragma unroll
                 for (int u = 0; u < TB; ++u) {
                     const int t = tb + u;
@@ -427,13 +431,16 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         if (lane < NR) sp[q][lane] = (d2){par[0] + par[1], pai[0] + pai[1]};
         wg_sync();  // B2: partial products of all four waves
         double pr = 0.0, pi = 0.0;
-        if (lane > j && lane < n) {
+        {  // the four reads in flight together (inside a lane predicate hipcc waited for each before the next)
+            d2 t[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t[w] = sp[w][lane < NR ? lane : NR - 1];
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                const d2 t = sp[w][lane];
-                pr += t[0];
-                pi += t[1];
+                pr += t[w][0];
+                pi += t[w][1];
             }
+            if (!(lane > j && lane < n)) pr = pi = 0.0;
         }
         // u = A v is in (pr, pi).  A is Hermitian, so rho = v^H u is real: one reduction instead of the
         // complex dot product p^H v of zhetd2 (p = tau u, p^H v = conj(tau) rho), and
@@ -451,7 +458,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
                 d2 vc[TB], wc[TB];
 #pragma unroll
                 for (int u = 0; u < TB; ++u) {
-                    vc[u] = sv[NW * (tb + u) + q];
+                    vc[u] = sx[j & 1][NW * (tb + u) + q];
                     wc[u] = sw[NW * (tb + u) + q];
                 }
 #pragma unroll
