@@ -21,6 +21,7 @@
 // Accuracy: backward stable, |dE| ~ n eps ||H||; the parity tests hold it to 1e-10 absolute.
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "tbk_internal.h"
 
@@ -103,6 +104,26 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& root, double& 
     rroot = fma(rroot, e, rroot);
 }
 
+
+// acc += x * (lane T of src in this lane's row of 16 lanes), acc -= ... : the f64 FMA takes a DPP operand with
+// row_newbcast on gfx90a and later (tools/dpp_probe.hip: right lanes, 93 % of the plain FMA rate), so a value every lane
+// needs -- v[c], w[c] of the reflector for the column c a register holds -- comes out of a REGISTER whose lane t holds
+// the value for the wave's t-th column, not out of an LDS broadcast read per column.
+template <int T>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double x) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(x), "n"(T));
+}
+template <int T>
+__device__ __forceinline__ void fnmac_bc(double& acc, double src, double x) {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(x), "n"(T));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // one wave writes and reads an LDS array: its LDS operations execute in order, the fence keeps the compiler from
 // moving them across each other
@@ -393,6 +414,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         }
     };
     if (q == 0) publish(0);
+    const int bc_slot = min(NW * (lane & 15) + q, NR - 1);  // the column whose v / w this lane holds for the broadcasts
 
     for (int j = 0; j < n - 1; ++j) {
         wg_sync();  // B1: sx, ssc describe the reflector of column j
@@ -407,27 +429,24 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         }
         const double tr = sc.tau[0], ti = sc.tau[1];
         const double vr = vme[0], vi = vme[1];
+        const d2 vb = sx[j & 1][bc_slot];
 
-        // partial p = A v over this wave's columns.  (Retired columns carry v = w = 0, so skipping them is
-        // only an optimisation: it is done per block of TB column groups so that the TB broadcast reads of v
-        // are in flight together.)
+        // partial p = A v over this wave's columns.  (Retired columns carry v = w = 0, so skipping them is only an
+        // optimisation, done per block of TB column groups.)  vb: lane t of every row of 16 lanes holds v[4 t + q].
         double par[2] = {0.0, 0.0}, pai[2] = {0.0, 0.0};
-#pragma unroll
-        for (int tb = 0; tb < NT; tb += TB) {
+        static_for<0, NT / TB>([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value * TB;
             if (NW * (tb + TB) - 1 > j) {  // uniform: any column of this block still active
-                d2 vc[TB];
-#pragma unroll
-                for (int u = 0; u < TB; ++u) vc[u] = sx[j & 1][NW * (tb + u) + q];
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    const int t = tb + u;
-                    par[t & 1] = fma(ar[t], vc[u][0], par[t & 1]);
-                    pai[t & 1] = fma(ar[t], vc[u][1], pai[t & 1]);
-                    par[t & 1] = fma(-ai[t], vc[u][1], par[t & 1]);
-                    pai[t & 1] = fma(ai[t], vc[u][0], pai[t & 1]);
-                }
+                static_for<0, TB>([&](auto uc) {
+                    constexpr int t = tb + decltype(uc)::value;
+                    double a_re = ar[t], a_im = ai[t];
+                    fmac_bc<t>(par[t & 1], vb[0], a_re);
+                    fmac_bc<t>(pai[t & 1], vb[1], a_re);
+                    fnmac_bc<t>(par[t & 1], vb[1], a_im);
+                    fmac_bc<t>(pai[t & 1], vb[0], a_im);
+                });
             }
-        }
+        });
         if (lane < NR) sp[q][lane] = (d2){par[0] + par[1], pai[0] + pai[1]};
         wg_sync();  // B2: partial products of all four waves
         double pr = 0.0, pi = 0.0;
@@ -450,34 +469,29 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         const double wr = fma(a2, vr, pr * tr - pi * ti);
         const double wi = fma(a2, vi, pr * ti + pi * tr);
         if (lane < NR) sw[lane] = (d2){wr, wi};
+        wave_lds_fence();
+        const d2 wb = sw[bc_slot];  // lane t of every row: w[4 t + q]  (this wave's own store, read back in order)
 
         // A -= v w^H + w v^H on this wave's columns
-#pragma unroll
-        for (int tb = 0; tb < NT; tb += TB) {
+        static_for<0, NT / TB>([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value * TB;
             if (NW * (tb + TB) - 1 > j) {
-                d2 vc[TB], wc[TB];
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    vc[u] = sx[j & 1][NW * (tb + u) + q];
-                    wc[u] = sw[NW * (tb + u) + q];
-                }
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    const int t = tb + u;
+                static_for<0, TB>([&](auto uc) {
+                    constexpr int t = tb + decltype(uc)::value;
                     double r = ar[t], m = ai[t];
-                    r = fma(-vr, wc[u][0], r);
-                    m = fma(-vi, wc[u][0], m);
-                    r = fma(-vi, wc[u][1], r);
-                    m = fma(vr, wc[u][1], m);
-                    r = fma(-wr, vc[u][0], r);
-                    m = fma(-wi, vc[u][0], m);
-                    r = fma(-wi, vc[u][1], r);
-                    m = fma(wr, vc[u][1], m);
+                    fnmac_bc<t>(r, wb[0], vr);
+                    fnmac_bc<t>(m, wb[0], vi);
+                    fnmac_bc<t>(r, wb[1], vi);
+                    fmac_bc<t>(m, wb[1], vr);
+                    fnmac_bc<t>(r, vb[0], wr);
+                    fnmac_bc<t>(m, vb[0], wi);
+                    fnmac_bc<t>(r, vb[1], wi);
+                    fmac_bc<t>(m, vb[1], wr);
                     ar[t] = r;
                     ai[t] = m;
-                }
+                });
             }
-        }
+        });
         if (own_next) publish(jn);
     }
 }
