@@ -587,12 +587,15 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
                 TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b ^ 1], 0));
             else if (c >= 2)
                 TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_tri[b], 0));
-            if (c >= 2) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
+            // (d, e) of chunk c - 2 must have been consumed before the reduction of chunk c overwrites them; beside
+            // the previous reduction, H(c) itself need not wait for that
+            if (c >= 2 && !h_overlap) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
         }
         TBK_CHECK(build(c0, nkc, d_H));
         TBK_HIP(hipEventRecord(m->ev_hk[b], m->stream));
 
         TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_hk[b], 0));
+        if (c >= 2 && h_overlap) TBK_HIP(hipStreamWaitEvent(m->stream_eig, m->ev_ql[b], 0));
         if (tbk_eig_small_supported(m->n_orb))
             TBK_CHECK(tbk_launch_tridiag(m, m->stream_eig, d_H, nkc, d_de));
         else if (two_stage)
