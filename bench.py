@@ -492,8 +492,11 @@ def main():
             if args.config == "cfg4":
                 # mesh planes are evaluated on the folded model (csrc/tbk_fold.hip): the contraction executes ~13x
                 # fewer flops than the direct sum these figures price
-                roofline["note"] = ("folded evaluation: the flop figures price the UNFOLDED sum; the matrix pipe "
-                                    "executes far fewer, so `frac` is not its utilisation here")
+                roofline["note"] = ("folded evaluation: the flop figures would price the UNFOLDED sum, which the matrix "
+                                    "pipe does not execute -- no fraction of peak is reported for this config; its "
+                                    "dominant kernel is the n <= 64 reduction (DESIGN.md section 5.4 / 5.6)")
+                for key in ("achieved", "frac", "frac_of_peak_measured", "hbm_frac"):
+                    roofline[key] = None
         else:
             out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not args.construct_only else n_orb * n_orb)
             b_k = out_bytes + 8 * dim

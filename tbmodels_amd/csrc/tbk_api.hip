@@ -465,11 +465,13 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
 // workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
 // tridiagonal stage on the QL stream: lane-per-matrix QL up to 64 orbitals, bisection above
-// Calls of at most max(4096, 640 n) k-points take the bisection kernel for every chunk: the lane-per-matrix QL
-// is a serial chain of ~n^2 rotations (2.7 ms at n = 64 however few matrices there are) that only pays when tens of
-// thousands of matrices share it and it can hide under the next chunk's reduction; bisection spends a wave per
-// matrix (VALU work ~ n per matrix).  Measured crossover at n = 64: ~49 000 k-points (24576: 30.4 vs 31.5 ms,
-// 32768: 39.7 vs 40.2, 49152: 59.6 vs 59.4, 65536: 78.3 vs 77.2).
+// Calls of at most max(4096, 384 n) k-points take the bisection kernel for every chunk: the lane-per-matrix QL
+// is a serial chain of ~n^2 rotations (1.6 ms at n = 64 however few matrices there are; 2.7 ms and a rule of 640 n
+// before the lanes ran free) that only pays when tens of thousands of matrices share it and it can hide under the
+// next chunk's reduction; bisection spends a wave per matrix (VALU work ~ n per matrix).  Measured crossover
+// (tools/bench_crossover.py, ms per call, QL vs bisection): n = 64, N_R = 4096: 16384 k-points 19.90 vs 19.79,
+// 24576: 29.09 vs 29.37, 32768: 38.06 vs 38.87; n = 32, N_R = 256: 12288: 1.20 vs 1.14, 16384: 1.43 vs 1.45.
+// TBK_SMALL_CALL_PER_ORBITAL overrides the factor (measurements only).
 constexpr int64_t TBK_SMALL_CALL = 4096;
 // (Up to 12 orbitals the QL chain used to be the shorter one -- 61 us at n = 8 -- until small matrices got the idle
 // lanes of their wave for multisection: 1000 silicon k-points 59 -> 20 us, so small calls bisect at every size now.)
@@ -541,7 +543,8 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const int64_t n_chunks = (int64_t)sched.size();
     const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
     // a property of the call, not of its chunking: TBK_OPT_K_CHUNK must not change the results
-    const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, 640 * (int64_t)m->n_orb);
+    static const int64_t per_orbital = getenv("TBK_SMALL_CALL_PER_ORBITAL") ? atoll(getenv("TBK_SMALL_CALL_PER_ORBITAL")) : 384;
+    const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, per_orbital * (int64_t)m->n_orb);
     TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
         TBK_CHECK(debuf[b]->reserve((size_t)max_chunk * n * 2 * sizeof(double)));

@@ -474,7 +474,7 @@ def test_eigensolver_structured_matrices(solver, n):
         scale = np.abs(ref).max() if name in ("tiny", "huge") else max(1.0, np.abs(ref).max())
         assert err <= 1e-12 * scale * n, (name, err)
         if solver == "auto" and n <= 64:
-            # two k-points take the bisection kernel; a batch past max(4096, 640 n) takes the QL pipeline (several
+            # two k-points take the bisection kernel; a batch past max(4096, 384 n) takes the QL pipeline (several
             # chunks, last one bisection): both must agree with LAPACK on every row
             many = np.array(model.eigenval(np.zeros((640 * n + 4100, 3))))
             err = np.abs(many - ref[None]).max()
