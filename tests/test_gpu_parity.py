@@ -224,6 +224,31 @@ def test_folded_grid_matches_direct_evaluation(dim, shape, offset, order):
     assert np.array_equal(a, np.array(model.eigenval(shuffled)))
 
 
+def test_folded_mesh_over_many_chunks_is_reproducible():
+    """The folded H(k) of chunk c + 1 is built beside the reduction of chunk c (second H buffer, `h_overlap` in
+    csrc/tbk_api.hip): many small chunks of a mesh must give the one-chunk result, the same bits on every repeat (a
+    missing wait between the streams shows up as a few wrong rows now and then), and the oracle's eigenvalues."""
+    from tbmodels_amd import _lib
+
+    n_orb, n_r = 12, 300
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 53)
+    k = _grid((4, 40, 40))
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    whole = model.eigenval_array(k)
+    for chunk in (512, 1024):
+        model.set_option(_lib.TBK_OPT_K_CHUNK, chunk)
+        first = model.eigenval_array(k)
+        assert np.abs(first - whole).max() < 1e-12
+        for _ in range(6):
+            assert np.array_equal(model.eigenval_array(k), first)
+    model.set_option(_lib.TBK_OPT_FOLD, 0)
+    assert 0.0 < np.abs(model.eigenval_array(k) - first).max() < 1e-12  # the folded path really ran
+    model.set_option(_lib.TBK_OPT_FOLD, 1)
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 0)
+    idx = np.random.default_rng(3).choice(len(k), 32, replace=False)
+    _close(whole[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
+
+
 def test_device_entry_point_never_reads_k_back_and_folds_through_the_hint():
     """include/tbk.h: the device entry points enqueue and return.  ``tbk_eigenval_device`` used to copy a
     device-resident k list back (plus a stream synchronisation) to look for mesh structure, and remembered a miss by
