@@ -321,13 +321,17 @@ struct HhScalars {
     d2 flag;   // [0] != 0: column already reduced (H = I), [1] unused
 };
 
-template <int NR>
-__global__ void __launch_bounds__(256)
+template <int NR, int NW>  // padded rows, waves per matrix
+__global__ void __launch_bounds__(NW * 64, NW == 2 ? 3 : 4)
 herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
-    constexpr int NW = 4;        // waves per matrix
     constexpr int NT = NR / NW;  // columns per lane
+    constexpr int NB = (NT + 15) / 16;  // registers that hold a vector for the row_newbcast operands (16 columns each)
     constexpr int TB = 2;        // column groups per skip block
-    typedef double dcol __attribute__((ext_vector_type(NT)));  // register array with a (uniform) dynamic index
+    // register arrays with a (uniform) dynamic index (`s_set_gpr_idx`): at most 16 columns each -- hipcc indexes a longer
+    // vector through scratch memory
+    constexpr int HT = NT / NB;
+    static_assert(NT % NB == 0, "columns per lane must split evenly over the register arrays");
+    typedef double dcol __attribute__((ext_vector_type(HT)));
     // 7 KiB of LDS per matrix: four resident workgroups leave room for two 64 KiB QL workgroups on the CU
     // (the QL of the previous chunk runs beside this kernel and must fit in one round).
     // reflector of step j in sx[j & 1]: written by the owner of column j after B2(j - 1), read by every wave between
@@ -349,23 +353,33 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     // Lane i <- row i of the Hermitian matrix whose upper triangle is stored: element (i, c) comes from
     // (min, max) of the pair, conjugated below the diagonal.  Unconditional loads from clamped addresses, all
     // NT in flight (hipcc waits for a predicated load where it is issued), masked afterwards.
-    dcol ar, ai;
+    dcol ar0, ai0, ar1, ai1;  // columns t < HT, t >= HT (the second pair only with NB == 2); named, not an array:
+                              // hipcc keeps an array of vectors in scratch memory
+    static_assert(NB <= 2, "at most 32 columns per lane");
+    auto AR = [&](auto bc) -> dcol& { if constexpr (decltype(bc)::value == 0) return ar0; else return ar1; };
+    auto AI = [&](auto bc) -> dcol& { if constexpr (decltype(bc)::value == 0) return ai0; else return ai1; };
+#define TBK_AR(t) AR(std::integral_constant<int, (t) / HT>{})[(t) % HT]
+#define TBK_AI(t) AI(std::integral_constant<int, (t) / HT>{})[(t) % HT]
     {
-        d2 raw[NT];
+        constexpr int LB = NT <= 16 ? NT : NT / 2;  // loads in flight together (a second set of NT pairs would spill)
         const int li = min(lane, n - 1);
+        static_for<0, NT / LB>([&](auto t0c) {
+            constexpr int t0 = decltype(t0c)::value * LB;
+            d2 raw[LB];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = min(NW * t + q, n - 1);
-            const int lo = min(li, c), hi = max(li, c);
-            raw[t] = *reinterpret_cast<const d2*>(Hm + ((size_t)lo * n + hi) * 2);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = NW * t + q;
-            const bool inside = lane < n && c < n;
-            ar[t] = inside ? raw[t][0] : 0.0;
-            ai[t] = inside ? (c >= lane ? raw[t][1] : -raw[t][1]) : 0.0;
-        }
+            for (int u = 0; u < LB; ++u) {
+                const int c = min(NW * (t0 + u) + q, n - 1);
+                const int lo = min(li, c), hi = max(li, c);
+                raw[u] = *reinterpret_cast<const d2*>(Hm + ((size_t)lo * n + hi) * 2);
+            }
+            static_for<0, LB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int c = NW * (t0 + u) + q;
+                const bool inside = lane < n && c < n;
+                TBK_AR(t0 + u) = inside ? raw[u][0] : 0.0;
+                TBK_AI(t0 + u) = inside ? (c >= lane ? raw[u][1] : -raw[u][1]) : 0.0;
+            });
+        });
     }
 
     // The owner of column jc publishes the reflector that annihilates it below the sub-diagonal -- v (lane i = v[i]) and
@@ -373,7 +387,14 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     // ~15 VALU issues per wave and step that three of the four waves now skip.)
     auto publish = [&](int jc) {
         const int tsel = jc / NW;
-        const double xr = ar[tsel], xi = ai[tsel];  // uniform dynamic index
+        double xr, xi;  // uniform dynamic index
+        if (NB == 1 || tsel < HT) {
+            xr = ar0[tsel % HT];
+            xi = ai0[tsel % HT];
+        } else {
+            xr = ar1[tsel % HT];
+            xi = ai1[tsel % HT];
+        }
         if (lane == jc) Dm[jc] = xr;
         if (jc >= n - 1) {
             if (lane == 0) Em[n - 1] = 0.0;
@@ -414,7 +435,9 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         }
     };
     if (q == 0) publish(0);
-    const int bc_slot = min(NW * (lane & 15) + q, NR - 1);  // the column whose v / w this lane holds for the broadcasts
+    int bc_slot[NB];  // the columns whose v / w this lane holds for the broadcasts: NW * (16 b + lane % 16) + q
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bc_slot[b] = min(NW * (16 * b + (lane & 15)) + q, NR - 1);
 
     for (int j = 0; j < n - 1; ++j) {
         wg_sync();  // B1: sx, ssc describe the reflector of column j
@@ -429,7 +452,9 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         }
         const double tr = sc.tau[0], ti = sc.tau[1];
         const double vr = vme[0], vi = vme[1];
-        const d2 vb = sx[j & 1][bc_slot];
+        d2 vb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) vb[b] = sx[j & 1][bc_slot[b]];
 
         // partial p = A v over this wave's columns.  (Retired columns carry v = w = 0, so skipping them is only an
         // optimisation, done per block of TB column groups.)  vb: lane t of every row of 16 lanes holds v[4 t + q].
@@ -439,11 +464,11 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             if (NW * (tb + TB) - 1 > j) {  // uniform: any column of this block still active
                 static_for<0, TB>([&](auto uc) {
                     constexpr int t = tb + decltype(uc)::value;
-                    double a_re = ar[t], a_im = ai[t];
-                    fmac_bc<t>(par[t & 1], vb[0], a_re);
-                    fmac_bc<t>(pai[t & 1], vb[1], a_re);
-                    fnmac_bc<t>(par[t & 1], vb[1], a_im);
-                    fmac_bc<t>(pai[t & 1], vb[0], a_im);
+                    double a_re = TBK_AR(t), a_im = TBK_AI(t);
+                    fmac_bc<t & 15>(par[t & 1], vb[t >> 4][0], a_re);
+                    fmac_bc<t & 15>(pai[t & 1], vb[t >> 4][1], a_re);
+                    fnmac_bc<t & 15>(par[t & 1], vb[t >> 4][1], a_im);
+                    fmac_bc<t & 15>(pai[t & 1], vb[t >> 4][0], a_im);
                 });
             }
         });
@@ -470,7 +495,9 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
         const double wi = fma(a2, vi, pr * ti + pi * tr);
         if (lane < NR) sw[lane] = (d2){wr, wi};
         wave_lds_fence();
-        const d2 wb = sw[bc_slot];  // lane t of every row: w[4 t + q]  (this wave's own store, read back in order)
+        d2 wb[NB];  // lane t of every row: w[NW (16 b + t) + q]  (this wave's own store, read back in order)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) wb[b] = sw[bc_slot[b]];
 
         // A -= v w^H + w v^H on this wave's columns
         static_for<0, NT / TB>([&](auto tbc) {
@@ -478,22 +505,24 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             if (NW * (tb + TB) - 1 > j) {
                 static_for<0, TB>([&](auto uc) {
                     constexpr int t = tb + decltype(uc)::value;
-                    double r = ar[t], m = ai[t];
-                    fnmac_bc<t>(r, wb[0], vr);
-                    fnmac_bc<t>(m, wb[0], vi);
-                    fnmac_bc<t>(r, wb[1], vi);
-                    fmac_bc<t>(m, wb[1], vr);
-                    fnmac_bc<t>(r, vb[0], wr);
-                    fnmac_bc<t>(m, vb[0], wi);
-                    fnmac_bc<t>(r, vb[1], wi);
-                    fmac_bc<t>(m, vb[1], wr);
-                    ar[t] = r;
-                    ai[t] = m;
+                    double r = TBK_AR(t), m = TBK_AI(t);
+                    fnmac_bc<t & 15>(r, wb[t >> 4][0], vr);
+                    fnmac_bc<t & 15>(m, wb[t >> 4][0], vi);
+                    fnmac_bc<t & 15>(r, wb[t >> 4][1], vi);
+                    fmac_bc<t & 15>(m, wb[t >> 4][1], vr);
+                    fnmac_bc<t & 15>(r, vb[t >> 4][0], wr);
+                    fnmac_bc<t & 15>(m, vb[t >> 4][0], wi);
+                    fnmac_bc<t & 15>(r, vb[t >> 4][1], wi);
+                    fmac_bc<t & 15>(m, vb[t >> 4][1], wr);
+                    TBK_AR(t) = r;
+                    TBK_AI(t) = m;
                 });
             }
         });
         if (own_next) publish(jn);
     }
+#undef TBK_AR
+#undef TBK_AI
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -658,14 +687,19 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
     if (n > 32) {
         // columns per lane = padded size / 4: a 40-orbital matrix in the 64-row instantiation does 16 column
         // updates per lane and step where 10 are enough (n = 48: 8.0 -> 7.2 ms per 65536 matrices)
+        // Up to 40 orbitals TWO waves per matrix (20 columns per lane, 168 registers, three waves per SIMD): the per-step
+        // overhead -- reductions, scalar chain, barriers -- is paid by two waves instead of four, 2.05 -> 1.82 ms per
+        // 32768 matrices.  Above, the register arrays of a two-wave split do not fit three waves per SIMD (hipcc spills
+        // them: 8 - 15 ms), and at two waves per SIMD the split is no faster than four waves per matrix (4.07 vs 4.14 ms
+        // at 64 orbitals): four waves.
         if (n <= 40)
-            hipLaunchKernelGGL(herm_tridiag4_kernel<40>, grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<40, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo);
         else if (n <= 48)
-            hipLaunchKernelGGL(herm_tridiag4_kernel<48>, grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<48, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
         else if (n <= 56)
-            hipLaunchKernelGGL(herm_tridiag4_kernel<56>, grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<56, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
         else
-            hipLaunchKernelGGL(herm_tridiag4_kernel<64>, grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<64, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }

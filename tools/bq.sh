@@ -1,6 +1,4 @@
 #!/bin/bash
 cd /root/repo
-export TBK_BENCH_SKIP_PEAK=1
-for ov in 0 1; do
-  TBK_H_OVERLAP_DIRECT=$ov python bench.py --cpu-sample 0 --config cfg2 --steps 4 --warmup 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg2 overlap_direct=$ov', d['value'], d['ms_per_step'], d['roofline']['frac'], d['stage_ms_per_step'], d['max_abs_err_vs_oracle'])"
-done
+bash tools/run_small.sh "40 32768" "33 32768" "48 32768" "64 32768" 2>&1 | grep "n="
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
