@@ -4,8 +4,9 @@
 //                                 16 x 16 tiles of the stored (upper) triangle of the trailing matrix, on the matrix
 //                                 pipe (v_mfma_f64_16x16x4_f64): the rank-16 update with the previous panel's (V, W)
 //                                 and the product with the next panel's V in the same visit of a tile.
-//   stage 2  band_chase_kernel    band -> tridiagonal by Householder bulge chasing in LDS, one sweep per wave,
-//                                 sweeps pipelined three blocks apart.
+//   stage 2  chase4_body          band -> tridiagonal by Householder bulge chasing in LDS, four sweeps per wave,
+//                                 sweeps pipelined two steps apart; the tail of the stage-1 kernel up to 256
+//                                 orbitals (the band never leaves the LDS), band_chase4_kernel above.
 //
 // Reference step: scipy.linalg.eigvalsh per k-point (/root/reference/src/tbmodels/_tb_model.py:1147-1150).
 // The one-stage reduction of tbk_eig_stream.hip reads the trailing triangle once per Householder step
@@ -177,191 +178,12 @@ __device__ __forceinline__ double sum_a(double v) {
     v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
     return v;
 }
-// sum over the column index b = lane >> 3 (lanes that share a)
-__device__ __forceinline__ double sum_b(double v) {
-    v += dpp_mov<0x128>(v);  // row_ror 8: b ^ 1
-    {
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
-    }
-    {
-        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
-    }
-    return v;
-}
 __device__ __forceinline__ d2 sum_a2(d2 v) { return (d2){sum_a(v[0]), sum_a(v[1])}; }
-__device__ __forceinline__ d2 sum_b2(d2 v) { return (d2){sum_b(v[0]), sum_b(v[1])}; }
-
-__device__ __forceinline__ double shfl_d(double v, int src_lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
-    hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
-    return __hiloint2double(hi, lo);
-}
-
-// zlarfg on a vector every lane knows through (x_a, x_b): returns beta, tau and this lane's v_a, v_b
-struct Reflector {
-    d2 va, vb, tau;
-    double beta;
-};
-__device__ __forceinline__ Reflector make_reflector(d2 xa, d2 xb, int a, int b) {
-    Reflector h;
-    const double sigma = sum_a(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
-    // alpha = x[0]: lane 0 holds it as xa
-    d2 alpha;
-    alpha[0] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[0])), __builtin_amdgcn_readfirstlane(__double2loint(xa[0])));
-    alpha[1] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa[1])), __builtin_amdgcn_readfirstlane(__double2loint(xa[1])));
-    h.tau = (d2){0.0, 0.0};
-    h.beta = alpha[0];
-    h.va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
-    h.vb = (b == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
-    if (!(sigma == 0.0 && alpha[1] == 0.0)) {
-        double root, rroot;
-        fast_sqrt_rsqrt(alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma, root, rroot);
-        const double beta = -copysign(root, alpha[0]);
-        const double rbeta = -copysign(rroot, alpha[0]);
-        h.tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
-        const double qr_ = alpha[0] - beta, qi_ = alpha[1];
-        const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
-        const d2 scale = (d2){qr_ * qn, -qi_ * qn};
-        if (a != 0) h.va = cmul(xa, scale);
-        if (b != 0) h.vb = cmul(xb, scale);
-        h.beta = beta;
-    }
-    return h;
-}
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-band_chase_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
-    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
-    d2* sL = reinterpret_cast<d2*>(bc_smem);                        // [16][np]
-    int* sStart = reinterpret_cast<int*>(sL + (size_t)16 * np);     // [n] first tick of every sweep
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int a = lane & 7, b = lane >> 3;
-    const size_t mat = blockIdx.x;
-    const d2* band = band_all + mat * (size_t)n * (PB + 1);
-
-    auto L = [&](int i, int j) -> d2& { return sL[(size_t)(i - j) * np + j]; };
-
-    for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
-    __syncthreads();
-    // lower band element (j + dd, j) = conj(H[j][j + dd])
-    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
-        const int j = i / (PB + 1), dd = i % (PB + 1);
-        if (j + dd < n) {
-            const d2 v = band[i];
-            sL[(size_t)dd * np + j] = (d2){v[0], -v[1]};
-        }
-    }
-    const int n_sweeps = n - 2;
-    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };  // ticks of sweep j
-    if (tid == 0) {
-        for (int s = 0; s < n_sweeps; ++s) {
-            int t0 = 0;
-            if (s > 0) t0 = sStart[s - 1] + stagger;
-            if (s >= NW) t0 = max(t0, sStart[s - NW] + sweep_len(s - NW));
-            sStart[s] = t0;
-        }
-    }
-    wg_sync();
-    if (n_sweeps > 0) {
-        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
-        int sw = wave;  // this wave's current / next sweep
-        int k = -1;     // tick inside the sweep, -1 = waiting
-        int k_len = 0;
-        d2 va = (d2){0.0, 0.0}, vb = va, tau = va;
-        for (int tick = 0; tick < total_ticks; ++tick) {
-            if (k < 0 && sw < n_sweeps && tick == sStart[sw]) {
-                k = 0;
-                k_len = sweep_len(sw);
-                // first reflector of the sweep: column sw below the diagonal
-                const int j = sw;
-                const d2 xa = L(j + 1 + a, j), xb = L(j + 1 + b, j);
-                const Reflector h = make_reflector(xa, xb, a, b);
-                va = h.va;
-                vb = h.vb;
-                tau = h.tau;
-                lds_fence();
-                if (b == 0 && j + 1 + a < n) L(j + 1 + a, j) = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
-            }
-            if (k >= 0) {
-                const int r0 = sw + 1 + PB * k;
-                const int q0 = r0 + PB;
-                // all loads of the tick first
-                const int di = r0 + max(a, b), dj = r0 + min(a, b);
-                d2 dv = L(di, dj);
-                const d2 bk = L(q0 + a, r0 + b);
-                const d2 bk0a = L(q0 + a, r0), bk0b = L(q0 + b, r0);
-                if (a < b) dv = conjd(dv);
-                if (a == b) dv[1] = 0.0;
-                // y = D v (by rows and by columns), rho = v^H y
-                const d2 ya = sum_b2(cmul(dv, vb));
-                const d2 yb = sum_a2(cmulc(va, dv));  // conj(D[a][b]) v[a] summed over a = y[b]
-                const double rho = sum_a(va[0] * ya[0] + va[1] * ya[1]);
-                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
-                const d2 ctau = conjd(tau);
-                d2 dn = dv;
-                {
-                    const d2 t1 = cmul(ctau, cmulc(va, yb));
-                    const d2 t2 = cmul(tau, cmulc(ya, vb));
-                    const d2 t3 = cmulc(va, vb);
-                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
-                    dn[0] += -t1[0] - t2[0] + f * t3[0];
-                    dn[1] += -t1[1] - t2[1] + f * t3[1];
-                }
-                if (a >= b && di < n) L(di, dj) = dn;
-                // block below: Bk' = Bk - tau u conj(v_b), u = Bk v
-                const d2 ua = sum_b2(cmul(bk, vb));
-                const d2 tu = cmul(tau, ua);
-                d2 bn = bk;
-                cfnmac(bn, tu, vb);
-                // its first column is the next reflector's vector: x[a] = Bk[a][0] - tau u[a] (v[0] = 1 when tau != 0)
-                d2 ub;
-                ub[0] = shfl_d(ua[0], b);
-                ub[1] = shfl_d(ua[1], b);
-                const d2 tub = cmul(tau, ub);
-                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};
-                const d2 xb = (d2){bk0b[0] - tub[0], bk0b[1] - tub[1]};
-                const Reflector h = make_reflector(xa, xb, a, b);
-                // left-apply to the remaining columns: Bk'' = Bk' - conj(tau2) v2_a z_b, z = v2^H Bk'
-                const d2 zb = sum_a2(cmulc(bn, h.va));  // conj(v2_a) Bk'[a][b] summed over a
-                const d2 f2 = cmul(conjd(h.tau), zb);
-                cfma(bn, (d2){-h.va[0], -h.va[1]}, f2);
-                if (b == 0) bn = (a == 0) ? (d2){h.beta, 0.0} : (d2){0.0, 0.0};
-                if (q0 + a < n && r0 + b < n) L(q0 + a, r0 + b) = bn;
-                va = h.va;
-                vb = h.vb;
-                tau = h.tau;
-                if (++k == k_len) {
-                    k = -1;
-                    sw += NW;
-                }
-            }
-            wg_sync();
-        }
-    }
-    for (int j = tid; j < n; j += NW * 64) {
-        D[mat * n + j] = L(j, j)[0];
-        double e = 0.0;
-        if (j + 1 < n) {
-            const d2 v = L(j + 1, j);
-            e = sqrt(v[0] * v[0] + v[1] * v[1]);
-        }
-        E[mat * n + j] = e;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// stage 2, packed: FOUR sweeps per wave.  A chase step works on 8 x 8 blocks; with a whole wave per step most of the
-// ~350 instructions are cross-lane reductions and scalar work replicated 64 times.  Here a sweep gets 16 lanes -- lane
+// stage 2: FOUR sweeps per wave.  A chase step works on 8 x 8 blocks; the first version gave a whole wave to a sweep, and
+// most of its ~350 instructions per step were cross-lane reductions and scalar work replicated 64 times (2.3 us per
+// 256 x 256 matrix; removed).  Here a sweep gets 16 lanes -- lane
 // (a = l & 7, h = (l >> 3) & 1) holds row a, columns 4 h .. 4 h + 3 of a block -- so row sums are four local terms plus
 // one exchange, the vectors that are needed by column (y, x) cross over through a wave-private LDS scratch, and every
 // instruction advances four sweeps at once (~115 instructions per chase step).
@@ -1317,48 +1139,28 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
     StageTimer t(m, TBK_T_EIG, s);
     {
         const int np = chase_pitch(n);
-        const size_t lds = (size_t)16 * np * 16 + (size_t)n * sizeof(int) + 16;
         // Consecutive sweeps run `stagger` chase steps apart: 2 is the closest that keeps the steps of one tick on
         // disjoint cells (tools/two_stage_model.py: check_pipeline).  Waves per workgroup: enough sweeps in flight to
         // fill that pipeline (a sweep is ~n / 8 steps long).  TBK_CHASE_NW / TBK_CHASE_STAGGER: measurements only.
         static const int env_nw = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
         static const int env_stagger = getenv("TBK_CHASE_STAGGER") ? atoi(getenv("TBK_CHASE_STAGGER")) : 0;
         const int stagger = env_stagger >= 2 ? env_stagger : 2;
-        static const bool packed = getenv("TBK_CHASE_PACK") == nullptr || atoi(getenv("TBK_CHASE_PACK")) != 0;
-        if (packed) {
-            // four sweeps per wave: a sweep is ~n / 8 steps long and sweeps start two ticks apart
-            const int nw4 = env_nw ? env_nw : (n <= 128 ? 2 : n <= 256 ? 4 : 8);
-            const size_t lds4 = (size_t)16 * np * 16 + (size_t)nw4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
-            static bool raised4[3][TBK_MAX_DEVICES] = {};
+        // four sweeps per wave: a sweep is ~n / 8 steps long and sweeps start two ticks apart
+        const int nw4 = env_nw ? env_nw : (n <= 128 ? 2 : n <= 256 ? 4 : 8);
+        const size_t lds4 = (size_t)16 * np * 16 + (size_t)nw4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
+        static bool raised4[3][TBK_MAX_DEVICES] = {};
 #define TBK_CHASE4(NWV, SLOT)                                                                                             \
     do {                                                                                                                  \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4_kernel<NWV>), 160 * 1024, raised4[SLOT]));   \
         hipLaunchKernelGGL(band_chase4_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds4, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
     } while (0)
-            if (nw4 <= 2)
-                TBK_CHASE4(2, 0);
-            else if (nw4 <= 4)
-                TBK_CHASE4(4, 1);
-            else
-                TBK_CHASE4(8, 2);
-#undef TBK_CHASE4
-            TBK_HIP(hipGetLastError());
-            return TBK_OK;
-        }
-        int nw = env_nw ? env_nw : (n <= 128 ? 4 : n <= 256 ? 8 : 16);
-        static bool raised[3][TBK_MAX_DEVICES] = {};
-#define TBK_CHASE(NWV, SLOT)                                                                                              \
-    do {                                                                                                                  \
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase_kernel<NWV>), 160 * 1024, raised[SLOT]));      \
-        hipLaunchKernelGGL(band_chase_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
-    } while (0)
-        if (nw <= 4)
-            TBK_CHASE(4, 0);
-        else if (nw <= 8)
-            TBK_CHASE(8, 1);
+        if (nw4 <= 2)
+            TBK_CHASE4(2, 0);
+        else if (nw4 <= 4)
+            TBK_CHASE4(4, 1);
         else
-            TBK_CHASE(16, 2);
-#undef TBK_CHASE
+            TBK_CHASE4(8, 2);
+#undef TBK_CHASE4
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Repeat-run bit identity of the reduction paths (race detector): python tools/race_check.py <n> <nk> <reps>
-Environment (read once per process): TBK_BAND_FUSE, TBK_CHASE_PACK, TBK_BAND."""
+Environment (read once per process): TBK_BAND_FUSE, TBK_BAND."""
 import os
 import sys
 
@@ -28,5 +28,5 @@ for rep in range(reps):
             i = bad[0]
             print("rep %d: %d matrices differ; first %d, max |dd| %.2e |de| %.2e" % (
                 rep, len(bad), i, np.abs(d[i] - first[0][i]).max(), np.abs(e[i] - first[1][i]).max()))
-print("n=%d nk=%d reps=%d env FUSE=%s PACK=%s: %d differing matrices" % (
-    n, nk, reps, os.environ.get("TBK_BAND_FUSE"), os.environ.get("TBK_CHASE_PACK"), bad_total))
+print("n=%d nk=%d reps=%d env FUSE=%s BAND=%s: %d differing matrices" % (
+    n, nk, reps, os.environ.get("TBK_BAND_FUSE"), os.environ.get("TBK_BAND"), bad_total))
