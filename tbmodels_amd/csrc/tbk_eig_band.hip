@@ -430,8 +430,8 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 
 // NT threads per workgroup, ROWS rows of the matrix per thread in the thread-per-row phases (n <= NT * ROWS), VN_LDS: the
 // next panel's V in LDS beside X (up to 256 orbitals) or in global memory (above: X alone is 64 KiB at 512 orbitals, and
-// with V beside it only ONE workgroup fits a CU -- nothing then overlaps its serial phases; the 8-wave / one-row variant
-// <512, 1, true> is kept for comparison, TBK_BAND_NT512_FROM).
+// with V beside it only ONE workgroup fits a CU -- nothing then overlaps its serial phases: the 8-wave / one-row
+// instantiation <512, 1, true> measured 31.7 us per 512 x 512 matrix against 29.7 and is no longer built).
 template <int NT, int ROWS, bool VN_LDS>
 __global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all, int np,
@@ -1093,14 +1093,11 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_EIG, s);
     const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
-    // variant: up to 256 orbitals 256 threads, a row per thread, V and X in LDS (two workgroups per CU); above, 256 threads
-    // with TWO rows per thread and V in global memory, so that two workgroups still fit a CU (76 KiB each at 512 orbitals)
-    // -- with 512 threads / V in LDS only one did and nothing overlapped its serial phases.  TBK_BAND_NT512_FROM = n
-    // selects the 512-thread variant from n orbitals on (measurements only).
-    static const int big_from = getenv("TBK_BAND_NT512_FROM") ? atoi(getenv("TBK_BAND_NT512_FROM")) : 1 << 30;
-    const int variant = n >= big_from ? 1 : (n <= 256 ? 0 : 2);
-    const int nw = variant == 1 ? 8 : 4;
-    const bool vn_lds = variant != 2;
+    // up to 256 orbitals a row per thread, V and X in LDS; above, TWO rows per thread and V in global memory, so that two
+    // workgroups still fit a CU (76 KiB each at 512 orbitals) -- with 512 threads / V in LDS only one did and nothing
+    // overlapped its serial phases (31.7 instead of 29.7 us per 512 x 512 matrix; that instantiation is gone)
+    const bool vn_lds = n <= 256;
+    constexpr int nw = 4;
     size_t lds = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
     // d_de_fused: the workgroup runs the second stage too (same LDS) and writes (d, e) itself; d_band is not used
     const int np = chase_pitch(n);
@@ -1112,19 +1109,17 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
-    static bool raised[3][TBK_MAX_DEVICES] = {};
+    static bool raised[2][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
     do {                                                                                                                        \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NTV, ROWSV, VNL>), 160 * 1024, raised[SLOT])); \
         hipLaunchKernelGGL((band_reduce_kernel<NTV, ROWSV, VNL>), dim3((unsigned)nk), dim3(NTV), lds, s, d_H, n, d_VW, d_VN,      \
                            static_cast<d2*>(d_band), np, 2, d_D, d_E);                                                          \
     } while (0)
-    if (variant == 0)
+    if (vn_lds)
         TBK_REDUCE(256, 1, true, 0);
-    else if (variant == 1)
-        TBK_REDUCE(512, 1, true, 1);
     else
-        TBK_REDUCE(256, 2, false, 2);
+        TBK_REDUCE(256, 2, false, 1);
 #undef TBK_REDUCE
     TBK_HIP(hipGetLastError());
     return TBK_OK;
