@@ -506,6 +506,24 @@ def test_eigensolver_structured_matrices(solver, n):
             assert err <= 1e-12 * scale * n, (name, "large batch", err)
 
 
+@pytest.mark.parametrize("n_orb", [20, 33, 40, 48, 64])
+def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
+    """One call past max(4096, 384 n) k-points takes the lane-per-matrix QL (64 DIFFERENT matrices per wave, every lane
+    with its own deflation state); the same k-points in calls of 4096 take the bisection kernel.  Every row must agree
+    (two independent tridiagonal eigensolvers behind the same reduction), a sample must match the oracle."""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 8, syn.MODEL_SEED + 300 + n_orb)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    nk = 384 * n_orb + 5003
+    k = syn.random_kpoints(nk, seed=77 + n_orb)
+    big = model.eigenval_array(k)
+    small = np.concatenate([model.eigenval_array(k[i:i + 4096]) for i in range(0, nk, 4096)])
+    assert big.shape == small.shape == (nk, n_orb)
+    assert np.abs(big - small).max() < 1e-12
+    assert np.all(np.diff(big, axis=1) >= 0)
+    idx = np.random.default_rng(5).choice(nk, 48, replace=False)
+    _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
+
+
 @pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512])
 def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     """``tbk_tridiagonal_reduce``: the reduction stage of the eigensolver alone (scipy's eigvalsh at _tb_model.py:1149 is
