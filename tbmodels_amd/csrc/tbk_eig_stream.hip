@@ -462,8 +462,9 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     // 16 n bytes of LDS (dynamic): at n = 64 a block must fit beside the 64 KiB QL blocks of the previous chunk
     extern __shared__ __attribute__((aligned(16))) double bs_smem[];
     const int n_pad = (n + 63) & ~63;
-    double* sd = bs_smem;
-    double* se2 = bs_smem + n_pad;  // se2[i] = e_i^2 couples i and i+1
+    // (d_i, e_{i-1}^2) side by side -- e_{i-1}^2 couples i - 1 and i: one 16-byte broadcast read per Sturm step (two
+    // 8-byte reads per step made the LDS pipe, not the vector unit, the bound once a step was down to 5 VALU issues)
+    double* sde = bs_smem;
     __shared__ double sred[2][16];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -508,8 +509,9 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const int sc_exp = (scale_raw > 0.0) ? -ilogb(scale_raw) : 0;
     if (tid < n) {
         const double es = ldexp(e, sc_exp);
-        sd[tid] = ldexp(d, sc_exp);
-        se2[tid] = fmax(es * es, 1e-60);
+        sde[2 * tid] = ldexp(d, sc_exp);
+        if (tid + 1 < n) sde[2 * (tid + 1) + 1] = fmax(es * es, 1e-60);
+        if (tid == 0) sde[1] = 0.0;
     }
     __syncthreads();
     gl = ldexp(gl, sc_exp);
@@ -530,7 +532,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     // (block-diagonal matrices with a spectrum symmetric about 0: tools/fuzz_parity.py) is redone with the rule in
     // every step; the other lanes get the same count from either form.
     auto sturm_count = [&](double x) -> int {
-        double pp = 1.0, p = sd[0] - x;
+        double pp = 1.0, p = sde[0] - x;
         int sgn = (p <= 0.0) ? 1 : 0;  // p_1 against p_0 = 1 > 0
         int cnt = sgn;
         auto step = [&](double d_i, double e2_prev) {
@@ -557,8 +559,9 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
             double dv[8], ev[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                dv[t] = sd[i0 + t];
-                ev[t] = se2[i0 + t - 1];
+                const d2 de = *reinterpret_cast<const d2*>(sde + 2 * (i0 + t));
+                dv[t] = de[0];
+                ev[t] = de[1];
             }
             const double p_in = p, pp_in = pp;
             unsigned hist = (unsigned)sgn;
@@ -582,7 +585,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
             }
             rescale();
         }
-        for (; i0 < n; ++i0) step(sd[i0], se2[i0 - 1]);  // ragged tail (< 8 steps)
+        for (; i0 < n; ++i0) step(sde[2 * i0], sde[2 * i0 + 1]);  // ragged tail (< 8 steps)
         return cnt;
     };
 
@@ -591,7 +594,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     if (LPE == 1 && n > 64) {
         // First round shared by the whole matrix: the n lanes count at n evenly spaced points of the Gershgorin
         // interval, and every lane reads ITS bracket off the (monotone) counts -- log2(n + 1) halvings for one sweep.
-        int* scnt = reinterpret_cast<int*>(se2 + n_pad);
+        int* scnt = reinterpret_cast<int*>(sde + 2 * n_pad);
         const double width = hi - lo;
         const double step_w = width / (n + 1);
         if (tid < n) scnt[tid] = sturm_count(lo + (tid + 1) * step_w);
