@@ -802,11 +802,16 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 lds_fence();
                 __syncthreads();
                 TBK_CLK(14);  // QR: barrier
-                auto total = [&](int k) {  // (summed where it is used: sixteen totals held at once spilled at 8 waves)
-                    double acc = 0.0;
+                // lane k < 16 of every wave adds the waves' partials of sum k (one read per wave of partials, different
+                // addresses), and a total reaches the other lanes as a scalar (`v_readlane`): with every thread adding
+                // all sixteen totals itself a step was 32 broadcast reads per wave on the LDS pipe two workgroups share
+                double mine = 0.0;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) acc += part[w * 64 + k];
-                    return acc;
+                for (int w = 0; w < NW; ++w) mine += part[w * 64 + (lane & 15)];
+                auto total = [&](int k) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(mine), k);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), k);
+                    return __hiloint2double(hi, lo);
                 };
                 const double gcc = total(0);
                 const d2 alpha = row_buf[c];
