@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "tbk_dpp.h"
 #include "tbk_internal.h"
 
 namespace {
@@ -73,6 +74,18 @@ __device__ __forceinline__ void cfnmac(d2& acc, d2 a, d2 b) {
     acc[1] = fma(-a[1], b[0], acc[1]);
     acc[0] = fma(-a[1], b[1], acc[0]);
     acc[1] = fma(a[0], b[1], acc[1]);
+}
+
+// acc -= a conj(b) with a = the value lane T of `a_bc` holds in this lane's row of 16 lanes (tbk_dpp.h); the same four
+// FMAs in the same order as cfnmac
+template <int T>
+__device__ __forceinline__ void cfnmac_bc(d2& acc, d2 a_bc, d2 b) {
+    double re = acc[0], im = acc[1];
+    fnmac_bc<T>(re, a_bc[0], b[0]);
+    fnmac_bc<T>(im, a_bc[1], b[0]);
+    fnmac_bc<T>(re, a_bc[1], b[1]);
+    fmac_bc<T>(im, a_bc[0], b[1]);
+    acc = (d2){re, im};
 }
 
 template <int CTRL>
@@ -452,7 +465,6 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     // [8][16] the pending [V | W] rows of the look-ahead: only alive between two barriers before the panel's first
     // reduction, so it shares the partial-sum area (2 KiB: with it apart, two workgroups of the 256-orbital kernel
     // left no room on a CU for a bisection workgroup of the previous chunk)
-    d2* sG = reinterpret_cast<d2*>(sPart);
     d2* sS = sRow + 16;                                    // [64]  S = T^H M T
     d2* sT = sS + 64;                                      // [8][8] T of the current panel
     d2* sTau = sT + 64;                                    // [8]
@@ -709,8 +721,13 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         if (m < 2) break;
         TBK_CLK(6);
         // ---- look-ahead: block row p (8 rows, columns >= 8 p) brought up to date with the pending (V, W) ----
-        if (have_update && tid < 128) sG[tid] = VW[vw_index(g0 + (tid >> 4), tid & 15)];
+        // the 8 pending rows [V | W][g0 + r][0 .. 15]: lane t of every row of 16 lanes holds entry t, and the FMAs below
+        // take it from there (row_newbcast) -- through LDS they were 128 broadcast reads per thread and panel, and two
+        // more workgroup barriers (the staging area is the partial-sum area of the reductions)
         wg_sync();
+        d2 pend[PB];
+#pragma unroll
+        for (int r = 0; r < PB; ++r) pend[r] = have_update ? VW[vw_index(min(g0 + r, n - 1), lane & 15)] : (d2){0.0, 0.0};
         d2 x[ROWS][PB];
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -728,30 +745,29 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         x[rr][r] = upper ? v : conjd(v);
                     }
                 }
-                if (have_update) {
-                    d2 vw[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) vw[c] = VW[vw_index(i_row, c)];
-#pragma unroll
-                    for (int r = 0; r < PB; ++r) {
-#pragma unroll
-                        for (int t = 0; t < PB; ++t) {
-                            cfnmac(x[rr][r], sG[r * 16 + t], vw[PB + t]);      // - V[g][t] conj(W[i][t])
-                            cfnmac(x[rr][r], sG[r * 16 + PB + t], vw[t]);      // - W[g][t] conj(V[i][t])
-                        }
-                    }
-                }
-                // the diagonal block is final
-                if (i_row < s) {
-#pragma unroll
-                    for (int r = 0; r < PB; ++r)
-                        if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[rr][r];
-                }
             }
-        }
-        if (have_update) {  // the pending rows (sG) share their LDS with the partial sums of the reductions below
-            lds_fence();
-            __syncthreads();
+            // (every lane of the wave takes part: a row_newbcast operand is read from lane t whatever this lane's row is,
+            // and a lane that is switched off supplies nothing; waves without a row of the panel's range skip the lot)
+            if (have_update && __any(in_rows)) {
+                d2 vw[16];
+                const int i_clamped = min(max(i_row, g0), n - 1);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) vw[c] = VW[vw_index(i_clamped, c)];
+                static_for<0, PB>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    static_for<0, PB>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        cfnmac_bc<t>(x[rr][r], pend[r], vw[PB + t]);       // - V[g][t] conj(W[i][t])
+                        cfnmac_bc<PB + t>(x[rr][r], pend[r], vw[t]);       // - W[g][t] conj(V[i][t])
+                    });
+                });
+            }
+            // the diagonal block is final
+            if (in_rows && i_row < s) {
+#pragma unroll
+                for (int r = 0; r < PB; ++r)
+                    if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[rr][r];
+            }
         }
         TBK_CLK(0);
         // ---- Householder QR of the panel on rows i >= s: y = conj(x) (model: panel_qr) ----

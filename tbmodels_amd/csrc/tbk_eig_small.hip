@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "tbk_dpp.h"
 #include "tbk_internal.h"
 
 namespace {
@@ -104,26 +105,6 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& root, double& 
     rroot = fma(rroot, e, rroot);
 }
 
-
-// acc += x * (lane T of src in this lane's row of 16 lanes), acc -= ... : the f64 FMA takes a DPP operand with
-// row_newbcast on gfx90a and later (tools/dpp_probe.hip: right lanes, 93 % of the plain FMA rate), so a value every lane
-// needs -- v[c], w[c] of the reflector for the column c a register holds -- comes out of a REGISTER whose lane t holds
-// the value for the wave's t-th column, not out of an LDS broadcast read per column.
-template <int T>
-__device__ __forceinline__ void fmac_bc(double& acc, double src, double x) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(x), "n"(T));
-}
-template <int T>
-__device__ __forceinline__ void fnmac_bc(double& acc, double src, double x) {
-    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(x), "n"(T));
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // one wave writes and reads an LDS array: its LDS operations execute in order, the fence keeps the compiler from
 // moving them across each other
