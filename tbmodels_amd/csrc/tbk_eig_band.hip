@@ -88,6 +88,17 @@ __device__ __forceinline__ void cfnmac_bc(d2& acc, d2 a_bc, d2 b) {
     acc = (d2){re, im};
 }
 
+// acc += a b with b = the value lane T of `b_bc` holds in this lane's row of 16 lanes; the products and order of cfma
+template <int T>
+__device__ __forceinline__ void cfma_bc(d2& acc, d2 a, d2 b_bc) {
+    double re = acc[0], im = acc[1];
+    fmac_bc<T>(re, b_bc[0], a[0]);
+    fmac_bc<T>(im, b_bc[1], a[0]);
+    fnmac_bc<T>(re, b_bc[1], a[1]);
+    fmac_bc<T>(im, b_bc[0], a[1]);
+    acc = (d2){re, im};
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1017,26 +1028,43 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
             wg_sync();
         }
+        {
+            // T and S (8 x 8 each): entry 16 k + t in lane t of register k of every row of 16 lanes, and the FMAs take
+            // them from there (row_newbcast: every lane of a wave takes part; xr, vr are zero outside the trailing rows)
+            // -- 100 LDS broadcast reads per thread before
+            d2 tb[4], sb[4];
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            if (qr_row[rr]) {
+            for (int k = 0; k < 4; ++k) {
+                tb[k] = sT[16 * k + (lane & 15)];
+                sb[k] = sS[16 * k + (lane & 15)];
+            }
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                if (!__any(qr_row[rr])) continue;  // wave-uniform
                 const int i_row = row_of(rr);
-                d2 xt[PB];
-#pragma unroll
-                for (int c = 0; c < PB; ++c) {
+                d2 xt[PB], vs[PB];
+                static_for<0, PB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
                     d2 acc = (d2){0.0, 0.0};
-#pragma unroll
-                    for (int c2 = 0; c2 <= c; ++c2) cfma(acc, xr[rr][c2], sT[c2 * PB + c]);
+                    static_for<0, c + 1>([&](auto c2c) {
+                        constexpr int c2 = decltype(c2c)::value;
+                        cfma_bc<8 * (c2 & 1) + c>(acc, xr[rr][c2], tb[c2 >> 1]);  // T[c2][c]
+                    });
                     xt[c] = acc;
-                }
+                    d2 acc2 = (d2){0.0, 0.0};
+                    static_for<0, PB>([&](auto c2c) {
+                        constexpr int c2 = decltype(c2c)::value;
+                        cfma_bc<8 * (c2 & 1) + c>(acc2, vr[rr][c2], sb[c2 >> 1]);  // S[c2][c]
+                    });
+                    vs[c] = acc2;
+                });
+                if (qr_row[rr]) {
 #pragma unroll
-                for (int c = 0; c < PB; ++c) {
-                    d2 acc = (d2){0.0, 0.0};
-#pragma unroll
-                    for (int c2 = 0; c2 < PB; ++c2) cfma(acc, vr[rr][c2], sS[c2 * PB + c]);
-                    const d2 w = (d2){xt[c][0] - 0.5 * acc[0], xt[c][1] - 0.5 * acc[1]};
-                    VW[vw_index(i_row, c)] = vr[rr][c];
-                    VW[vw_index(i_row, PB + c)] = w;
+                    for (int c = 0; c < PB; ++c) {
+                        const d2 w = (d2){xt[c][0] - 0.5 * vs[c][0], xt[c][1] - 0.5 * vs[c][1]};
+                        VW[vw_index(i_row, c)] = vr[rr][c];
+                        VW[vw_index(i_row, PB + c)] = w;
+                    }
                 }
             }
         }
