@@ -924,22 +924,26 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             wg_finish<NW>(56, sPart, sTot, tid);
             // lane a of the first wave builds row a of T: T[a][c] = -tau_c sum_{c2 = a}^{c - 1} T[a][c2] G[c2][c]
             if (tid < PB) {
+                // (the three other waves wait for these eight lanes: all Gram sums and tau first, in flight together, then
+                // the recurrence on registers, then the row -- read where they are used, between the stores of T, every
+                // one of the 64 reads was a round trip on the chain)
                 const int a = tid;
-                d2 trow[PB];
+                d2 gm[28], tauv[PB], trow[PB];
+#pragma unroll
+                for (int k = 0; k < 28; ++k) gm[k] = *reinterpret_cast<const d2*>(sTot + 2 * k);
+#pragma unroll
+                for (int c = 0; c < PB; ++c) tauv[c] = sTau[c];
 #pragma unroll
                 for (int c = 0; c < PB; ++c) {
                     d2 acc = (d2){0.0, 0.0};
 #pragma unroll
-                    for (int c2 = 0; c2 < c; ++c2) {
-                        const int slot = 2 * (c * (c - 1) / 2 + c2);
-                        const d2 g = (d2){sTot[slot], sTot[slot + 1]};
-                        if (c2 >= a) cfma(acc, trow[c2], g);
-                    }
-                    const d2 tau_c = sTau[c];
-                    const d2 t = cmul(tau_c, acc);
-                    trow[c] = (c == a) ? tau_c : (c > a ? (d2){-t[0], -t[1]} : (d2){0.0, 0.0});
-                    sT[a * PB + c] = trow[c];
+                    for (int c2 = 0; c2 < c; ++c2)
+                        if (c2 >= a) cfma(acc, trow[c2], gm[c * (c - 1) / 2 + c2]);
+                    const d2 t = cmul(tauv[c], acc);
+                    trow[c] = (c == a) ? tauv[c] : (c > a ? (d2){-t[0], -t[1]} : (d2){0.0, 0.0});
                 }
+#pragma unroll
+                for (int c = 0; c < PB; ++c) sT[a * PB + c] = trow[c];
             }
         }
         TBK_CLK(2);
