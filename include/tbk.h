@@ -61,7 +61,7 @@ typedef enum tbk_status {
  *   ROCSOLVER rocsolver_zheevd_strided_batched
  *   AUTO      WAVE when n_orb <= 64; the streaming Householder kernel up to n_orb = 512; ROCSOLVER above.
  * Tridiagonal stage of the two hand-written paths: lane-per-matrix QL for large batches of n_orb <= 64,
- * bisection on Sturm counts otherwise (n_orb > 64, calls of <= max(4096, 384 n_orb) k-points, and the last
+ * bisection on Sturm counts otherwise (n_orb > 64, calls of <= max(4096, 768 n_orb) k-points, and the last
  * chunk of a call).  Both are backward stable; they agree to rounding, so eigenvalues are reproducible run to
  * run but depend on the batch size at the 1e-13 level. */
 enum { TBK_EIG_AUTO = 0, TBK_EIG_WAVE = 1, TBK_EIG_ROCSOLVER = 2 };

@@ -465,13 +465,14 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
 // VALU-bound with 14 KiB of LDS per workgroup, the QL is a latency-bound serial chain with 64 KiB per
 // workgroup and almost no issue pressure -- so QL(c-1) runs in the shadow of tridiag(c).
 // tridiagonal stage on the QL stream: lane-per-matrix QL up to 64 orbitals, bisection above
-// Calls of at most max(4096, 384 n) k-points take the bisection kernel for every chunk: the lane-per-matrix QL
-// is a serial chain of ~n^2 rotations (1.6 ms at n = 64 however few matrices there are; 2.7 ms and a rule of 640 n
-// before the lanes ran free) that only pays when tens of thousands of matrices share it and it can hide under the
-// next chunk's reduction; bisection spends a wave per matrix (VALU work ~ n per matrix).  Measured crossover
-// (tools/bench_crossover.py, ms per call, QL vs bisection): n = 64, N_R = 4096: 16384 k-points 19.90 vs 19.79,
-// 24576: 29.09 vs 29.37, 32768: 38.06 vs 38.87; n = 32, N_R = 256: 12288: 1.20 vs 1.14, 16384: 1.43 vs 1.45.
-// TBK_SMALL_CALL_PER_ORBITAL overrides the factor (measurements only).
+// Calls of at most max(4096, 768 n) k-points take the bisection kernel for every chunk: the lane-per-matrix QL
+// is a serial chain of ~n^2 rotations (1.6 ms at n = 64 however few matrices there are) that only pays when tens of
+// thousands of matrices share it and it can hide under the next chunk's reduction; bisection spends a wave per
+// matrix (VALU work ~ n per matrix) and got ~1.7x faster with the secant steps of tbk_eig_stream.hip.  Measured
+// crossover (tools/bench_crossover.py, ms per call, QL vs bisection): n = 64, N_R = 4096: 49152 k-points 57.29 vs
+// 56.84, 57344: 66.71 vs 66.82, 100000: 114.4 vs 115.5; n = 48, N_R = 512: 30000: 5.94 vs 5.79, 40000: 7.55 vs 7.81;
+// n = 32, N_R = 256: 16384: 1.45 vs 1.42, 24576: 1.84 vs 1.87.  (The rule was 640 n in round 1 and 384 n between the
+// free-running QL and the faster bisection.)  TBK_SMALL_CALL_PER_ORBITAL overrides the factor (measurements only).
 constexpr int64_t TBK_SMALL_CALL = 4096;
 // (Up to 12 orbitals the QL chain used to be the shorter one -- 61 us at n = 8 -- until small matrices got the idle
 // lanes of their wave for multisection: 1000 silicon k-points 59 -> 20 us, so small calls bisect at every size now.)
@@ -543,7 +544,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const int64_t n_chunks = (int64_t)sched.size();
     const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
     // a property of the call, not of its chunking: TBK_OPT_K_CHUNK must not change the results
-    static const int64_t per_orbital = getenv("TBK_SMALL_CALL_PER_ORBITAL") ? atoll(getenv("TBK_SMALL_CALL_PER_ORBITAL")) : 384;
+    static const int64_t per_orbital = getenv("TBK_SMALL_CALL_PER_ORBITAL") ? atoll(getenv("TBK_SMALL_CALL_PER_ORBITAL")) : 768;
     const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, per_orbital * (int64_t)m->n_orb);
     TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)

@@ -499,21 +499,21 @@ def test_eigensolver_structured_matrices(solver, n):
         scale = np.abs(ref).max() if name in ("tiny", "huge") else max(1.0, np.abs(ref).max())
         assert err <= 1e-12 * scale * n, (name, err)
         if solver == "auto" and n <= 64:
-            # two k-points take the bisection kernel; a batch past max(4096, 384 n) takes the QL pipeline (several
+            # two k-points take the bisection kernel; a batch past max(4096, 768 n) takes the QL pipeline (several
             # chunks, last one bisection): both must agree with LAPACK on every row
-            many = np.array(model.eigenval(np.zeros((640 * n + 4100, 3))))
+            many = np.array(model.eigenval(np.zeros((768 * n + 4100, 3))))
             err = np.abs(many - ref[None]).max()
             assert err <= 1e-12 * scale * n, (name, "large batch", err)
 
 
 @pytest.mark.parametrize("n_orb", [20, 33, 40, 48, 64])
 def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
-    """One call past max(4096, 384 n) k-points takes the lane-per-matrix QL (64 DIFFERENT matrices per wave, every lane
+    """One call past max(4096, 768 n) k-points takes the lane-per-matrix QL (64 DIFFERENT matrices per wave, every lane
     with its own deflation state); the same k-points in calls of 4096 take the bisection kernel.  Every row must agree
     (two independent tridiagonal eigensolvers behind the same reduction), a sample must match the oracle."""
     r_vec, hop, pos = syn.dense_model_arrays(n_orb, 8, syn.MODEL_SEED + 300 + n_orb)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
-    nk = 384 * n_orb + 5003
+    nk = 768 * n_orb + 5003
     k = syn.random_kpoints(nk, seed=77 + n_orb)
     big = model.eigenval_array(k)
     small = np.concatenate([model.eigenval_array(k[i:i + 4096]) for i in range(0, nk, 4096)])

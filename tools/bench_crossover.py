@@ -13,7 +13,7 @@ n, n_r = int(sys.argv[1]), int(sys.argv[2])
 r_vec, hop, pos = syn.dense_model_arrays(n, n_r, syn.MODEL_SEED + 2)
 model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
 model.pin_staging()
-for nk in (6144, 8192, 12288, 16384, 24576, 32768, 40960, 49152):
+for nk in [int(x) for x in sys.argv[3:]] or (6144, 8192, 12288, 16384, 24576, 32768, 40960, 49152):
     k = syn.random_kpoints(nk)
     model.eigenval_array(k)
     t0 = time.perf_counter()
