@@ -953,12 +953,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             const int i_row = row_of(rr);
             if (i_row < npad) {
 #pragma unroll
-                for (int c = 0; c < PB; ++c) {
-                    sVn[(size_t)i_row * PB + c] = vn[rr][c];
-                    sX[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
-                }
+                for (int c = 0; c < PB; ++c) sVn[(size_t)i_row * PB + c] = vn[rr][c];
             }
         }
+        // (X is cleared in linear order: a thread clearing its own row of 128 bytes shares its banks with every second
+        // lane -- the V stores above pay that, the rows being the threads' own)
+        for (int i = tid; i < npad * PB; i += NT) sX[i] = (d2){0.0, 0.0};
         if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
         wg_sync();
         TBK_CLK(3);
