@@ -507,6 +507,24 @@ def main():
                 "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
             }
 
+        # the reduction to tridiagonal form (the dominant kernel of the configs above 64 orbitals): (16/3) n^3 flops per
+        # matrix (eigensolve, values only) over the HIP-event time of the reduction stage on its own stream
+        eig_roofline = None
+        if not args.construct_only and stage_ms.get("eig", 0.0) > 0.0:
+            eig_flops = 16.0 / 3.0 * n_orb ** 3
+            eig_s = stage_ms["eig"] * 1e-3
+            eig_tf = eig_flops * nk_gpu * args.steps / eig_s / 1e12
+            eig_roofline = {
+                "kernel": ("herm_tridiag4_kernel / herm_tridiag_packed_kernel" if n_orb <= 64 else
+                           "herm_tridiag_stream_kernel" if n_orb <= 128 else
+                           "band_reduce_kernel (+ chase)" if n_orb <= 512 else "rocsolver zheevd"),
+                "bound": "valu-f64" if n_orb <= 128 else "mfma",
+                "flops_per_matrix": eig_flops, "achieved": round(eig_tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(eig_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                "stage_ms_per_step": round(stage_ms["eig"] / args.steps, 3),
+                "note": "stage time on the reduction's stream; other stages run beside it on other streams",
+            }
+
         sample = args.cpu_sample
         if sample < 0:
             # ~10-15 s of single-core work each (17-19 ms per k-point at the headline shape)
@@ -552,6 +570,7 @@ def main():
                 "eigensolver": args.eigensolver,
             },
             "roofline": roofline,
+            "eig_roofline": eig_roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "host_api": host_api,
