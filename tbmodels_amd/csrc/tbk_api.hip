@@ -702,9 +702,24 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
     // (13 instead of 313 lattice vectors at the headline shape); all lines of the piece go through ONE launch with
     // per-line operands and shared phase rows (tbk_launch_hk_dense_lines).  Ragged ends of the piece, and anything
     // that does not have this structure, take piece_plane.
-    auto piece = [&](int64_t lo, int64_t hi, double* d_Hp) -> int {
-        const int dim1 = dim - 1;
-        if (dim1 < 2 || hi - lo < 512) return piece_plane(lo, hi, d_Hp);
+    struct LineInfo {
+        bool ok = false;     // the piece has a body of whole mesh lines
+        int e2 = -1;         // reduced component shared along a line
+        int64_t L = 0;       // points per line
+        int64_t body = 0;    // first point of the body
+        int64_t n_lines = 0;
+    };
+    const int dim1 = dim - 1;
+    const int line_cap = 512;  // lines per batch (operands: cap x k2'' x row)
+    auto same_line = [&](int64_t a0, int64_t b0, int64_t L, int e2) {  // equal remaining coordinates along two lines
+        for (int64_t t = 0; t < L; ++t)
+            for (int e = 0; e < dim1; ++e)
+                if (e != e2 && h_k[(a0 + t) * dim + reduced[e]] != h_k[(b0 + t) * dim + reduced[e]]) return false;
+        return true;
+    };
+    auto analyse = [&](int64_t lo, int64_t hi) -> LineInfo {
+        LineInfo li;
+        if (dim1 < 2 || hi - lo < 512) return li;
         // the reduced component with the longest sub-runs
         int e2 = -1;
         int64_t best_changes = hi - lo;
@@ -716,69 +731,140 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
                 e2 = e;
             }
         }
-        if (e2 < 0 || best_changes < 4) return piece_plane(lo, hi, d_Hp);
+        if (e2 < 0 || best_changes < 4) return li;
         const int c2 = reduced[e2];
         std::vector<int64_t> sb(1, lo);  // sub-run starts
         for (int64_t i = lo + 1; i < hi; ++i)
             if (h_k[i * dim + c2] != h_k[(i - 1) * dim + c2]) sb.push_back(i);
         sb.push_back(hi);
         const size_t n_sub = sb.size() - 1;
-        if (n_sub < 6) return piece_plane(lo, hi, d_Hp);
+        if (n_sub < 6) return li;
         const int64_t L = sb[2] - sb[1];  // an interior line
-        if (L < 8 || L > TBK_BM) return piece_plane(lo, hi, d_Hp);
-        auto same_line = [&](int64_t a0, int64_t b0) {  // equal remaining coordinates along two lines of length L
-            for (int64_t t = 0; t < L; ++t)
-                for (int e = 0; e < dim1; ++e)
-                    if (e != e2 && h_k[(a0 + t) * dim + reduced[e]] != h_k[(b0 + t) * dim + reduced[e]]) return false;
-            return true;
-        };
+        if (L < 8 || L > TBK_BM) return li;
         // body: the longest prefix of interior sub-runs (from the second one) that are lines like the first of them
-        size_t first = (sb[1] - sb[0] == L && same_line(sb[0], sb[1])) ? 0 : 1, last = first;
-        while (last < n_sub && sb[last + 1] - sb[last] == L && same_line(sb[first], sb[last])) ++last;
-        const int64_t n_lines = (int64_t)(last - first);
-        if (n_lines < 4) return piece_plane(lo, hi, d_Hp);
+        size_t first = (sb[1] - sb[0] == L && same_line(sb[0], sb[1], L, e2)) ? 0 : 1, last = first;
+        while (last < n_sub && sb[last + 1] - sb[last] == L && same_line(sb[first], sb[last], L, e2)) ++last;
+        li.n_lines = (int64_t)(last - first);
+        if (li.n_lines < 4) return li;
+        li.ok = true;
+        li.e2 = e2;
+        li.L = L;
+        li.body = sb[first];
+        return li;
+    };
+    // lines a0, a0 + L, ... (n of them) of the CURRENT first-level model -> slots slot0 ... of the second-level plan
+    auto fold_body = [&](tbk_fold_plan_t& plan2, const LineInfo& li, int64_t a0, int64_t n, int slot0) -> int {
+        return tbk_fold_lines(m, plan2, d_k2 + a0 * dim1 + li.e2, li.L * dim1, (int)n, slot0);
+    };
+    // one launch for n lines whose operands are in slots 0 .. n - 1 (shared phase rows: the lines have equal coordinates)
+    auto contract_lines = [&](tbk_fold_plan_t& plan2, const LineInfo& li, int64_t a0, int64_t n, double* d_Hp) -> int {
+        const int64_t row_len = (int64_t)m->ncol_pad * 2;
+        tbk_fold_saved_t saved2;
+        TBK_CHECK(tbk_fold_enter(m, plan2, 0, saved2));
+        int rc = m->ws_kline.reserve((size_t)li.L * std::max(dim1 - 1, 1) * sizeof(double));
+        if (rc == TBK_OK) rc = tbk_fold_drop_component(m, d_k2 + a0 * dim1, dim1, li.e2, li.L, m->ws_kline.as<double>());
+        if (rc == TBK_OK) rc = m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * TBK_BM * sizeof(double));
+        if (rc == TBK_OK) rc = fill_rows(m, m->ws_kline.as<double>(), li.L, TBK_BM, m->ws_phase.as<double>());
+        if (rc == TBK_OK)
+            rc = tbk_launch_hk_dense_lines(m, m->ws_phase.as<double>(), n, (int)li.L, plan2.k2 * row_len, d_Hp);
+        tbk_fold_leave(m, saved2);
+        return rc;
+    };
+
+    // Second level (meshes): inside a plane the k-points come in LINES -- equal-length sub-runs of one more shared
+    // component whose remaining coordinates repeat from line to line.  Every line is a (dim - 2)-dimensional model
+    // (13 instead of 313 lattice vectors at the headline shape); all lines of the piece go through ONE launch with
+    // per-line operands and shared phase rows (tbk_launch_hk_dense_lines).  Ragged ends of the piece, and anything
+    // that does not have this structure, take piece_plane.
+    auto piece = [&](int64_t lo, int64_t hi, double* d_Hp) -> int {
+        const LineInfo li = analyse(lo, hi);
+        if (!li.ok) return piece_plane(lo, hi, d_Hp);
         tbk_fold_plan_t* plan2 = nullptr;
-        const int cap = 256;  // lines per batch (operands: cap x k2'' x row)
-        TBK_CHECK(tbk_fold_subplan(m, plan1, e2, cap, &plan2));
+        TBK_CHECK(tbk_fold_subplan(m, plan1, li.e2, line_cap, &plan2));
         if (!plan2 || plan2->n_rho * 3 > plan1.n_rho) return piece_plane(lo, hi, d_Hp);
 
-        if (sb[first] > lo) TBK_CHECK(piece_plane(lo, sb[first], d_Hp));  // ragged head
-        const int64_t row_len = (int64_t)m->ncol_pad * 2;
-        for (int64_t l0 = 0; l0 < n_lines; l0 += cap) {
-            const int64_t nl = std::min<int64_t>(cap, n_lines - l0);
-            const int64_t a0 = sb[first] + l0 * L;
+        if (li.body > lo) TBK_CHECK(piece_plane(lo, li.body, d_Hp));  // ragged head
+        for (int64_t l0 = 0; l0 < li.n_lines; l0 += line_cap) {
+            const int64_t nl = std::min<int64_t>(line_cap, li.n_lines - l0);
+            const int64_t a0 = li.body + l0 * li.L;
             // (the lines' shared-component values are read on the device: first point of every line)
-            TBK_CHECK(tbk_fold_lines(m, *plan2, d_k2 + a0 * dim1 + e2, L * dim1, (int)nl));
-            tbk_fold_saved_t saved2;
-            TBK_CHECK(tbk_fold_enter(m, *plan2, 0, saved2));
-            int rc = m->ws_kline.reserve((size_t)L * std::max(dim1 - 1, 1) * sizeof(double));
-            if (rc == TBK_OK) rc = tbk_fold_drop_component(m, d_k2 + a0 * dim1, dim1, e2, L, m->ws_kline.as<double>());
-            if (rc == TBK_OK) rc = m->ws_phase.reserve((size_t)std::max<int64_t>(m->k2, 1) * TBK_BM * sizeof(double));
-            if (rc == TBK_OK) rc = fill_rows(m, m->ws_kline.as<double>(), L, TBK_BM, m->ws_phase.as<double>());
-            if (rc == TBK_OK)
-                rc = tbk_launch_hk_dense_lines(m, m->ws_phase.as<double>(), nl, (int)L, plan2->k2 * row_len,
-                                               d_Hp + (size_t)(a0 - lo) * nn2);
-            tbk_fold_leave(m, saved2);
-            TBK_CHECK(rc);
+            TBK_CHECK(fold_body(*plan2, li, a0, nl, 0));
+            TBK_CHECK(contract_lines(*plan2, li, a0, nl, d_Hp + (size_t)(a0 - lo) * nn2));
         }
-        const int64_t body_end = sb[first] + n_lines * L;
+        const int64_t body_end = li.body + li.n_lines * li.L;
         if (body_end < hi) TBK_CHECK(piece_plane(body_end, hi, d_Hp + (size_t)(body_end - lo) * nn2));  // ragged tail
         return TBK_OK;
     };
 
+    // first-level model of run r in place (its group folded if it is not in the plan's buffer)
+    auto enter_run = [&](size_t r, tbk_fold_saved_t& saved) -> int {
+        if (group_lo < 0 || (int64_t)r < group_lo || (int64_t)r >= group_lo + group) {
+            group_lo = (int64_t)r;
+            const int n_g = (int)std::min<int64_t>(group, n_runs - group_lo);
+            double kf[64];
+            for (int g = 0; g < n_g; ++g) kf[g] = h_k[runs[(size_t)(group_lo + g)] * dim + f];
+            TBK_CHECK(tbk_fold_group(m, plan1, kf, n_g, 0));
+        }
+        return tbk_fold_enter(m, plan1, (int)((int64_t)r - group_lo), saved);
+    };
+    // A chunk of WHOLE runs that are nothing but equal mesh lines (the planes of a mesh: run_schedule cuts chunks at
+    // run boundaries): the lines of all its planes are folded plane by plane into consecutive slots -- light launches
+    // that get through beside the previous chunk's reduction -- and contracted by ONE launch, instead of one contraction
+    // (which cannot start before the reduction has left the chip) and four light launches behind it per plane.
+    auto batched = [&](int64_t c0, int64_t nkc, double* d_H, bool* done) -> int {
+        *done = false;
+        const size_t r0 = (size_t)(std::upper_bound(runs.begin(), runs.end(), c0) - runs.begin()) - 1;
+        if (runs[r0] != c0) return TBK_OK;
+        size_t r1 = r0;
+        while (r1 + 1 < runs.size() && runs[r1 + 1] <= c0 + nkc) ++r1;
+        if (r1 - r0 < 2 || runs[r1] != c0 + nkc) return TBK_OK;  // fewer than two whole runs, or a cut run
+        const LineInfo li0 = analyse(runs[r0], runs[r0 + 1]);
+        if (!li0.ok || li0.body != runs[r0] || li0.body + li0.n_lines * li0.L != runs[r0 + 1]) return TBK_OK;
+        int64_t total = li0.n_lines;
+        for (size_t r = r0 + 1; r < r1; ++r) {
+            const LineInfo li = analyse(runs[r], runs[r + 1]);
+            if (!li.ok || li.e2 != li0.e2 || li.L != li0.L || li.body != runs[r] ||
+                li.body + li.n_lines * li.L != runs[r + 1] || !same_line(runs[r0], runs[r], li0.L, li0.e2))
+                return TBK_OK;
+            total += li.n_lines;
+        }
+        if (total > line_cap) return TBK_OK;
+        tbk_fold_plan_t* plan2 = nullptr;
+        TBK_CHECK(tbk_fold_subplan(m, plan1, li0.e2, line_cap, &plan2));
+        if (!plan2 || plan2->n_rho * 3 > plan1.n_rho) return TBK_OK;
+        int slot = 0;
+        for (size_t r = r0; r < r1; ++r) {
+            tbk_fold_saved_t saved;
+            TBK_CHECK(enter_run(r, saved));
+            const int64_t n = (runs[r + 1] - runs[r]) / li0.L;
+            const int rc = fold_body(*plan2, li0, runs[r], n, slot);
+            tbk_fold_leave(m, saved);
+            TBK_CHECK(rc);
+            slot += (int)n;
+        }
+        {
+            // the second-level plan sits on top of a first-level model: any run of the chunk will do for the shapes
+            tbk_fold_saved_t saved;
+            TBK_CHECK(enter_run(r0, saved));
+            const int rc = contract_lines(*plan2, li0, c0, total, d_H);
+            tbk_fold_leave(m, saved);
+            TBK_CHECK(rc);
+        }
+        *done = true;
+        return TBK_OK;
+    };
+
     const HBuilder folded = [&](int64_t c0, int64_t nkc, double* d_H) -> int {
+        {
+            bool done = false;
+            TBK_CHECK(batched(c0, nkc, d_H, &done));
+            if (done) return TBK_OK;
+        }
         size_t r = (size_t)(std::upper_bound(runs.begin(), runs.end(), c0) - runs.begin()) - 1;
         for (int64_t lo = c0; lo < c0 + nkc; ++r) {
             const int64_t hi = std::min(runs[r + 1], c0 + nkc);
-            if (group_lo < 0 || (int64_t)r < group_lo || (int64_t)r >= group_lo + group) {
-                group_lo = (int64_t)r;
-                const int n_g = (int)std::min<int64_t>(group, n_runs - group_lo);
-                double kf[64];
-                for (int g = 0; g < n_g; ++g) kf[g] = h_k[runs[(size_t)(group_lo + g)] * dim + f];
-                TBK_CHECK(tbk_fold_group(m, plan1, kf, n_g, 0));
-            }
             tbk_fold_saved_t saved;
-            TBK_CHECK(tbk_fold_enter(m, plan1, (int)((int64_t)r - group_lo), saved));
+            TBK_CHECK(enter_run(r, saved));
             const int rc = piece(lo, hi, d_H + (size_t)(lo - c0) * nn2);
             tbk_fold_leave(m, saved);
             TBK_CHECK(rc);

@@ -299,9 +299,9 @@ int tbk_fold_group(tbk_model* m, tbk_fold_plan_t& plan, const double* h_kf, int 
     return TBK_OK;
 }
 
-// All n_lines (<= plan.capacity) lines of a mesh plane piece in one go: their shared-component values are read on
-// the device (d_kf[line * stride]); slots 0 .. n_lines - 1.
-int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int64_t stride, int n_lines) {
+// All n_lines lines of a mesh plane piece in one go: their shared-component values are read on the device
+// (d_kf[line * stride]); slots slot0 .. slot0 + n_lines - 1 of the plan's buffer (slot0 + n_lines <= plan.capacity).
+int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int64_t stride, int n_lines, int slot0) {
     const int64_t row_len = (int64_t)m->ncol_pad * 2;
     StageTimer t(m, TBK_T_PHASE);
     if ((size_t)plan.table_entries < (size_t)plan.n_r * n_lines) {
@@ -316,7 +316,7 @@ int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int6
     TBK_HIP(hipGetLastError());
     dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)plan.n_rho_pad, (unsigned)((n_lines + FOLD_GROUP - 1) / FOLD_GROUP));
     hipLaunchKernelGGL(fold_rows_group_kernel, grid, dim3(256), 0, m->stream, m->d_B, row_len, plan.d_lptr, plan.d_lrec,
-                       plan.d_table, n_lines, plan.k2 * row_len, plan.d_B2);
+                       plan.d_table, n_lines, plan.k2 * row_len, plan.d_B2 + (size_t)slot0 * plan.k2 * row_len);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

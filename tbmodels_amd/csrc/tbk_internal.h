@@ -281,7 +281,7 @@ int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, d
 int tbk_fold_choose(tbk_model* m, const double* h_k, int64_t nk, std::vector<int64_t>& run_starts);
 int tbk_fold_group_size();
 int tbk_fold_group(tbk_model* m, tbk_fold_plan_t& plan, const double* h_kf, int n_g, int slot0);
-int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int64_t stride, int n_lines);
+int tbk_fold_lines(tbk_model* m, tbk_fold_plan_t& plan, const double* d_kf, int64_t stride, int n_lines, int slot0 = 0);
 int tbk_fold_enter(tbk_model* m, tbk_fold_plan_t& plan, int slot, tbk_fold_saved_t& saved);
 void tbk_fold_leave(tbk_model* m, const tbk_fold_saved_t& saved);
 int tbk_fold_drop_component(tbk_model* m, const double* d_k, int dim, int f, int64_t nk, double* d_k2);
