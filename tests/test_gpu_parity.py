@@ -249,6 +249,34 @@ def test_folded_mesh_over_many_chunks_is_reproducible():
     _close(whole[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
+def test_chunks_of_whole_mesh_planes_take_one_contraction():
+    """Chunks that consist of whole mesh planes (here two planes of 40 lines per chunk: TBK_OPT_K_CHUNK = 3200) fold the
+    lines of all their planes into consecutive operand slots and contract them in ONE launch (`batched` in
+    csrc/tbk_api.hip): same eigenvalues as the direct path, as plane-by-plane chunks, and the same bits on every repeat."""
+    from tbmodels_amd import _lib
+
+    n_orb, n_r = 12, 300
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 54)
+    k = _grid((6, 40, 40), (0.1, 0.0, 0.3))
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 1600)  # one plane per chunk: the per-plane path
+    per_plane = model.eigenval_array(k)
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 3200)  # two whole planes per chunk: batched
+    first = model.eigenval_array(k)
+    assert np.abs(first - per_plane).max() < 1e-12
+    for _ in range(5):
+        assert np.array_equal(model.eigenval_array(k), first)
+    # a slab that starts and ends inside planes: ragged chunks fall back to the per-piece path
+    lo, hi = 700, len(k) - 900
+    assert np.abs(model.eigenval_array(k[lo:hi]) - first[lo:hi]).max() < 1e-12
+    model.set_option(_lib.TBK_OPT_FOLD, 0)
+    assert 0.0 < np.abs(model.eigenval_array(k) - first).max() < 1e-12
+    model.set_option(_lib.TBK_OPT_FOLD, 1)
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 0)
+    idx = np.random.default_rng(4).choice(len(k), 32, replace=False)
+    _close(first[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
+
+
 def test_device_entry_point_never_reads_k_back_and_folds_through_the_hint():
     """include/tbk.h: the device entry points enqueue and return.  ``tbk_eigenval_device`` used to copy a
     device-resident k list back (plus a stream synchronisation) to look for mesh structure, and remembered a miss by
