@@ -843,9 +843,10 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
             slot += (int)n;
         }
         {
-            // the second-level plan sits on top of a first-level model: any run of the chunk will do for the shapes
+            // the second-level plan sits on top of a first-level model: any run of the chunk will do for the shapes (the
+            // last one is in the buffer whatever groups the chunk straddles)
             tbk_fold_saved_t saved;
-            TBK_CHECK(enter_run(r0, saved));
+            TBK_CHECK(enter_run(r1 - 1, saved));
             const int rc = contract_lines(*plan2, li0, c0, total, d_H);
             tbk_fold_leave(m, saved);
             TBK_CHECK(rc);
