@@ -201,15 +201,178 @@ def cpu_baseline_all_cores(arrays, kpts, per_proc):
     }
 
 
+def launch_ranks(n_ranks):
+    """
+    ``bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON line.
+
+    This process has made no GPU call yet and never makes one (importing tbmodels_amd._lib does not load libtbk): the
+    ranks are new interpreters, never a re-exec of a process that touched the GPU.  They get what a launcher would
+    set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) plus the rendezvous directory and run token of
+    ``tbmodels_amd.rendezvous``.  The first rank that fails ends the run: the others are stopped (by pid) and the exit
+    status is non-zero.  Returns the exit status.
+    """
+    import shutil  # pylint: disable=import-outside-toplevel
+    import socket  # pylint: disable=import-outside-toplevel
+    import subprocess  # pylint: disable=import-outside-toplevel
+    import tempfile  # pylint: disable=import-outside-toplevel
+    import uuid  # pylint: disable=import-outside-toplevel
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    rdzv = tempfile.mkdtemp(prefix="tbk_rdzv_", dir=base)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    token = uuid.uuid4().hex[:16]
+    procs = []
+    status = 0
+    try:
+        for rank in range(n_ranks):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
+                       LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       TBK_RDZV_DIR=rdzv, TBK_RDZV_TOKEN=token, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            # rank 0 prints the one JSON line on this process' stdout; whatever else a rank prints goes to stderr
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if rank == 0 else sys.stderr))
+        alive = set(range(n_ranks))
+        while alive and status == 0:
+            for rank in sorted(alive):
+                code = procs[rank].poll()
+                if code is None:
+                    continue
+                alive.discard(rank)
+                if code != 0:
+                    status = code if code > 0 else 1
+                    sys.stderr.write("[bench] rank %d exited with status %d: stopping the other ranks\n" % (rank, code))
+                    break
+            time.sleep(0.02)
+    finally:
+        for proc in procs:  # exact pids of the children started above, nothing else
+            if proc.poll() is None:
+                proc.terminate()
+        deadline = time.monotonic() + 10.0
+        for proc in procs:
+            try:
+                proc.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                proc.wait()
+        shutil.rmtree(rdzv, ignore_errors=True)
+    return status
+
+
+def trace_identity_error(arrays, k_slab, eig_all, n_rows=4096):
+    """max | sum_i E_i(k) - tr H(k) | over rows drawn from the whole slab: tr H(k) = sum_R 2 Re(e^{2 pi i k.R} tr hop[R])
+    is host work independent of the GPU path, and rows from everywhere cover every k chunk of the pipeline."""
+    nk = len(k_slab)
+    rows = np.sort(np.random.default_rng(1).choice(nk, min(nk, n_rows), replace=False))
+    if arrays["kind"] == "dense":
+        traces = np.einsum("rii->r", arrays["hop"])
+    else:
+        traces = np.zeros(len(arrays["R"]), dtype=complex)
+        diag = arrays["row"] == arrays["col"]
+        np.add.at(traces, np.searchsorted(arrays["r_ptr"], np.flatnonzero(diag), side="right") - 1, arrays["val"][diag])
+    phase = np.exp(2j * np.pi * (k_slab[rows] @ arrays["R"].T.astype(float)))
+    return float(np.abs(eig_all[rows].sum(axis=1) - 2.0 * (phase @ traces).real).max())
+
+
+def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
+    """The reduction to tridiagonal form: (16/3) n^3 flops per matrix (eigensolve, values only) over the
+    HIP-event time of the reduction stage on its own stream."""
+    eig_flops = 16.0 / 3.0 * n_orb ** 3
+    eig_tf = eig_flops * matrices / (eig_ms * 1e-3) / 1e12
+    return {
+        "kernel": ("herm_tridiag4_kernel / herm_tridiag_packed_kernel" if n_orb <= 64 else
+                   "herm_tridiag_stream_kernel" if n_orb <= 128 else
+                   "band_reduce_kernel (+ chase)" if n_orb <= 512 else "rocsolver zheevd"),
+        "bound": "valu-f64" if n_orb <= 128 else "mfma",
+        "flops_per_matrix": eig_flops, "achieved": round(eig_tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(eig_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+        "stage_ms_per_step": round(eig_ms / steps, 3),
+        "note": "stage time on the reduction's stream; other stages run beside it on other streams",
+    }
+
+
+def config_kpoints(name, nk, dim):
+    if name == "cfg1":
+        return np.ascontiguousarray(synthetic.uniform_grid(10)[:nk])
+    if name == "cfg4":
+        return np.ascontiguousarray(synthetic.grid_slab(100, 0, nk))
+    return np.ascontiguousarray(np.random.default_rng(synthetic.K_SEED).random((nk, dim)))
+
+
+def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup=1):
+    """
+    One of the other BASELINE configs at its FULL size on this GPU, after the main clock and outside ``ms_per_step``:
+    `steps` timed passes of tbk_eigenval_device_hint over the config's k list (resident in HBM), the stage times, the
+    reduction's roofline entry, and the same two correctness checks as the main line (oracle sample, trace identity).
+    """
+    _, n_orb, _, nk, _ = CONFIGS[name]
+    t_build = time.perf_counter()
+    own = model is None
+    if arrays is None:
+        arrays = build_model_arrays(name)
+    if own:
+        model = stage(lib, device, arrays)
+    dim = arrays["R"].shape[1]
+    n_r = len(arrays["R"])
+    k = config_kpoints(name, nk, dim)
+    build_s = time.perf_counter() - t_build
+    d_k, d_e = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.tbk_device_malloc(device, k.nbytes, ctypes.byref(d_k)))
+    _lib.check(lib.tbk_device_malloc(device, nk * n_orb * 8, ctypes.byref(d_e)))
+    try:
+        _lib.check(lib.tbk_memcpy_h2d(device, d_k, _lib.ptr(k), k.nbytes))
+        hint = _lib.ptr(k) if name in ("cfg1", "cfg4") else None  # meshes: the host list is the structure hint
+        _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 1))
+        for _ in range(warmup):
+            _lib.check(lib.tbk_eigenval_device_hint(model, d_k, hint, nk, d_e))
+        _lib.check(lib.tbk_eigenval_check(model))
+        _lib.check(lib.tbk_get_timing(model, None, None, 1))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _lib.check(lib.tbk_eigenval_device_hint(model, d_k, hint, nk, d_e))
+        _lib.check(lib.tbk_synchronize(model))
+        elapsed = time.perf_counter() - t0
+        _lib.check(lib.tbk_eigenval_check(model))
+        ms = (ctypes.c_double * _lib.TBK_T_COUNT)()
+        launches = (ctypes.c_int64 * _lib.TBK_T_COUNT)()
+        _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
+        stage_ms = {stage_name: ms[i] for i, stage_name in enumerate(_lib.STAGE_NAMES)}
+        eig = np.empty((nk, n_orb))
+        _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig), d_e, eig.nbytes))
+    finally:
+        lib.tbk_device_free(device, d_k)
+        lib.tbk_device_free(device, d_e)
+        if own:
+            lib.tbk_model_destroy(model)
+    trace_err = trace_identity_error(arrays, k, eig)
+    sample = {"cfg1": 64, "cfg3": 4, "cfg4": 16, "cfg5": 1}.get(name, 8)
+    _, _, cpu_eig = cpu_baseline(arrays, k, sample)  # the oracle as the checker
+    parity = float(np.abs(cpu_eig - eig[:len(cpu_eig)]).max())
+    entry = {
+        "workload": "%s: %s N_orb=%d N_R=%d, %d %s k-points, eigenval (H(k)+eig), 1 GPU"
+                    % (name, arrays["kind"], n_orb, n_r, nk, "grid" if name in ("cfg1", "cfg4") else "random"),
+        "value": round(nk * steps / elapsed, 1), "unit": "k-points/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "stage_ms_per_step": {key: round(v / steps, 3) for key, v in stage_ms.items()},
+        "eig_roofline": eig_roofline_entry(n_orb, nk * steps, stage_ms["eig"], steps) if stage_ms["eig"] > 0 else None,
+        "max_abs_err_vs_oracle": parity, "oracle_sample": sample,
+        "max_trace_identity_err_4096_rows": trace_err,
+        "model_build_and_staging_s": round(build_s, 2),
+    }
+    if not (parity <= 1e-10 and trace_err <= 1e-10):
+        raise SystemExit("parity failure in %s: %r" % (name, entry))
+    return entry
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # no launcher: this process becomes one (it never touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     kind, n_orb, n_r, nk_gpu, cfg_idx = CONFIGS[args.config]
@@ -437,16 +600,7 @@ def main():
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_head), d_e, eig_head.nbytes))
         eig_all = np.empty((nk_gpu, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_all), d_e, eig_all.nbytes))
-        rows = np.sort(np.random.default_rng(1).choice(nk_gpu, min(nk_gpu, 4096), replace=False))
-        if arrays["kind"] == "dense":
-            traces = np.einsum("rii->r", arrays["hop"])
-        else:
-            traces = np.zeros(n_r, dtype=complex)
-            diag = arrays["row"] == arrays["col"]
-            np.add.at(traces, np.searchsorted(arrays["r_ptr"], np.flatnonzero(diag), side="right") - 1,
-                      arrays["val"][diag])
-        phase = np.exp(2j * np.pi * (k_slab[rows] @ arrays["R"].T.astype(float)))
-        trace_err = float(np.abs(eig_all[rows].sum(axis=1) - 2.0 * (phase @ traces).real).max())
+        trace_err = trace_identity_error(arrays, k_slab, eig_all)
         del eig_all
 
     result = None
@@ -511,19 +665,7 @@ def main():
         # matrix (eigensolve, values only) over the HIP-event time of the reduction stage on its own stream
         eig_roofline = None
         if not args.construct_only and stage_ms.get("eig", 0.0) > 0.0:
-            eig_flops = 16.0 / 3.0 * n_orb ** 3
-            eig_s = stage_ms["eig"] * 1e-3
-            eig_tf = eig_flops * nk_gpu * args.steps / eig_s / 1e12
-            eig_roofline = {
-                "kernel": ("herm_tridiag4_kernel / herm_tridiag_packed_kernel" if n_orb <= 64 else
-                           "herm_tridiag_stream_kernel" if n_orb <= 128 else
-                           "band_reduce_kernel (+ chase)" if n_orb <= 512 else "rocsolver zheevd"),
-                "bound": "valu-f64" if n_orb <= 128 else "mfma",
-                "flops_per_matrix": eig_flops, "achieved": round(eig_tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(eig_tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                "stage_ms_per_step": round(stage_ms["eig"] / args.steps, 3),
-                "note": "stage time on the reduction's stream; other stages run beside it on other streams",
-            }
+            eig_roofline = eig_roofline_entry(n_orb, nk_gpu * args.steps, stage_ms["eig"], args.steps)
 
         sample = args.cpu_sample
         if sample < 0:
@@ -544,6 +686,16 @@ def main():
                           "scipy eigvalsh), one process, %.1f s" % (sample, nk_gpu, cpu_dt),
                 "host_cpus": os.cpu_count(),
             }
+        # the other BASELINE configs at full size, after the clock (not part of value / ms_per_step): the cfg2 model on
+        # the 100^3 mesh (cfg4, this GPU's share at N = 1 = the whole mesh) reuses the staged handle
+        other = None
+        if (world == 1 and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr
+                and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1"):
+            other = {}
+            _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_AUTO))
+            other["cfg4"] = run_other_config(lib, device, "cfg4", model=model, arrays=arrays)
+            for name in ("cfg1", "cfg3", "cfg5"):
+                other[name] = run_other_config(lib, device, name)
         result = {
             "metric": "k-points/sec (H(k)+eig) at N_orb=%d, N_R=%d" % (n_orb, n_r) if not args.construct_only
                       else "k-points/sec (H(k) construction only) at N_orb=%d, N_R=%d" % (n_orb, n_r),
@@ -576,6 +728,7 @@ def main():
             "host_api": host_api,
             "rccl_ranks": rccl_ranks,
             "per_rank": per_rank,
+            "configs": other,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "max_abs_err_vs_oracle": parity,
             "max_trace_identity_err_4096_rows": trace_err,

@@ -108,6 +108,18 @@ int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int convention, cons
 /* Ascending eigenvalues of H(k) (convention 2) for nk k-points. */
 int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E_out);
 
+/* ---- the hot path on several devices from ONE process (host buffers) ----------------------
+ * handles[0..n_handles) are staged copies of the SAME model, normally one per device (several on one device are
+ * allowed).  The k list is cut into contiguous slabs of ceil(nk / n_handles) rows (handle i takes slab i; the last
+ * slabs may be short or empty), every slab runs on its handle's device from its own host thread, and every device
+ * copies its result straight into its rows of the caller's array: k-points are independent (_tb_model.py:1111-1123)
+ * and the result is in caller order (:1147-1150) without any exchange.  Mesh slabs are folded like whole meshes.
+ * On failure the status and message of the first failing slab in k order are returned (a NaN k-point gives
+ * TBK_ERR_NOT_FINITE exactly once).  n_handles == 1 is tbk_eigenval / tbk_hamilton. */
+int tbk_eigenval_multi(tbk_model* const* handles, int n_handles, const double* k, int64_t nk, double* E_out);
+int tbk_hamilton_multi(tbk_model* const* handles, int n_handles, const double* k, int64_t nk, int convention,
+                       const double* pos, double* H_out);
+
 /* ---- the hot path, device buffers (bench, sharded runs, device-side consumers) ----------- */
 int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, int convention,
                         const double* d_pos, double* d_H);
@@ -170,7 +182,8 @@ void tbk_comm_destroy(tbk_comm* c);
 /* Size of the communicator and this process' rank in it, as RCCL reports them (ncclCommCount / ncclCommUserRank). */
 int tbk_comm_ranks(tbk_comm* c, int* count, int* rank);
 /* All-gather of per-rank eigenvalue slabs: every rank contributes `count` doubles from d_send and
- * receives world_size * count doubles in rank order in d_recv.  Enqueued on `m`'s stream. */
+ * receives world_size * count doubles in rank order in d_recv.  Enqueued on `m`'s stream; with m == NULL (a rank
+ * that could not stage its model still has to take part) on the communicator's own stream (tbk_comm_synchronize). */
 int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
                            int64_t count);
 /* The same gather on the communicator's own stream: it starts once the work enqueued on `m`'s stream so far

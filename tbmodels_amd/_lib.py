@@ -50,6 +50,8 @@ SIGNATURES = {
     ),
     "tbk_hamilton": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _vp]),
     "tbk_eigenval": (_c_int, [_vp, _vp, _c_i64, _vp]),
+    "tbk_eigenval_multi": (_c_int, [_vp, _c_int, _vp, _c_i64, _vp]),
+    "tbk_hamilton_multi": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int, _vp, _vp]),
     "tbk_hamilton_device": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _vp]),
     "tbk_eigenval_device": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "tbk_eigenval_device_hint": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),

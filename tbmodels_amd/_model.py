@@ -36,6 +36,14 @@ except ImportError:  # pragma: no cover
 __all__ = ("Model",)
 
 
+def _devices_from_env():
+    """``TBK_DEVICES=0,1,...`` (several GPUs behind one model), else ``TBK_DEVICE=i``, else device 0."""
+    listed = os.environ.get("TBK_DEVICES", "").strip()
+    if listed:
+        return [int(part) for part in listed.replace(";", ",").split(",") if part.strip() != ""]
+    return [int(os.environ.get("TBK_DEVICE", "0"))]
+
+
 def _first_nonzero(vec):
     for x in vec:
         if x != 0:
@@ -185,11 +193,11 @@ class Model:
         sparse=False,
     ):
         hop = {} if hop is None else hop
-        self._handle = None
+        self._handles = []
         self._staged_fingerprint = None
         self._pinned = False
         self._call_lock = threading.RLock()
-        self.device = int(os.environ.get("TBK_DEVICE", "0"))
+        self.devices = _devices_from_env()
 
         self.set_sparse(sparse)
 
@@ -504,7 +512,7 @@ class Model:
     # ------------------------------------------------------------------ pickling
     def __getstate__(self):
         state = dict(self.__dict__)
-        state["_handle"] = None
+        state["_handles"] = []
         state["_staged_fingerprint"] = None
         state.pop("_call_lock", None)
         return state
@@ -512,21 +520,58 @@ class Model:
     def __setstate__(self, state):
         # (the hop dict's exposure flag / edit counter are NOT touched here: copy.copy(model) shares the dict with
         # the original, whose handed-out references stay live; a pickled dict resets itself in _HopDict.__reduce__)
+        state = dict(state)
+        state.pop("_handle", None)  # states written before a model could sit on several devices
+        legacy_device = state.pop("device", None)
         self.__dict__.update(state)
+        self._handles = []
+        if "_devices" not in state:
+            self._devices = [int(legacy_device)] if legacy_device is not None else _devices_from_env()
         self._call_lock = threading.RLock()
 
     def __del__(self):
         self._drop_staging()
 
     # ------------------------------------------------------------------ staging
+    @property
+    def device(self):
+        """The (first) GPU this model evaluates on; assigning an index makes it the only one."""
+        return self.devices[0]
+
+    @device.setter
+    def device(self, index):
+        self.devices = [int(index)]
+
+    @property
+    def devices(self):
+        """
+        GPU indices this model is staged on.  With more than one, ``hamilton`` / ``eigenval`` cut the k list into
+        contiguous slabs, one per entry, and every device fills its rows of the result (``tbk_eigenval_multi``): the
+        same single call of a single process as in the reference (``_tb_model.py:1134-1150``), no launcher.  Default:
+        ``TBK_DEVICES=0,1,...`` (or ``TBK_DEVICE=i``, or device 0).  An index may repeat (several staged copies on one GPU).
+        """
+        return list(self._devices)
+
+    @devices.setter
+    def devices(self, indices):
+        indices = [int(i) for i in indices]
+        if not indices or any(i < 0 for i in indices):
+            raise ValueError("devices must be a non-empty list of GPU indices, got {!r}".format(indices))
+        if indices != getattr(self, "_devices", None):
+            self._drop_staging()
+        self._devices = indices
+
+    @property
+    def _handle(self):
+        return self._handles[0] if self._handles else None
+
     def _drop_staging(self):
-        handle = getattr(self, "_handle", None)
-        if handle is not None:
+        handles, self._handles = getattr(self, "_handles", []), []
+        for handle in handles:
             try:
                 _lib.lib().tbk_model_destroy(handle)
             except Exception:  # pylint: disable=broad-except  # interpreter shutdown
                 pass
-        self._handle = None
         self._staged_fingerprint = None
 
     def pin_staging(self, pinned=True):
@@ -541,12 +586,12 @@ class Model:
         no pass over the bytes), the content fingerprint afterwards."""
         hop = self.hop
         if isinstance(hop, _HopDict) and not hop.exposed:
-            return ("version", hop.version, self.device, self.size, self.dim, bool(self._sparse))
+            return ("version", hop.version, tuple(self._devices), self.size, self.dim, bool(self._sparse))
         return self._fingerprint()
 
     def _fingerprint(self):
         running = _xxhash.xxh3_64() if _xxhash is not None else 1
-        meta = [self.device, self.size, self.dim, int(self._sparse), len(self.hop)]
+        meta = [*self._devices, -1, self.size, self.dim, int(self._sparse), len(self.hop)]
         for key, mat in self._hop_items():
             meta.extend(key)
             if self._sparse:
@@ -583,35 +628,52 @@ class Model:
         return r_vec, (np.array(r_ptr, dtype=np.int64), cat(rows, np.int32), cat(cols, np.int32), cat(vals, np.complex128))
 
     def _staged(self):
-        """The ``tbk_model*`` for the current contents of ``self.hop`` (re-staged when they changed)."""
-        if self._handle is not None and self._pinned:
-            return self._handle
+        """The ``tbk_model*`` on the first device for the current contents of ``self.hop`` (re-staged when they changed)."""
+        return self._staged_all()[0]
+
+    def _staged_all(self):
+        """One ``tbk_model*`` per entry of ``self.devices`` for the current contents of ``self.hop``."""
+        if self._handles and self._pinned:
+            return self._handles
         fingerprint = self._staging_key()
-        if self._handle is not None and fingerprint == self._staged_fingerprint:
-            return self._handle
+        if self._handles and fingerprint == self._staged_fingerprint:
+            return self._handles
         self._drop_staging()
         lib = _lib.lib()
         r_vec, payload = self.packed_hop()
-        handle = ctypes.c_void_p()
-        if self._sparse:
-            r_ptr, row, col, val = payload
-            status = lib.tbk_model_create_csr(
-                self.device, self.dim, self.size, len(r_vec), _lib.ptr(r_vec), _lib.ptr(r_ptr), _lib.ptr(row),
-                _lib.ptr(col), _lib.ptr(val), ctypes.byref(handle),
-            )
-        else:
-            status = lib.tbk_model_create_dense(
-                self.device, self.dim, self.size, len(r_vec), _lib.ptr(r_vec), _lib.ptr(payload), ctypes.byref(handle)
-            )
-        _lib.check(status)
-        self._handle = handle
+        handles = []
+        try:
+            for device in self._devices:  # the hoppings are replicated: every device holds the whole model
+                handle = ctypes.c_void_p()
+                if self._sparse:
+                    r_ptr, row, col, val = payload
+                    status = lib.tbk_model_create_csr(
+                        device, self.dim, self.size, len(r_vec), _lib.ptr(r_vec), _lib.ptr(r_ptr), _lib.ptr(row),
+                        _lib.ptr(col), _lib.ptr(val), ctypes.byref(handle),
+                    )
+                else:
+                    status = lib.tbk_model_create_dense(
+                        device, self.dim, self.size, len(r_vec), _lib.ptr(r_vec), _lib.ptr(payload), ctypes.byref(handle)
+                    )
+                _lib.check(status)
+                handles.append(handle)
+        except Exception:
+            for handle in handles:
+                lib.tbk_model_destroy(handle)
+            raise
+        self._handles = handles
         self._staged_fingerprint = fingerprint
-        return handle
+        return handles
+
+    def _handle_array(self):
+        handles = self._staged_all()
+        return (ctypes.c_void_p * len(handles))(*[h.value for h in handles]), len(handles)
 
     def set_option(self, option, value):
         """Forward a ``TBK_OPT_*`` option to the staged model (see ``include/tbk.h``)."""
         with self._call_lock:
-            _lib.check(_lib.lib().tbk_model_set_option(self._staged(), option, int(value)))
+            for handle in self._staged_all():
+                _lib.check(_lib.lib().tbk_model_set_option(handle, option, int(value)))
 
     # ------------------------------------------------------------------ the hot path
     def _k_array(self, k):
@@ -647,8 +709,10 @@ class Model:
         out = _outbuf.empty((n_k, self.size, self.size), np.complex128)
         pos = np.ascontiguousarray(self.pos, dtype=np.float64) if convention == 1 else None
         with self._call_lock:  # (re)staging and the call are one step for other threads (ctypes drops the GIL)
+            handles, n_handles = self._handle_array()
             _lib.check(
-                _lib.lib().tbk_hamilton(self._staged(), _lib.ptr(k_array), n_k, int(convention), _lib.ptr(pos), _lib.ptr(out))
+                _lib.lib().tbk_hamilton_multi(handles, n_handles, _lib.ptr(k_array), n_k, int(convention), _lib.ptr(pos),
+                                              _lib.ptr(out))
             )
         return out[0] if single else out
 
@@ -673,7 +737,8 @@ class Model:
             # NaN / Inf in k or in the hoppings reach the eigenvalues; the library checks those on the device and
             # returns TBK_ERR_NOT_FINITE -> ValueError, scipy.linalg.eigvalsh(check_finite=True)'s answer to the
             # non-finite Hamiltonian (two np.isfinite passes here cost as much as the kernels for small models)
-            _lib.check(_lib.lib().tbk_eigenval(self._staged(), _lib.ptr(k_array), n_k, _lib.ptr(out)))
+            handles, n_handles = self._handle_array()
+            _lib.check(_lib.lib().tbk_eigenval_multi(handles, n_handles, _lib.ptr(k_array), n_k, _lib.ptr(out)))
         return out[0] if single else out
 
     def construct_kdotp(self, k, order):

@@ -90,14 +90,16 @@ extern "C" void tbk_comm_destroy(tbk_comm* c) {
 
 extern "C" int tbk_comm_allgather_f64(tbk_comm* c, tbk_model* m, const double* d_send, double* d_recv,
                                       int64_t count) {
-    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
+    TBK_ARG(c != nullptr, "comm is NULL");
     TBK_ARG(count >= 0, "count < 0");
     if (count == 0) return TBK_OK;
     TBK_ARG(d_send && d_recv, "send / recv is NULL");
     TBK_HIP(hipSetDevice(c->device));
-    if (m->timing) tbk_range_push("tbk:allgather_eigenvalues");
-    const ncclResult_t r = ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, m->stream);
-    if (m->timing) tbk_range_pop();
+    // m == NULL (a rank whose staging failed still has to take part): the communicator's own stream
+    const bool ranged = m != nullptr && m->timing;
+    if (ranged) tbk_range_push("tbk:allgather_eigenvalues");
+    const ncclResult_t r = ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, c->comm, m ? m->stream : c->stream);
+    if (ranged) tbk_range_pop();
     TBK_NCCL(r);
     return TBK_OK;
 }

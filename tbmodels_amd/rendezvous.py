@@ -28,12 +28,17 @@ __all__ = ("FileGroup", "TorchGroup", "group_from_env")
 def _run_token():
     """
     A string that is the same in every rank of ONE launch and differs between launches: the launcher's pid plus its
-    start time (``/proc/<ppid>/stat`` field 22, so a recycled pid does not collide).  ``TBK_RDZV_TOKEN`` overrides it
-    for ranks that do not share a parent process.
+    start time (``/proc/<ppid>/stat`` field 22, so a recycled pid does not collide) -- or, when the launcher names its
+    run (``TORCHELASTIC_RUN_ID`` other than torchrun's static default "none"), that id plus ``MASTER_PORT``.
+    ``TBK_RDZV_TOKEN`` overrides both for ranks that share neither (``bench.py --gpus N`` sets it for its ranks).
     """
     token = os.environ.get("TBK_RDZV_TOKEN")
     if token:
         return token
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    if run_id and run_id != "none" and os.environ.get("MASTER_PORT"):
+        # a launcher-wide id: also right when the ranks are started through per-rank wrapper shells (no shared parent)
+        return "%s-%s" % (run_id, os.environ["MASTER_PORT"])
     ppid = os.getppid()
     start = "0"
     try:
@@ -52,14 +57,20 @@ class FileGroup:
     earlier, crashed run -- a reused ``TBK_RDZV_DIR`` -- cannot feed this run a stale RCCL id or stale slabs.
     """
 
-    def __init__(self, rank, world, path, poll_s=2e-4, timeout_s=600.0, token=None):
+    def __init__(self, rank, world, path, poll_s=2e-4, timeout_s=600.0, token=None, first_timeout_s=None):
         self.rank = int(rank)
         self.world = int(world)
         self.path = path
         self.poll_s = poll_s
         self.timeout_s = timeout_s
+        # the FIRST exchange is where ranks with different tokens / directories never meet: fail that one fast
+        if first_timeout_s is None:
+            first_timeout_s = float(os.environ.get("TBK_RDZV_FIRST_TIMEOUT", "180"))
+        self.first_timeout_s = min(float(first_timeout_s), timeout_s)
         self.token = token or _run_token()
         self._seq = 0
+        self._met = False     # one exchange with every peer has completed
+        self._mine = []       # (sequence number, path) of the files this rank wrote and has not removed yet
         os.makedirs(path, exist_ok=True)
 
     # -- primitives ---------------------------------------------------------------------------
@@ -68,19 +79,40 @@ class FileGroup:
         tmp = os.path.join(self.path, ".%s.%d.tmp" % (name, self.rank))
         with open(tmp, "wb") as handle:
             handle.write(data)
-        os.replace(tmp, os.path.join(self.path, name))  # atomic: readers never see a partial file
+        final = os.path.join(self.path, name)
+        os.replace(tmp, final)  # atomic: readers never see a partial file
+        self._mine.append((self._seq, final))
 
     def _get(self, name):
         target = os.path.join(self.path, "%s.%s" % (self.token, name))
-        deadline = time.monotonic() + self.timeout_s
+        limit = self.timeout_s if self._met else self.first_timeout_s
+        deadline = time.monotonic() + limit
         while True:
             try:
                 with open(target, "rb") as handle:
                     return handle.read()
             except FileNotFoundError:
                 if time.monotonic() > deadline:
-                    raise TimeoutError("rendezvous: waited %.0f s for %s" % (self.timeout_s, target))
+                    raise TimeoutError(
+                        "rendezvous: rank %d of %d waited %.0f s for %s (run token %r, directory %r: every rank of a "
+                        "launch must see the same two -- set TBK_RDZV_TOKEN / TBK_RDZV_DIR when the ranks do not share "
+                        "a parent process)" % (self.rank, self.world, limit, target, self.token, self.path))
                 time.sleep(self.poll_s)
+
+    def _retire(self, before):
+        """Remove this rank's files of exchanges older than sequence number `before`.  Called after an all-gather with
+        that number completed: every rank has then written its part of it, i.e. finished reading everything earlier,
+        so the number of files (each a tmpfs page and an inode) stays bounded however long the run."""
+        keep = []
+        for seq, path in self._mine:
+            if seq < before:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+            else:
+                keep.append((seq, path))
+        self._mine = keep
 
     def _next(self, tag):
         self._seq += 1
@@ -91,7 +123,10 @@ class FileGroup:
         """Every rank contributes ``data``; returns the list of all contributions in rank order."""
         key = self._next("ag")
         self._put("%s.r%d" % (key, self.rank), bytes(data))
-        return [self._get("%s.r%d" % (key, r)) for r in range(self.world)]
+        parts = [self._get("%s.r%d" % (key, r)) for r in range(self.world)]
+        self._met = True
+        self._retire(self._seq)
+        return parts
 
     def barrier(self):
         self.all_gather_bytes(b"\x01")
@@ -181,18 +216,16 @@ class TorchGroup:
 
 def group_from_env():
     """
-    The :class:`FileGroup` of a ``torch.distributed.run`` / ``torchrun`` launch on one node: ranks from
-    RANK / WORLD_SIZE, directory keyed by MASTER_PORT and the launcher's pid (all workers share one parent).
-    ``TBK_RDZV_DIR`` overrides the directory.
+    The :class:`FileGroup` of a ``torch.distributed.run`` / ``torchrun`` / ``bench.py --gpus N`` launch on one node:
+    ranks from RANK / WORLD_SIZE, directory named after MASTER_PORT and the run token (:func:`_run_token`: the same in
+    every rank of one launch).  ``TBK_RDZV_DIR`` overrides the directory.
     """
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    token = _run_token()
     path = os.environ.get("TBK_RDZV_DIR")
     if not path:
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-        path = os.path.join(
-            base,
-            "tbk_rdzv_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"),
-                                   os.getppid()),
-        )
-    return FileGroup(rank, world, path)
+        safe = "".join(c if c.isalnum() or c in "-_" else "_" for c in token)
+        path = os.path.join(base, "tbk_rdzv_%s_%s" % (os.environ.get("MASTER_PORT", "0"), safe))
+    return FileGroup(rank, world, path, token=token)

@@ -114,7 +114,7 @@ class ShardedEigenval:
         if stop > start:
             try:
                 slab[: stop - start] = np.asarray(evaluate(k[start:stop])).reshape(stop - start, n_orb)
-            except (ValueError, np.linalg.LinAlgError) as exc:  # e.g. NaN in this rank's slab only
+            except Exception as exc:  # pylint: disable=broad-except  # e.g. NaN in this rank's slab only, out of memory, ...
                 failure = exc
         # all ranks take the same branch: the failure of one is raised on every rank, after the same collectives
         failed = self.group.allreduce_max(1.0 if failure is not None else 0.0)
@@ -147,39 +147,55 @@ class ShardedEigenval:
 
     def _device_gather_locked(self, k, start, stop, per, n_k, n_orb):
         lib = _lib.lib()
-        handle = self.model._staged()  # pylint: disable=protected-access
-        comm = self._communicator()
         dev = self.device
-        k_slab = np.ascontiguousarray(k[start:stop])
-        d_k = self._buffer("k", k_slab.nbytes)
-        d_send = self._buffer("send", per * n_orb * 8)
-        d_recv = self._buffer("recv", self.world * per * n_orb * 8)
-        # Every rank goes through the SAME sequence of collectives whatever happens locally: a rank that raised
-        # before the all-gather (or after it, on a NaN in its own slab only) would leave the others hanging in the
-        # next collective.  Local failures are carried as a status and reduced over the ranks before anyone raises.
-        status, message = 0, ""
-        if stop > start:
-            status = lib.tbk_memcpy_h2d(dev, d_k, _lib.ptr(k_slab), k_slab.nbytes)
-            if status == 0:
+        # What a rank sends: its slab's eigenvalues and ONE status word behind them.  Every rank goes through the same
+        # collectives whatever happens locally -- a rank that raised before the all-gather (or after it, on a NaN in its
+        # own slab only) would leave the others hanging in the next collective -- and the status travels IN the gather:
+        # no host-side collective on the data path (it was an allreduce through the rendezvous files per call).
+        count = per * n_orb + 1
+        comm = self._communicator()  # first call: a host broadcast of the RCCL id, taken by every rank alike
+        d_send = self._buffer("send", count * 8)
+        d_recv = self._buffer("recv", self.world * count * 8)
+        status, message, failure, handle = 0, "", None, None
+        try:  # local trouble (staging, allocation, a NaN k-point) becomes this rank's status word
+            handle = self.model._staged()  # pylint: disable=protected-access
+            if stop > start:
+                k_slab = np.ascontiguousarray(k[start:stop])
+                d_k = self._buffer("k", k_slab.nbytes)
+                _lib.check(lib.tbk_memcpy_h2d(dev, d_k, _lib.ptr(k_slab), k_slab.nbytes))
                 # the host slab goes along as the structure hint: mesh slabs are folded (include/tbk.h)
-                status = lib.tbk_eigenval_device_hint(handle, d_k, _lib.ptr(k_slab), stop - start, d_send)
-            if status != 0:
-                message = _lib.last_error()
-        gather_status = lib.tbk_comm_allgather_f64(comm, handle, d_send, d_recv, per * n_orb)
-        if gather_status != 0 and status == 0:
-            status, message = gather_status, _lib.last_error()
-        check_status = lib.tbk_eigenval_check(handle)  # synchronises; non-finite / non-converged flags of THIS rank
-        if check_status != 0 and status == 0:
-            status, message = check_status, _lib.last_error()
-        worst = int(self.group.allreduce_max(float(status)))
-        if worst != 0:
-            if status == 0:
-                status = worst
-                message = "a peer rank failed (status %d) while evaluating its k slab" % worst
-            _raise_status(status, message)
-        out = np.empty((self.world * per, n_orb), dtype=np.float64)
+                _lib.check(lib.tbk_eigenval_device_hint(handle, d_k, _lib.ptr(k_slab), stop - start, d_send))
+                _lib.check(lib.tbk_eigenval_check(handle))  # synchronises; non-finite / non-converged flags of THIS rank
+        except Exception as exc:  # pylint: disable=broad-except
+            failure = exc
+            status = _status_of(exc)
+            message = str(exc)
+        word = np.array([float(status)])
+        tail = ctypes.c_void_p(d_send.value + per * n_orb * 8)
+        _lib.check(lib.tbk_memcpy_h2d(dev, tail, _lib.ptr(word), 8))
+        # (without a staged handle the gather runs on the communicator's own stream)
+        _lib.check(lib.tbk_comm_allgather_f64(comm, handle, d_send, d_recv, count))
+        _lib.check(lib.tbk_comm_synchronize(comm) if handle is None else lib.tbk_synchronize(handle))
+        out = np.empty((self.world, count), dtype=np.float64)
         _lib.check(lib.tbk_memcpy_d2h(dev, _lib.ptr(out), d_recv, out.nbytes))
-        return out[:n_k].copy()
+        if failure is not None:
+            raise failure
+        worst = int(out[:, -1].max())
+        if worst != 0:
+            bad = int(np.argmax(out[:, -1]))
+            _raise_status(worst, "rank %d failed (status %d) while evaluating its k slab" % (bad, worst))
+        return out[:, :-1].reshape(self.world * per, n_orb)[:n_k].copy()
+
+
+def _status_of(exc):
+    """The ``tbk_status`` that `_lib.check` maps to the type of `exc` (the inverse of :func:`_raise_status`)."""
+    if isinstance(exc, np.linalg.LinAlgError):
+        return _lib.TBK_ERR_NO_CONVERGENCE
+    if isinstance(exc, ValueError):
+        return _lib.TBK_ERR_NOT_FINITE
+    if isinstance(exc, MemoryError):
+        return _lib.TBK_ERR_MEMORY
+    return _lib.TBK_ERR_DEVICE
 
 
 def _raise_status(status, message):

@@ -1,0 +1,288 @@
+"""
+GPU tests (``-m gpu``) of the multi-GPU surfaces on the ONE GPU a test box has.
+
+* the one-process-per-GPU form (``sharding.ShardedEigenval`` over RCCL, ``tbk_comm_*``): a world-1 communicator runs
+  every line of the device-gather path -- RCCL accepts one rank;
+* the single-process form behind the unchanged methods (``tbk_eigenval_multi`` / ``tbk_hamilton_multi``,
+  ``Model.devices``): the device list ``[0, 0]`` = two staged handles on the one GPU, two host threads;
+* ``bench.py --gpus N`` starting its own ranks.
+
+What must stay true is the reference's: k-points are independent (``/root/reference/src/tbmodels/_tb_model.py:1111-1123``)
+and results come back in caller order (``:1147-1150``).
+"""
+
+import ctypes
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import tbmodels_amd
+from tbmodels_amd import _lib
+from tbmodels_amd import synthetic as syn
+from tbmodels_amd.rendezvous import FileGroup
+from tbmodels_amd.sharding import ShardedEigenval
+from oracle import tbk_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-10
+
+
+def _grid(shape):
+    axes = [np.linspace(0, 1, n, endpoint=False) for n in shape]
+    return np.ascontiguousarray(np.stack([m.reshape(-1) for m in np.meshgrid(*axes, indexing="ij")], axis=1))
+
+
+def _counter(model, which):
+    value = ctypes.c_int64(-1)
+    _lib.check(_lib.lib().tbk_model_counter(model._staged(), which, ctypes.byref(value)))
+    return value.value
+
+
+@pytest.fixture()
+def small_model():
+    n_orb, n_r = 12, 300
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 61)
+    return tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos), r_vec, hop
+
+
+# ------------------------------------------------------------------------------------------------
+# one process per GPU: world-1 RCCL communicator
+# ------------------------------------------------------------------------------------------------
+def test_sharded_eigenval_device_path_with_a_one_rank_communicator(tmp_path, small_model):
+    """``ShardedEigenval(model, group, device=0)`` takes `_device_gather` (H2D of the slab, tbk_eigenval_device_hint,
+    status word, ncclAllGather, D2H): bit-identical to the plain call on random k and on a ragged mesh slab (folded
+    through the hint), and within 1e-10 of the oracle."""
+    model, r_vec, hop = small_model
+    group = FileGroup(0, 1, str(tmp_path / "rdzv"), token="t1")
+    sharded = ShardedEigenval(model, group, device=0)
+    try:
+        rand = syn.random_kpoints(3001, seed=5)
+        got = sharded(rand)
+        assert got.shape == (3001, 12)
+        assert np.array_equal(got, model.eigenval_array(rand))
+        idx = np.random.default_rng(2).choice(len(rand), 16, replace=False)
+        assert np.abs(got[idx] - np.array(oracle.eigenval(r_vec, hop, rand[idx]))).max() <= TOL
+
+        comm = sharded._communicator()
+        n_ranks, my_rank = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(_lib.lib().tbk_comm_ranks(comm, ctypes.byref(n_ranks), ctypes.byref(my_rank)))
+        assert (n_ranks.value, my_rank.value) == (1, 0)
+
+        slab = _grid((4, 40, 40))[211:5903]  # starts and ends inside a plane: ragged runs
+        folded_before = _counter(model, _lib.TBK_CNT_FOLDED_CALLS)
+        got = sharded(slab)
+        assert _counter(model, _lib.TBK_CNT_FOLDED_CALLS) == folded_before + 1  # the hint reached the library
+        assert np.array_equal(got, model.eigenval_array(slab))
+        idx = np.random.default_rng(3).choice(len(slab), 16, replace=False)
+        assert np.abs(got[idx] - np.array(oracle.eigenval(r_vec, hop, slab[idx]))).max() <= TOL
+
+        one = sharded(rand[7])  # a single k-point is a 1-row list
+        assert one.shape == (1, 12) and np.array_equal(one[0], model.eigenval_array(rand[7]))
+        # the data path left nothing behind in the rendezvous directory beyond the RCCL id exchange
+        assert len(os.listdir(group.path)) <= 2
+    finally:
+        sharded.close()
+        group.close()
+
+
+def test_sharded_eigenval_nan_slab_raises_then_recovers(tmp_path, small_model):
+    """A NaN k-point: ValueError (scipy's check_finite, carried by the status word through the gather), then a clean call."""
+    model, _, _ = small_model
+    group = FileGroup(0, 1, str(tmp_path / "rdzv"), token="t2")
+    sharded = ShardedEigenval(model, group, device=0)
+    try:
+        k = syn.random_kpoints(500, seed=8)
+        bad = k.copy()
+        bad[123, 1] = np.nan
+        with pytest.raises(ValueError):
+            sharded(bad)
+        assert np.array_equal(sharded(k), model.eigenval_array(k))
+    finally:
+        sharded.close()
+        group.close()
+
+
+def test_overlapped_allgather_with_a_chunked_pipeline(small_model):
+    """Six steps of ``tbk_comm_wait_slot`` / chunked ``tbk_eigenval_device_hint`` / ``tbk_comm_allgather_f64_overlapped``
+    (the bench's step) reproduce the in-stream gather: with a small TBK_OPT_K_CHUNK the pipeline's other streams write
+    d_E, the gather runs on the communicator's stream, and the buffers of a slot are reused two steps later."""
+    model, r_vec, hop = small_model
+    lib = _lib.lib()
+    n_orb = 12
+    handle = model._staged()
+    uid = np.zeros(128, dtype=np.uint8)
+    _lib.check(lib.tbk_comm_unique_id(_lib.ptr(uid)))
+    comm = ctypes.c_void_p()
+    _lib.check(lib.tbk_comm_create(0, 1, 0, _lib.ptr(uid), ctypes.byref(comm)))
+    nk = 20_000
+    lists = [np.ascontiguousarray(syn.random_kpoints(nk, seed=100 + s)) for s in range(6)]
+    buffers = []
+
+    def dmalloc(nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(lib.tbk_device_malloc(0, nbytes, ctypes.byref(p)))
+        buffers.append(p)
+        return p
+
+    try:
+        d_k = [dmalloc(nk * 3 * 8) for _ in range(2)]
+        d_e = [dmalloc(nk * n_orb * 8) for _ in range(2)]
+        d_g = [dmalloc(nk * n_orb * 8) for _ in range(2)]
+        reference = []
+        for k in lists:  # in-stream form, default chunking
+            _lib.check(lib.tbk_memcpy_h2d(0, d_k[0], _lib.ptr(k), k.nbytes))
+            _lib.check(lib.tbk_eigenval_device(handle, d_k[0], nk, d_e[0]))
+            _lib.check(lib.tbk_comm_allgather_f64(comm, handle, d_e[0], d_g[0], nk * n_orb))
+            _lib.check(lib.tbk_eigenval_check(handle))
+            out = np.empty((nk, n_orb))
+            _lib.check(lib.tbk_memcpy_d2h(0, _lib.ptr(out), d_g[0], out.nbytes))
+            reference.append(out)
+        assert np.abs(reference[0][:8] - np.array(oracle.eigenval(r_vec, hop, lists[0][:8]))).max() <= TOL
+
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 4096))  # 5 chunks per call
+        results = [None] * 6
+        for step, k in enumerate(lists):
+            slot = step & 1
+            if step >= 2:  # the slot's previous gather must be complete before its result is read and its buffers reused
+                _lib.check(lib.tbk_comm_synchronize(comm))
+                out = np.empty((nk, n_orb))
+                _lib.check(lib.tbk_memcpy_d2h(0, _lib.ptr(out), d_g[slot], out.nbytes))
+                results[step - 2] = out
+            _lib.check(lib.tbk_comm_wait_slot(comm, handle, slot))
+            _lib.check(lib.tbk_memcpy_h2d(0, d_k[slot], _lib.ptr(k), k.nbytes))
+            _lib.check(lib.tbk_eigenval_device_hint(handle, d_k[slot], _lib.ptr(k), nk, d_e[slot]))
+            _lib.check(lib.tbk_comm_allgather_f64_overlapped(comm, handle, d_e[slot], d_g[slot], nk * n_orb, slot))
+        _lib.check(lib.tbk_synchronize(handle))
+        _lib.check(lib.tbk_comm_synchronize(comm))
+        _lib.check(lib.tbk_eigenval_check(handle))
+        for step in (4, 5):
+            out = np.empty((nk, n_orb))
+            _lib.check(lib.tbk_memcpy_d2h(0, _lib.ptr(out), d_g[step & 1], out.nbytes))
+            results[step] = out
+        for step in range(6):
+            # chunking changes which tridiagonal solver a chunk takes: agreement to rounding, not to the bit
+            assert np.abs(results[step] - reference[step]).max() < 1e-12, step
+    finally:
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 0))
+        lib.tbk_comm_destroy(comm)
+        for p in buffers:
+            lib.tbk_device_free(0, p)
+
+
+# ------------------------------------------------------------------------------------------------
+# one process, several devices, unchanged methods
+# ------------------------------------------------------------------------------------------------
+def test_model_on_a_device_list_equals_the_single_device_result(small_model):
+    model, r_vec, hop = small_model
+    twin = pickle.loads(pickle.dumps(model))
+    assert twin._handles == [] and twin.devices == model.devices
+    twin.devices = [0, 0]  # two staged copies on the one GPU, two host threads
+    rand = syn.random_kpoints(5001, seed=21)  # odd count: slabs of 2501 and 2500
+    single = model.eigenval_array(rand)
+    both = twin.eigenval_array(rand)
+    assert len(twin._handles) == 2
+    assert np.abs(both - single).max() < 1e-12  # slab sizes decide the tridiagonal solver of a chunk: rounding level
+    idx = np.random.default_rng(4).choice(len(rand), 16, replace=False)
+    assert np.abs(both[idx] - np.array(oracle.eigenval(r_vec, hop, rand[idx]))).max() <= TOL
+    as_list = twin.eigenval(rand[:5])
+    assert isinstance(as_list, list) and len(as_list) == 5 and as_list[0].shape == (12,)
+    assert twin.eigenval(rand[0]).shape == (12,)  # one k-point: the second slab is empty
+
+    slab = _grid((4, 40, 40))[211:5903]  # ragged mesh slab: each half is folded on its own
+    assert np.abs(twin.eigenval_array(slab) - model.eigenval_array(slab)).max() < 1e-12
+    assert _counter(twin, _lib.TBK_CNT_FOLDED_CALLS) >= 1
+
+    ham = twin.hamilton(rand[:301], convention=1)
+    assert np.array_equal(ham, model.hamilton(rand[:301], convention=1))
+    assert np.abs(ham[:4] - oracle.hamilton(r_vec, hop, rand[:4], 1, pos=model.pos)).max() <= TOL
+
+    bad = rand.copy()
+    bad[4000, 2] = np.inf  # lands in the second slab only
+    with pytest.raises(ValueError) as info:
+        twin.eigenval(bad)
+    assert "infs or NaNs" in str(info.value)
+    assert np.abs(twin.eigenval_array(rand) - single).max() < 1e-12  # and the model is usable afterwards
+
+    clone = pickle.loads(pickle.dumps(twin))  # pickling drops the handles, keeps the device list
+    assert clone._handles == [] and clone.devices == [0, 0]
+    twin.add_on_site([0.25] * 12)  # an edit re-stages every copy
+    shifted = twin.eigenval_array(rand[:64])
+    assert np.abs(shifted - (single[:64] + 0.25)).max() < 1e-12
+
+
+def test_eigenval_multi_c_abi_argument_checks(small_model):
+    model, _, _ = small_model
+    lib = _lib.lib()
+    handle = model._staged()
+    k = syn.random_kpoints(10)
+    out = np.empty((10, 12))
+    assert lib.tbk_eigenval_multi(None, 1, _lib.ptr(k), 10, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    pair = (ctypes.c_void_p * 2)(handle.value, None)
+    assert lib.tbk_eigenval_multi(pair, 2, _lib.ptr(k), 10, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    other = tbmodels_amd.Model.from_packed(*syn.dense_model_arrays(6, 4, 1)[:2])
+    mixed = (ctypes.c_void_p * 2)(handle.value, other._staged().value)
+    assert lib.tbk_eigenval_multi(mixed, 2, _lib.ptr(k), 10, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    same = (ctypes.c_void_p * 3)(handle.value, handle.value, handle.value)  # one handle three times: serialised by its lock
+    _lib.check(lib.tbk_eigenval_multi(same, 3, _lib.ptr(k), 10, _lib.ptr(out)))
+    assert np.abs(out - model.eigenval_array(k)).max() < 1e-12
+    _lib.check(lib.tbk_eigenval_multi(same, 3, _lib.ptr(k), 0, _lib.ptr(out)))  # empty list
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus N
+# ------------------------------------------------------------------------------------------------
+def _bench(extra_args, extra_env, timeout=600):
+    env = dict(os.environ, TBK_BENCH_SKIP_CONFIGS="1", TBK_BENCH_SKIP_PEAK="1", **extra_env)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(name, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample", "0"] + extra_args, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, check=False)
+
+
+def test_bench_with_a_forced_one_rank_communicator():
+    """``TBK_BENCH_FORCE_COMM=1 bench.py --gpus 1``: the overlapped RCCL all-gather inside the timed region reports one
+    rank and costs (next to) nothing."""
+    values = {}
+    for attempt in range(2):  # a second pair if the first one was disturbed
+        for forced in ("0", "1"):
+            done = _bench(["--gpus", "1", "--steps", "5"], {"TBK_BENCH_FORCE_COMM": forced})
+            assert done.returncode == 0, done.stderr.decode()[-2000:]
+            line = json.loads(done.stdout.decode().strip().splitlines()[-1])
+            assert line["n_gpus"] == 1 and line["max_abs_err_vs_oracle"] is None
+            assert line["max_trace_identity_err_4096_rows"] <= TOL
+            assert line["rccl_ranks"] == (1 if forced == "1" else 0)
+            values[forced] = line["value"]
+        if abs(values["1"] / values["0"] - 1.0) <= 0.02:
+            break
+    assert abs(values["1"] / values["0"] - 1.0) <= 0.02, values
+
+
+def test_bench_starts_its_own_ranks_and_fails_for_rccl_reasons_on_one_gpu():
+    """``bench.py --gpus 2`` with no launcher in the environment starts two rank processes itself.  On a one-GPU box both
+    land on device 0 and RCCL refuses the communicator: a non-zero exit that names RCCL -- not the launcher."""
+    if _lib.device_count() >= 2:
+        done = _bench(["--gpus", "2", "--nk", "8192"], {})
+        assert done.returncode == 0, done.stderr.decode()[-2000:]
+        line = json.loads(done.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+        return
+    done = _bench(["--gpus", "2", "--nk", "8192"], {}, timeout=900)
+    err = done.stderr.decode()
+    assert done.returncode != 0
+    assert "RCCL communicator unavailable" in err, err[-2000:]
+    assert "launch with" not in err
+    assert done.stdout.decode().strip() == ""  # no number that RCCL never produced
+    # the launch mechanics themselves (two ranks, rendezvous, max over ranks, one JSON line) with the host gather
+    done = _bench(["--gpus", "2", "--nk", "8192"], {"TBK_BENCH_ALLOW_HOST_GATHER": "1"}, timeout=900)
+    assert done.returncode == 0, done.stderr.decode()[-2000:]
+    lines = [ln for ln in done.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and "host all-gather" in line["config"]["collective"]
