@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "tbk_internal.h"
 
@@ -147,7 +148,9 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave-uniform by construction; said so to the compiler, so that everything derived from it -- the K rows this
+    // wave stages, their global row pointers, the LDS destinations (M0) -- is scalar-unit arithmetic
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1;  // which 64 k-points
     const int wn = wave & 1;   // which 32 packed elements
     const int l15 = lane & 15;
@@ -155,12 +158,6 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 
     const int64_t m0 = (int64_t)mt_idx * a.rows_per_tile;  // first k-point of the tile's output rows
     const int64_t n0 = (int64_t)nt_idx * TBK_BNP;
-
-    // staging: wave w copies K rows w, w+4, w+8, w+12 of both operands, 16 B per lane
-    const double* gA = a.A + (int64_t)mt_idx * a.a_tile_stride + lane * 2;
-    const double* gB = a.Bt + (int64_t)mt_idx * a.b_tile_stride + n0 * 2 + lane * 2;
-    const int64_t ldgA = a.nk_pad;
-    const int64_t ldgB = (int64_t)a.ncol_pad * 2;
 
     d4 acc[4][2][2];
 #pragma unroll
@@ -182,42 +179,67 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
         }
     }
 
-    // global -> LDS without a register round trip (global_load_lds_dwordx4): every wave-instruction
-    // copies one 1 KiB K row; the LDS destination is the wave-uniform row base + 16 B per lane, which is
-    // exactly the padded row layout.  No staging VGPRs: the kernel stays under 184 registers, so two of
-    // its workgroups leave room on every SIMD for a wave of the eigensolver's tridiagonalisation.
-    auto issue_stage = [&](int s, int buf) {
-        const int64_t kk0 = (int64_t)s * TBK_BK;
-        double* sA = smem + buf * STAGE_DOUBLES;
-        double* sB = sA + TBK_BK * LDA;
+    // The K loop holds NO vector-unit instruction besides the MFMAs.  On gfx950 an f64 MFMA and ANY VALU instruction
+    // of the SIMD's waves exclude each other (tools/pipe_probe.hip: times add exactly, also for 32-bit integer adds),
+    // and a wave issues one VALU instruction per 8 cycles: the 44 address instructions hipcc's first version of this loop
+    // carried per stage (64-bit pointer increments in VGPRs, v_readfirstlane for M0, ds_read base adds) cost the matrix
+    // pipe ~350 of the 4096 cycles of a stage.  Now:
+    //   * staging (global -> LDS, global_load_lds_dwordx4: one 1 KiB K row per wave-instruction, no staging VGPRs):
+    //     wave w copies K rows w, w + 4, w + 8, w + 12 of both operands; the row pointers are wave-uniform (SGPR pairs,
+    //     advanced by s_add), the lane's 16 bytes are ONE loop-invariant 32-bit VGPR offset, the LDS row base goes to
+    //     M0 from scalar registers;
+    //   * fragment reads: per-lane LDS base addresses of the two operands in both buffers (four loop-invariant VGPRs),
+    //     every (K step, fragment) a compile-time ds_read offset (the loop is written out for buffer 0 and 1).
+    const uint32_t lane_bytes = (uint32_t)lane * 16u;
+    const int64_t ldgA = a.nk_pad * (int64_t)sizeof(double);                   // bytes per K row
+    const int64_t ldgB = (int64_t)a.ncol_pad * 2 * (int64_t)sizeof(double);
+    const char* rowA = reinterpret_cast<const char*>(a.A + (int64_t)mt_idx * a.a_tile_stride) + ((int64_t)s_begin * TBK_BK + wave) * ldgA;
+    const char* rowB = reinterpret_cast<const char*>(a.Bt + (int64_t)mt_idx * a.b_tile_stride + n0 * 2) + ((int64_t)s_begin * TBK_BK + wave) * ldgB;
+    auto issue_stage = [&](auto bufc) {  // the stage rowA / rowB point at -> buffer bufc; advances them by one stage
+        constexpr int buf = decltype(bufc)::value;
+        double* sA = smem + buf * STAGE_DOUBLES + wave * LDA;
+        double* sB = smem + buf * STAGE_DOUBLES + TBK_BK * LDA + wave * LDB;
+        // (the offset is re-defined inside the block that uses it: instruction selection works per basic block and only
+        // takes the SGPR-base form of the load for `uniform pointer + zext(32-bit VGPR)` it can see whole; hoisted out
+        // of the loop the zero-extension became a VGPR pair and every load cost a 64-bit VALU add)
+        uint32_t off = lane_bytes;
+        asm volatile("" : "+v"(off));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = wave + 4 * i;
-            const int64_t kk = kk0 + row;
-            __builtin_amdgcn_global_load_lds((gptr_t)(gA + kk * ldgA), (lptr_t)(sA + row * LDA), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gB + kk * ldgB), (lptr_t)(sB + row * LDB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(rowA + (int64_t)(4 * i) * ldgA + off), (lptr_t)(sA + 4 * i * LDA), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(rowB + (int64_t)(4 * i) * ldgB + off), (lptr_t)(sB + 4 * i * LDB), 16, 0, 0);
         }
+        rowA += TBK_BK * ldgA;
+        rowB += TBK_BK * ldgB;
     };
-
-    if (n_stage > s_begin) issue_stage(s_begin, 0);
-    __syncthreads();  // drains the LDS-DMA queue (vmcnt) before the barrier
-
-    for (int s = s_begin; s < n_stage; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < n_stage) issue_stage(s + 1, buf ^ 1);  // lands during this stage's MFMAs
-
-        const double* sA = smem + buf * STAGE_DOUBLES + wm * 64 + l15;
-        const double* sB = smem + buf * STAGE_DOUBLES + TBK_BK * LDA + wn * 64 + l15;
+    // one opaque per-lane base per (buffer, K step, operand): the four fragments of a step are then two ds_read2_b64 with
+    // immediate offsets (left to itself hipcc derives the bases of a stage from one register with a VALU add each)
+    typedef __attribute__((address_space(3))) const double* lds_cptr;
+    uint32_t fragA[2][TBK_BK / 4], fragB[2][TBK_BK / 4];  // LDS byte addresses
+    {
+        const uint32_t s0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+#pragma unroll
+        for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+            for (int ks = 0; ks < TBK_BK / 4; ++ks) {
+                fragA[buf][ks] = s0 + 8u * (uint32_t)(buf * STAGE_DOUBLES + wm * 64 + l15 + (ks * 4 + l4) * LDA);
+                fragB[buf][ks] = s0 + 8u * (uint32_t)(buf * STAGE_DOUBLES + TBK_BK * LDA + wn * 64 + l15 + (ks * 4 + l4) * LDB);
+                asm volatile("" : "+v"(fragA[buf][ks]), "+v"(fragB[buf][ks]));
+            }
+    }
+    auto compute_stage = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
 #pragma unroll
         for (int ks = 0; ks < TBK_BK / 4; ++ks) {
-            const int krow = ks * 4 + l4;
+            const lds_cptr sA = (lds_cptr)(uintptr_t)fragA[buf][ks];
+            const lds_cptr sB = (lds_cptr)(uintptr_t)fragB[buf][ks];
             double fa[4], fb[2][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = sA[krow * LDA + i * 16];
+            for (int i = 0; i < 4; ++i) fa[i] = sA[i * 16];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                fb[j][0] = sB[krow * LDB + j * 32];
-                fb[j][1] = sB[krow * LDB + j * 32 + 16];
+                fb[j][0] = sB[j * 32];
+                fb[j][1] = sB[j * 32 + 16];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -227,8 +249,23 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                     acc[i][j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j][1], acc[i][j][1], 0, 0, 0);
                 }
         }
+    };
+    using buf0 = std::integral_constant<int, 0>;
+    using buf1 = std::integral_constant<int, 1>;
+
+    // two stages per trip (buffer 0, then 1), so that everything above is a compile-time offset; an odd stage behind it
+    const int left = n_stage - s_begin;
+    if (left > 0) issue_stage(buf0{});
+    __syncthreads();  // drains the LDS-DMA queue (vmcnt) before the barrier
+    for (int pair = 0; pair < (left >> 1); ++pair) {
+        issue_stage(buf1{});  // lands during this stage's MFMAs
+        compute_stage(buf0{});
         __syncthreads();  // next stage has landed (vmcnt(0)) and everyone is done reading this one
+        if (2 * pair + 2 < left) issue_stage(buf0{});
+        compute_stage(buf1{});
+        __syncthreads();
     }
+    if (left & 1) compute_stage(buf0{});
 
     // ---- epilogue: scatter the packed tile into H[k][i][j] (and H[k][j][i]), or park the partial tile ----
 #pragma unroll
