@@ -227,45 +227,67 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
                 asm volatile("" : "+v"(fragA[buf][ks]), "+v"(fragB[buf][ks]));
             }
     }
-    auto compute_stage = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
+    struct Frags {
+        double fa[4], fb[2][2];
+    };
+    auto read_frags = [&](auto bufc, auto ksc) -> Frags {
+        constexpr int buf = decltype(bufc)::value, ks = decltype(ksc)::value;
+        const lds_cptr sA = (lds_cptr)(uintptr_t)fragA[buf][ks];
+        const lds_cptr sB = (lds_cptr)(uintptr_t)fragB[buf][ks];
+        Frags f;
 #pragma unroll
-        for (int ks = 0; ks < TBK_BK / 4; ++ks) {
-            const lds_cptr sA = (lds_cptr)(uintptr_t)fragA[buf][ks];
-            const lds_cptr sB = (lds_cptr)(uintptr_t)fragB[buf][ks];
-            double fa[4], fb[2][2];
+        for (int i = 0; i < 4; ++i) f.fa[i] = sA[i * 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = sA[i * 16];
+        for (int j = 0; j < 2; ++j) {
+            f.fb[j][0] = sB[j * 32];
+            f.fb[j][1] = sB[j * 32 + 16];
+        }
+        return f;
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                fb[j][0] = sB[j * 32];
-                fb[j][1] = sB[j * 32 + 16];
+                acc[i][j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.fa[i], f.fb[j][0], acc[i][j][0], 0, 0, 0);
+                acc[i][j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.fa[i], f.fb[j][1], acc[i][j][1], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j][0], acc[i][j][0], 0, 0, 0);
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j][1], acc[i][j][1], 0, 0, 0);
-                }
-        }
     };
     using buf0 = std::integral_constant<int, 0>;
     using buf1 = std::integral_constant<int, 1>;
+    using ks0 = std::integral_constant<int, 0>;
+    using ks1 = std::integral_constant<int, 1>;
+    using ks2 = std::integral_constant<int, 2>;
+    using ks3 = std::integral_constant<int, 3>;
+    static_assert(TBK_BK == 16, "four K steps per stage are written out below");
+    // One stage: the fragments of K step ks + 1 are requested before the MFMAs of step ks; the stage barrier sits in
+    // front of the LAST step's MFMAs, and the first fragments of the NEXT stage are requested right behind it -- under
+    // those 16 MFMAs instead of in front of an idle matrix pipe.
+    auto stage = [&](auto bufc, auto nextc, Frags& cur, bool more) {
+        Frags f1 = read_frags(bufc, ks1{});
+        mfma_step(cur);
+        Frags f2 = read_frags(bufc, ks2{});
+        mfma_step(f1);
+        Frags f3 = read_frags(bufc, ks3{});
+        mfma_step(f2);
+        __syncthreads();  // the next stage has landed (vmcnt(0)) and everyone has READ this one (its last fragments are in registers)
+        if (more) cur = read_frags(nextc, ks0{});
+        mfma_step(f3);
+    };
 
     // two stages per trip (buffer 0, then 1), so that everything above is a compile-time offset; an odd stage behind it
     const int left = n_stage - s_begin;
     if (left > 0) issue_stage(buf0{});
     __syncthreads();  // drains the LDS-DMA queue (vmcnt) before the barrier
+    Frags cur = read_frags(buf0{}, ks0{});
     for (int pair = 0; pair < (left >> 1); ++pair) {
         issue_stage(buf1{});  // lands during this stage's MFMAs
-        compute_stage(buf0{});
-        __syncthreads();  // next stage has landed (vmcnt(0)) and everyone is done reading this one
-        if (2 * pair + 2 < left) issue_stage(buf0{});
-        compute_stage(buf1{});
-        __syncthreads();
+        stage(buf0{}, buf1{}, cur, true);
+        const bool more = 2 * pair + 2 < left;
+        if (more) issue_stage(buf0{});
+        stage(buf1{}, buf0{}, cur, more);
     }
-    if (left & 1) compute_stage(buf0{});
+    if (left & 1) stage(buf0{}, buf1{}, cur, false);
 
     // ---- epilogue: scatter the packed tile into H[k][i][j] (and H[k][j][i]), or park the partial tile ----
 #pragma unroll
