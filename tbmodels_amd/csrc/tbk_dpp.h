@@ -7,6 +7,14 @@
 // Householder reflector for the column c a register holds, a pending panel row, the 8 x 8 factors of the compact WY
 // form -- then comes out of ONE register whose lane t holds the t-th value, instead of an LDS broadcast read per value
 // (a 64-lane read that moves 1 KiB through the LDS pipe to deliver 16 bytes).
+//
+// Hazards.  The DPP FMAs go out through inline asm, and LLVM's hazard recogniser does not look inside asm blocks:
+// gfx9 needs 2 wait states between a VALU write of the VGPR a DPP operand reads and the DPP instruction, and 5 after a
+// VALU write of EXEC; the hardware does not interlock them.  An `s_nop 1` in front of every DPP FMA was measured:
+// +10 % on the n <= 64 reduction (12 such FMAs per column and step), so it is not there.  Instead the BUILT objects
+// are checked: tools/dpp_hazard_lint.py disassembles every kernel and fails (tests/test_dpp_hazards.py, CPU suite)
+// if a VALU instruction writes a DPP source register less than 2 instructions, or EXEC less than 5 instructions,
+// ahead of a v_fmac_f64_dpp -- a scheduler change that creates the hazard breaks the build check, not the numbers.
 #pragma once
 
 #include <hip/hip_runtime.h>

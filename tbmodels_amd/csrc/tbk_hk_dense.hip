@@ -367,11 +367,14 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
             acc[q][1] = fma(aq, bi, acc[q][1]);
         }
     }
+    // (a predicate per k-point, not a `break`: leaving the unrolled loop early made the accumulator index dynamic, and
+    // hipcc then kept all 2 NKV accumulators of the 16- and 32-point instantiations in scratch memory: 272 / 528 B per thread)
 #pragma unroll
     for (int q = 0; q < NKV; ++q) {
-        if (q >= nk_here) break;
-        double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kbase + q) * a.ncol_pad + e) * 2;
-        *reinterpret_cast<d2*>(part) = (d2){acc[q][0], acc[q][1]};
+        if (q < nk_here) {
+            double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kbase + q) * a.ncol_pad + e) * 2;
+            *reinterpret_cast<d2*>(part) = (d2){acc[q][0], acc[q][1]};
+        }
     }
 }
 

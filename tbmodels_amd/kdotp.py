@@ -160,9 +160,11 @@ class KdotpModel:
     def to_hdf5(self):
         """
         The tree ``hdf5_lite.write`` stores for the reference's ``SimpleHDF5Mapping`` serialisation of this class
-        (``kdotp.py:19-36``: one attribute, ``taylor_coefficients``, a dict with tuple keys).  The dict / tuple
-        layout follows ``fsc.hdf5_io`` 1.0.x as far as it can be told without the package (not installed here, and
-        the reference ships no such file): ``builtins.dict`` = ``keys`` + ``values`` lists.
+        (``kdotp.py:19-36``: one attribute, ``taylor_coefficients``, a dict with tuple keys).  ``fsc.hdf5_io`` (not
+        installed here, and the reference ships no such file) writes a mapping as ``builtins.dict`` with ONE group
+        ``items`` = ``list(obj.items())``, i.e. a ``builtins.list`` of ``builtins.tuple(key, value)`` pairs, and reads
+        that (or, for legacy files, a ``value`` group of string keys) back: a ``keys`` + ``values`` pair of lists --
+        what this method wrote until round 3 -- does not load there.  ``from_hdf5`` still reads both.
         """
         def number(x):
             return {"type_tag": "builtins.number", "value": np.int64(x)}
@@ -172,21 +174,22 @@ class KdotpModel:
             tree.update({str(i): item for i, item in enumerate(items)})
             return tree
 
-        keys = [sequence("builtins.tuple", [number(x) for x in key]) for key in self.taylor_coefficients]
-        values = [{"type_tag": "numpy.ndarray", "value": np.asarray(mat, dtype=complex)}
-                  for mat in self.taylor_coefficients.values()]
+        pairs = [
+            sequence("builtins.tuple", [
+                sequence("builtins.tuple", [number(x) for x in key]),
+                {"type_tag": "numpy.ndarray", "value": np.asarray(mat, dtype=complex)},
+            ])
+            for key, mat in self.taylor_coefficients.items()
+        ]
         return {
             "type_tag": "tbmodels.kdotp_model",
-            "taylor_coefficients": {
-                "type_tag": "builtins.dict",
-                "keys": sequence("builtins.list", keys),
-                "values": sequence("builtins.list", values),
-            },
+            "taylor_coefficients": {"type_tag": "builtins.dict", "items": sequence("builtins.list", pairs)},
         }
 
     @classmethod
     def from_hdf5(cls, tree):
-        """Inverse of :meth:`to_hdf5`; also accepts the ``items`` (list of pairs) form of a ``builtins.dict``."""
+        """Inverse of :meth:`to_hdf5` (``items``: a list of pairs); also accepts the ``keys`` + ``values`` lists that
+        earlier versions of this package wrote."""
         def plain(node):
             if isinstance(node, dict):
                 tag = node.get("type_tag")
