@@ -141,7 +141,10 @@ __device__ __forceinline__ double seg_sum(double v) {
 template <int NRP>
 __global__ void __launch_bounds__(64)
 herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, double* __restrict__ D,
-                           double* __restrict__ E) {
+                           double* __restrict__ E, int64_t h_stride, int ldd, int off) {
+    // h_stride: doubles between consecutive matrices (n * n * 2 when they are packed back to back; larger when the
+    // matrices are the trailing blocks herm_tridiag4_kernel left at the head of bigger ones); (d, e) of matrix m go to
+    // D / E + m * ldd + off
     constexpr int G = 64 / NRP;  // matrices per wave
     constexpr int CG = 4;        // columns per uniform-branch group
     constexpr int NGR = NRP / CG;
@@ -153,9 +156,9 @@ herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, doub
     const int64_t mat = (int64_t)blockIdx.x * G + lane / NRP;
     const bool live = mat < nk;
     const int64_t mc = live ? mat : nk - 1;
-    const double* Hm = H + (size_t)mc * n * n * 2;
-    double* Dm = D + (size_t)mc * n;
-    double* Em = E + (size_t)mc * n;
+    const double* Hm = H + (size_t)mc * h_stride;
+    double* Dm = D + (size_t)mc * ldd + off;
+    double* Em = E + (size_t)mc * ldd + off;
 
     // lane <- row `row` of the Hermitian matrix whose upper triangle is stored (unconditional clamped loads)
     double ar[NRP], ai[NRP];
@@ -176,6 +179,26 @@ herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, doub
         }
     }
     double xr = ar[0], xi = ai[0];
+
+    // v[c] and w[c] of a lane's own matrix reach the FMAs as DPP operands (row_newbcast: lane t of the lane's row of 16)
+    // wherever a matrix spans whole rows of 16 lanes: NRP = 16 -- the vectors themselves are the operand registers;
+    // NRP = 32 -- ONE permlane16 swap of a vector with itself leaves [r0 r0 r2 r2] and [r1 r1 r3 r3] (r_k = row k of 16
+    // lanes), i.e. entries 0..15 and 16..31 of both matrices of the wave in every row of their segments.  The first
+    // version read them as LDS broadcasts: 96 ds_read_b128 per step at 32 orbitals -- the LDS pipe was the bound.
+    // (NRP = 8: two matrices share a row of 16 lanes; LDS as before.)
+    constexpr bool BC = NRP >= 16;
+    constexpr int NB = NRP >= 16 ? NRP / 16 : 1;
+    auto spread = [&](double x, double (&o)[NB]) {
+        if constexpr (NRP == 32) {
+            const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+            const auto rl = __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+            const auto rh = __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+            o[0] = __hiloint2double((int)rh[0], (int)rl[0]);
+            o[NB - 1] = __hiloint2double((int)rh[1], (int)rl[1]);
+        } else {
+            o[0] = x;
+        }
+    };
 
     for (int j = 0; j < n - 1; ++j) {
         if (live && row == j) Dm[j] = xr;
@@ -201,34 +224,50 @@ herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, doub
         } else if (row == j + 1) {
             vr = 1.0;
         }
-        wave_lds_fence();
-        sv[lane] = (d2){vr, vi};
-        wave_lds_fence();
+        double vbr[NB], vbi[NB];
+        if constexpr (BC) {
+            spread(vr, vbr);
+            spread(vi, vbi);
+        } else {
+            wave_lds_fence();
+            sv[lane] = (d2){vr, vi};
+            wave_lds_fence();
+        }
 
-        // p = A v over the columns of this lane's matrix
+        // u = A v over the columns of this lane's matrix
         double pr = 0.0, pi = 0.0;
         {
             double par[CG], pai[CG];
 #pragma unroll
             for (int cc = 0; cc < CG; ++cc) par[cc] = pai[cc] = 0.0;
-#pragma unroll
-            for (int gr = 0; gr < NGR; ++gr) {
+            static_for<0, NGR>([&](auto grc) {
+                constexpr int gr = decltype(grc)::value;
                 if (gr * CG + CG - 1 > j) {  // uniform (all matrices of the launch have n orbitals)
-                    d2 vb[CG];
+                    if constexpr (BC) {
+                        static_for<0, CG>([&](auto ccc) {
+                            constexpr int cc = decltype(ccc)::value, c = gr * CG + cc;
+                            fmac_bc<c & 15>(par[cc], vbr[c >> 4], ar[c]);
+                            fmac_bc<c & 15>(pai[cc], vbi[c >> 4], ar[c]);
+                            fnmac_bc<c & 15>(par[cc], vbi[c >> 4], ai[c]);
+                            fmac_bc<c & 15>(pai[cc], vbr[c >> 4], ai[c]);
+                        });
+                    } else {
+                        d2 vb[CG];
 #pragma unroll
-                    for (int cc = 0; cc < CG; ++cc) vb[cc] = sv[base + gr * CG + cc];
+                        for (int cc = 0; cc < CG; ++cc) vb[cc] = sv[base + gr * CG + cc];
 #pragma unroll
-                    for (int cc = 0; cc < CG; ++cc) {
-                        par[cc] = fma(ar[gr * CG + cc], vb[cc][0], par[cc]);
-                        pai[cc] = fma(ar[gr * CG + cc], vb[cc][1], pai[cc]);
-                    }
+                        for (int cc = 0; cc < CG; ++cc) {
+                            par[cc] = fma(ar[gr * CG + cc], vb[cc][0], par[cc]);
+                            pai[cc] = fma(ar[gr * CG + cc], vb[cc][1], pai[cc]);
+                        }
 #pragma unroll
-                    for (int cc = 0; cc < CG; ++cc) {
-                        par[cc] = fma(-ai[gr * CG + cc], vb[cc][1], par[cc]);
-                        pai[cc] = fma(ai[gr * CG + cc], vb[cc][0], pai[cc]);
+                        for (int cc = 0; cc < CG; ++cc) {
+                            par[cc] = fma(-ai[gr * CG + cc], vb[cc][1], par[cc]);
+                            pai[cc] = fma(ai[gr * CG + cc], vb[cc][0], pai[cc]);
+                        }
                     }
                 }
-            }
+            });
 #pragma unroll
             for (int cc = 0; cc < CG; ++cc) {
                 pr += par[cc];
@@ -236,49 +275,71 @@ herm_tridiag_packed_kernel(const double* __restrict__ H, int n, int64_t nk, doub
             }
         }
         if (!((row > j) && (row < n))) pr = pi = 0.0;
-        {  // p *= tau
-            const double t = pr * tr - pi * ti;
-            pi = pr * ti + pi * tr;
-            pr = t;
+        // A is Hermitian, so rho = v^H u is real: ONE reduction instead of the complex dot product p^H v of zhetd2
+        // (p = tau u, p^H v = conj(tau) rho), and  w = p - (tau / 2)(p^H v) v = tau u - (|tau|^2 rho / 2) v
+        const double rho = seg_sum<NRP>(pr * vr + pi * vi);
+        const double a2 = -0.5 * (tr * tr + ti * ti) * rho;
+        const double wr = fma(a2, vr, pr * tr - pi * ti);
+        const double wi = fma(a2, vi, pr * ti + pi * tr);
+        double wbr[NB], wbi[NB];
+        if constexpr (BC) {
+            spread(wr, wbr);
+            spread(wi, wbi);
+        } else {
+            sw[lane] = (d2){wr, wi};
+            wave_lds_fence();
         }
-        // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
-        const double dr = seg_sum<NRP>(pr * vr + pi * vi);
-        const double di = seg_sum<NRP>(pr * vi - pi * vr);
-        const double a2r = -0.5 * (tr * dr - ti * di), a2i = -0.5 * (tr * di + ti * dr);
-        const double wr = pr + (a2r * vr - a2i * vi);
-        const double wi = pi + (a2r * vi + a2i * vr);
-        sw[lane] = (d2){wr, wi};
-        wave_lds_fence();
 
         // A -= v w^H + w v^H; the next Householder column is captured on the way
         double nxr = 0.0, nxi = 0.0;
-#pragma unroll
-        for (int gr = 0; gr < NGR; ++gr) {
+        static_for<0, NGR>([&](auto grc) {
+            constexpr int gr = decltype(grc)::value;
             if (gr * CG + CG - 1 > j) {
-                d2 vb[CG], wb[CG];
+                if constexpr (BC) {
+                    static_for<0, CG>([&](auto ccc) {
+                        constexpr int cc = decltype(ccc)::value, c = gr * CG + cc;
+                        double r = ar[c], mm = ai[c];
+                        fnmac_bc<c & 15>(r, wbr[c >> 4], vr);
+                        fnmac_bc<c & 15>(mm, wbr[c >> 4], vi);
+                        fnmac_bc<c & 15>(r, wbi[c >> 4], vi);
+                        fmac_bc<c & 15>(mm, wbi[c >> 4], vr);
+                        fnmac_bc<c & 15>(r, vbr[c >> 4], wr);
+                        fnmac_bc<c & 15>(mm, vbr[c >> 4], wi);
+                        fnmac_bc<c & 15>(r, vbi[c >> 4], wi);
+                        fmac_bc<c & 15>(mm, vbi[c >> 4], wr);
+                        ar[c] = r;
+                        ai[c] = mm;
+                        if (c == j + 1) {  // uniform
+                            nxr = r;
+                            nxi = mm;
+                        }
+                    });
+                } else {
+                    d2 vb[CG], wb[CG];
 #pragma unroll
-                for (int cc = 0; cc < CG; ++cc) {
-                    vb[cc] = sv[base + gr * CG + cc];
-                    wb[cc] = sw[base + gr * CG + cc];
-                }
+                    for (int cc = 0; cc < CG; ++cc) {
+                        vb[cc] = sv[base + gr * CG + cc];
+                        wb[cc] = sw[base + gr * CG + cc];
+                    }
 #pragma unroll
-                for (int cc = 0; cc < CG; ++cc) {
-                    const int c = gr * CG + cc;
-                    ar[c] = fma(-vr, wb[cc][0], ar[c]);
-                    ai[c] = fma(-vi, wb[cc][0], ai[c]);
-                    ar[c] = fma(-vi, wb[cc][1], ar[c]);
-                    ai[c] = fma(vr, wb[cc][1], ai[c]);
-                    ar[c] = fma(-wr, vb[cc][0], ar[c]);
-                    ai[c] = fma(-wi, vb[cc][0], ai[c]);
-                    ar[c] = fma(-wi, vb[cc][1], ar[c]);
-                    ai[c] = fma(wr, vb[cc][1], ai[c]);
-                    if (c == j + 1) {  // uniform
-                        nxr = ar[c];
-                        nxi = ai[c];
+                    for (int cc = 0; cc < CG; ++cc) {
+                        const int c = gr * CG + cc;
+                        ar[c] = fma(-vr, wb[cc][0], ar[c]);
+                        ai[c] = fma(-vi, wb[cc][0], ai[c]);
+                        ar[c] = fma(-vi, wb[cc][1], ar[c]);
+                        ai[c] = fma(vr, wb[cc][1], ai[c]);
+                        ar[c] = fma(-wr, vb[cc][0], ar[c]);
+                        ai[c] = fma(-wi, vb[cc][0], ai[c]);
+                        ar[c] = fma(-wi, vb[cc][1], ar[c]);
+                        ai[c] = fma(wr, vb[cc][1], ai[c]);
+                        if (c == j + 1) {  // uniform
+                            nxr = ar[c];
+                            nxi = ai[c];
+                        }
                     }
                 }
             }
-        }
+        });
         xr = nxr;
         xi = nxi;
     }
@@ -304,7 +365,14 @@ struct HhScalars {
 
 template <int NR, int NW>  // padded rows, waves per matrix
 __global__ void __launch_bounds__(NW * 64, NW == 2 ? 3 : 4)
-herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
+herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps) {
+    // n_steps = n - 1: the whole reduction.  n_steps = n - 32 (split mode): only the first n - 32 Householder steps; the
+    // trailing 32 x 32 block, fully updated, is then written over the head of this matrix' own storage (row-major,
+    // leading dimension 32, upper triangle) for herm_tridiag_packed_kernel<32>, which finishes two such blocks per wave:
+    // there the per-step overhead (reductions, scalar chain) is paid once per TWO matrices instead of four times per
+    // matrix, and no lane idles on a retired row -- steps 32 .. 62 of a 64 x 64 matrix cost 1.4 ms per 32768 matrices
+    // here and 0.7 there.
+    const bool split = n_steps < n - 1;
     constexpr int NT = NR / NW;  // columns per lane
     constexpr int NB = (NT + 15) / 16;  // registers that hold a vector for the row_newbcast operands (16 columns each)
     constexpr int TB = 2;        // column groups per skip block
@@ -327,7 +395,7 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t mat = blockIdx.x;
-    const double* Hm = H + mat * (size_t)n * n * 2;
+    double* Hm = H + mat * (size_t)n * n * 2;
     double* Dm = D + mat * (size_t)n;
     double* Em = E + mat * (size_t)n;
 
@@ -420,12 +488,13 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
 #pragma unroll
     for (int b = 0; b < NB; ++b) bc_slot[b] = min(NW * (16 * b + (lane & 15)) + q, NR - 1);
 
-    for (int j = 0; j < n - 1; ++j) {
+    for (int j = 0; j < n_steps; ++j) {
         wg_sync();  // B1: sx, ssc describe the reflector of column j
         const d2 vme = (lane < NR) ? sx[j & 1][lane] : (d2){0.0, 0.0};
         const HhScalars sc = ssc;
         const int jn = j + 1;  // next column, owned by wave jn % 4
-        const bool own_next = (jn & (NW - 1)) == q;
+        // (split mode: column n_steps is the first one of the trailing block -- its reflector is the next kernel's)
+        const bool own_next = (jn & (NW - 1)) == q && !(split && jn == n_steps);
         if (__builtin_amdgcn_readfirstlane(__double2hiint(sc.flag[0])) != 0) {
             wg_sync();  // B2 (keeps the barrier count of both branches equal; orders the reads above)
             if (own_next) publish(jn);
@@ -501,6 +570,19 @@ herm_tridiag4_kernel(const double* __restrict__ H, int n, double* __restrict__ D
             }
         });
         if (own_next) publish(jn);
+    }
+    if (split) {
+        // Every wave has consumed its loads of H long ago (they are behind the first step's barriers), so the head of
+        // the matrix' storage is free.  Element (i, c), i >= c, of the trailing block goes to the UPPER-triangle slot
+        // (c, i) as its conjugate -- the matrix is Hermitian and both triangles are kept up to date here -- so that the
+        // lanes of a column write consecutive addresses.
+        const int s0 = n_steps;
+        static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int c = NW * t + q;
+            if (c >= s0 && c < n && lane >= c && lane < n)
+                *reinterpret_cast<d2*>(Hm + ((size_t)(c - s0) * 32 + (lane - s0)) * 2) = (d2){TBK_AR(t), -TBK_AI(t)};
+        });
     }
 #undef TBK_AR
 #undef TBK_AI
@@ -658,13 +740,14 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
 bool tbk_eig_small_supported(int n) { return n >= 1 && n <= 64; }
 
 // d_de holds the tridiagonal of every matrix: d[nk][n] followed by e[nk][n]
-int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t nk, double* d_de) {
+int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     double* d_D = d_de;
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
     const dim3 grid((unsigned)nk), block(64);
+    const int64_t packed = (int64_t)n * n * 2;
     if (n > 32) {
         // columns per lane = padded size / 4: a 40-orbital matrix in the 64-row instantiation does 16 column
         // updates per lane and step where 10 are enough (n = 48: 8.0 -> 7.2 ms per 65536 matrices)
@@ -673,23 +756,32 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t n
         // 32768 matrices.  Above, the register arrays of a two-wave split do not fit three waves per SIMD (hipcc spills
         // them: 8 - 15 ms), and at two waves per SIMD the split is no faster than four waves per matrix (4.07 vs 4.14 ms
         // at 64 orbitals): four waves.
+        // Round 3: the four-wave kernel only does the first n - 32 steps; the trailing 32 x 32 block goes through the
+        // head of the matrix' own storage to the packed kernel (two matrices per wave).  TBK_SMALL_SPLIT=0: one kernel.
+        static const bool split_on = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
+        const int n_steps = split_on ? n - 32 : n - 1;
         if (n <= 40)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<40, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<40, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
         else if (n <= 48)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<48, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<48, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
         else if (n <= 56)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<56, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<56, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
         else
-            hipLaunchKernelGGL((herm_tridiag4_kernel<64, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo);
+            hipLaunchKernelGGL((herm_tridiag4_kernel<64, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
         TBK_HIP(hipGetLastError());
+        if (split_on) {
+            hipLaunchKernelGGL(herm_tridiag_packed_kernel<32>, dim3((unsigned)((nk + 1) / 2)), block, 0, s, d_H, 32, nk, d_D, d_Eo,
+                               packed, n, n - 32);
+            TBK_HIP(hipGetLastError());
+        }
         return TBK_OK;
     }
     if (n <= 8)
-        hipLaunchKernelGGL(herm_tridiag_packed_kernel<8>, dim3((unsigned)((nk + 7) / 8)), block, 0, s, d_H, n, nk, d_D, d_Eo);
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<8>, dim3((unsigned)((nk + 7) / 8)), block, 0, s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
     else if (n <= 16)
-        hipLaunchKernelGGL(herm_tridiag_packed_kernel<16>, dim3((unsigned)((nk + 3) / 4)), block, 0, s, d_H, n, nk, d_D, d_Eo);
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<16>, dim3((unsigned)((nk + 3) / 4)), block, 0, s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
     else
-        hipLaunchKernelGGL(herm_tridiag_packed_kernel<32>, dim3((unsigned)((nk + 1) / 2)), block, 0, s, d_H, n, nk, d_D, d_Eo);
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<32>, dim3((unsigned)((nk + 1) / 2)), block, 0, s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

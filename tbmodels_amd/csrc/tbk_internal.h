@@ -272,7 +272,8 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
 
 // tbk_eig_small.hip
 bool tbk_eig_small_supported(int n);
-int tbk_launch_tridiag(tbk_model* m, hipStream_t s, const double* d_H, int64_t nk, double* d_de);
+// (above 32 orbitals the head of every matrix in d_H is overwritten with its trailing 32 x 32 block: H is consumed)
+int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
 // `beside_ql`: this launch shares the chip with another QL launch (the tail of the chunk pipeline): use
 // half-size workgroups (32 KiB of LDS) that fit next to two resident 64 KiB ones.
 int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E, bool beside_ql = false);
