@@ -364,7 +364,7 @@ struct HhScalars {
 };
 
 template <int NR, int NW>  // padded rows, waves per matrix
-__global__ void __launch_bounds__(NW * 64, NW == 2 ? 3 : 4)
+__global__ void __launch_bounds__(NW * 64, NW == 2 ? 2 : 4)
 herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps) {
     // n_steps = n - 1: the whole reduction.  n_steps = n - 32 (split mode): only the first n - 32 Householder steps; the
     // trailing 32 x 32 block, fully updated, is then written over the head of this matrix' own storage (row-major,
@@ -760,12 +760,23 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, dou
         // head of the matrix' own storage to the packed kernel (two matrices per wave).  TBK_SMALL_SPLIT=0: one kernel.
         static const bool split_on = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
         const int n_steps = split_on ? n - 32 : n - 1;
+        // TWO waves per matrix at every size when the kernel only does the first n - 32 steps (round 3; TBK_SMALL_NW2=0:
+        // four): those are the steps with the most FMAs per reduction / barrier / scalar chain, and halving the copies of
+        // that overhead buys more than the lower occupancy costs (178 registers at 64 rows: two waves per SIMD) -- cfg2
+        // 951 -> 963 k, cfg4 8.84 -> 9.26 M k-points/s.  For the WHOLE reduction it was a wash (4.07 vs 4.14 ms, round 2).
+        static const bool two_waves = split_on && !(getenv("TBK_SMALL_NW2") && atoi(getenv("TBK_SMALL_NW2")) == 0);
         if (n <= 40)
             hipLaunchKernelGGL((herm_tridiag4_kernel<40, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
+        else if (n <= 48 && two_waves)
+            hipLaunchKernelGGL((herm_tridiag4_kernel<48, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
         else if (n <= 48)
             hipLaunchKernelGGL((herm_tridiag4_kernel<48, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
+        else if (n <= 56 && two_waves)
+            hipLaunchKernelGGL((herm_tridiag4_kernel<56, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
         else if (n <= 56)
             hipLaunchKernelGGL((herm_tridiag4_kernel<56, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
+        else if (two_waves)
+            hipLaunchKernelGGL((herm_tridiag4_kernel<64, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
         else
             hipLaunchKernelGGL((herm_tridiag4_kernel<64, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
         TBK_HIP(hipGetLastError());
