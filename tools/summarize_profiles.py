@@ -7,7 +7,7 @@ Turn the rocprofv3 outputs of one round (tools/profile_round.sh) into the small,
 Expects (any subset):  <dir>/trace/*_kernel_stats.csv, <dir>/trace_cfgN/*_kernel_stats.csv     kernel time summaries
                        <dir>/cfgN_{fetch,write,sq,sq2,tcc}/*_counter_collection.csv            one PMC group per pass
 Writes profiles/<tag>_kernel_stats[_cfgN].csv, profiles/<tag>_pmc_summary.txt (cfg2, the bench line),
-profiles/<tag>_pmc_cfg3.txt, profiles/<tag>_pmc_cfg5.txt and profiles/<tag>_traffic.json (HBM bytes per launch of the
+profiles/<tag>_pmc_cfg3.txt, _cfg4.txt, _cfg5.txt and profiles/<tag>_traffic.json (HBM bytes per launch of the
 H(k) kernel: what bench.py reports as roofline.traffic).
 """
 import collections
@@ -18,23 +18,35 @@ import os
 import shutil
 import sys
 
-KERNELS = ("hk_dense", "hk_csr", "herm_tridiag4", "herm_tridiag_stream", "band_reduce", "band_chase", "phase_rows",
-           "tridiag_ql", "tridiag_bisect")
+KERNELS = ("hk_dense", "hk_csr", "herm_tridiag4", "herm_tridiag_packed", "herm_tridiag_stream", "band_reduce", "band_chase",
+           "phase_rows", "tridiag_ql", "tridiag_bisect", "fold_rows")
 CONFIG_NOTE = {
     "cfg2": "cfg2: dense N_orb=64, N_R=4096, 100 000 random k-points (the bench line)",
     "cfg3": "cfg3: CSR N_orb=256, N_R=512, 50 000 random k-points",
+    "cfg4": "cfg4: the cfg2 model on the 100 x 100 x 100 mesh (folded evaluation), one GPU",
     "cfg5": "cfg5: dense N_orb=512, N_R=2048, 10 000 random k-points",
 }
 
 
 def load_counters(path):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    """kernel -> counter -> [(value, grid)] over the MEASURED step only: the profiled command runs one warm-up step and one
+    measured step with the same launches, so the first half of every (kernel, counter) series -- in dispatch order --
+    belongs to the warm-up and is dropped."""
+    series = collections.defaultdict(lambda: collections.defaultdict(list))
     for name in glob.glob(os.path.join(path, "*_counter_collection.csv")):
         with open(name) as handle:
             for row in csv.DictReader(handle):
                 for key in KERNELS:
                     if key in row["Kernel_Name"]:
-                        agg[key][row["Counter_Name"]].append((float(row["Counter_Value"]), int(row["Grid_Size"])))
+                        series[key][row["Counter_Name"]].append(
+                            (int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"]), int(row["Grid_Size"])))
+                        break
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for key, counters in series.items():
+        for counter, rows in counters.items():
+            rows.sort()
+            measured = rows[len(rows) // 2:] if len(rows) >= 2 else rows
+            agg[key][counter] = [(value, grid) for _, value, grid in measured]
     return agg
 
 
@@ -49,7 +61,7 @@ def summarize_config(tag, src, cfg):
     lines = [
         "%s -- PMC summary, %s." % (tag, CONFIG_NOTE[cfg]),
         "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --cpu-sample 0 --config %s "
-        "--steps 1 --warmup 1 (one pass per counter group; the warm-up step's launches are in the averages too)" % cfg,
+        "--steps 1 --warmup 1 (one pass per counter group; the launches of the warm-up step are dropped: the measured step only)" % cfg,
         "values: average per launch over the launches with the largest grid (= full k chunks)",
         "FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced",
         "stream (MI355X_MICROARCH.md, HBM), so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE matched a known byte",
@@ -87,7 +99,7 @@ def main():
     for cfg in ("cfg1", "cfg3", "cfg4", "cfg5"):
         for name in glob.glob(os.path.join(src, "trace_%s" % cfg, "*_kernel_stats.csv")):
             shutil.copy(name, os.path.join(out_dir, "%s_kernel_stats_%s.csv" % (tag, cfg)))
-    for cfg in ("cfg2", "cfg3", "cfg5"):
+    for cfg in ("cfg2", "cfg3", "cfg4", "cfg5"):
         lines, traffic = summarize_config(tag, src, cfg)
         if lines is None:
             continue
