@@ -281,7 +281,8 @@ def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
     eig_flops = 16.0 / 3.0 * n_orb ** 3
     eig_tf = eig_flops * matrices / (eig_ms * 1e-3) / 1e12
     return {
-        "kernel": ("herm_tridiag4_kernel / herm_tridiag_packed_kernel" if n_orb <= 64 else
+        "kernel": ("herm_tridiag_packed_kernel" if n_orb <= 32 else
+                   "herm_tridiag4_kernel (first n - 32 steps) + herm_tridiag_packed_kernel (trailing 32 x 32)" if n_orb <= 64 else
                    "herm_tridiag_stream_kernel" if n_orb <= 128 else
                    "band_reduce_kernel (+ chase)" if n_orb <= 512 else "rocsolver zheevd"),
         "bound": "valu-f64" if n_orb <= 128 else "mfma",
@@ -576,8 +577,21 @@ def main():
         as_list = list(e_host)
         dt_list = time.perf_counter() - t1
         del as_list
+        # Z2Pack-style callers evaluate ONE k-point per call (_tb_model.py:1103-1108): wall-clock of such calls
+        one_h = np.empty((1, n_orb, n_orb), dtype=np.complex128)
+        one_e = np.empty((1, n_orb))
+        single = {}
+        for name, call in (("hamilton", lambda q: lib.tbk_hamilton(model, _lib.ptr(k_slab[q:q + 1]), 1, 2, None, _lib.ptr(one_h))),
+                           ("eigenval", lambda q: lib.tbk_eigenval(model, _lib.ptr(k_slab[q:q + 1]), 1, _lib.ptr(one_e)))):
+            for q in range(8):
+                _lib.check(call(q))
+            t1 = time.perf_counter()
+            for q in range(8, 136):
+                _lib.check(call(q))
+            single[name] = round((time.perf_counter() - t1) / 128 * 1e6, 1)
         host_api = {
             "value": round(nk_gpu / dt_call, 1), "unit": "k-points/s", "ms_per_call": round(dt_call * 1e3, 3),
+            "single_k_us": single,
             "includes": "H2D of k, all kernels, non-finite check, D2H of eigenvalues (tbk_eigenval on host buffers)",
             "list_return_ms": round(dt_list * 1e3, 3),
             "value_with_list_return": round(nk_gpu / (dt_call + dt_list), 1),
