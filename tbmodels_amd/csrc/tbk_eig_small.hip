@@ -365,7 +365,11 @@ struct HhScalars {
 
 template <int NR, int NW>  // padded rows, waves per matrix
 __global__ void __launch_bounds__(NW * 64, NW == 2 ? 2 : 4)
-herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps) {
+herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps, int64_t h_stride, int ldd,
+                     int off) {
+    // h_stride: doubles between consecutive matrices (n * n * 2 when packed back to back; larger when they are the trailing
+    // 64 x 64 blocks the streaming kernel of tbk_eig_stream.hip left at the head of bigger matrices); (d, e) of matrix m go
+    // to D / E + m * ldd + off
     // n_steps = n - 1: the whole reduction.  n_steps = n - 32 (split mode): only the first n - 32 Householder steps; the
     // trailing 32 x 32 block, fully updated, is then written over the head of this matrix' own storage (row-major,
     // leading dimension 32, upper triangle) for herm_tridiag_packed_kernel<32>, which finishes two such blocks per wave:
@@ -395,9 +399,9 @@ herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restric
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t mat = blockIdx.x;
-    double* Hm = H + mat * (size_t)n * n * 2;
-    double* Dm = D + mat * (size_t)n;
-    double* Em = E + mat * (size_t)n;
+    double* Hm = H + mat * (size_t)h_stride;
+    double* Dm = D + mat * (size_t)ldd + off;
+    double* Em = E + mat * (size_t)ldd + off;
 
     // Lane i <- row i of the Hermitian matrix whose upper triangle is stored: element (i, c) comes from
     // (min, max) of the pair, conjugated below the diagonal.  Unconditional loads from clamped addresses, all
@@ -740,53 +744,64 @@ tridiag_ql_kernel(const double* __restrict__ D, const double* __restrict__ E, in
 bool tbk_eig_small_supported(int n) { return n >= 1 && n <= 64; }
 
 // d_de holds the tridiagonal of every matrix: d[nk][n] followed by e[nk][n]
+// The register-resident reduction of nk n x n matrices (32 < n <= 64) that sit h_stride doubles apart in d_H; (d, e) of
+// matrix m to d_D / d_E + m * ldd + off.  Two launches: the first n - 32 steps (four or two waves per matrix), then the
+// trailing 32 x 32 blocks two per wave.
+static int launch_tridiag_33_64(hipStream_t s, double* d_H, int n, int64_t nk, double* d_D, double* d_Eo, int64_t h_stride, int ldd, int off) {
+    const dim3 grid((unsigned)nk), block(64);
+    // columns per lane = padded size / 4: a 40-orbital matrix in the 64-row instantiation does 16 column
+    // updates per lane and step where 10 are enough (n = 48: 8.0 -> 7.2 ms per 65536 matrices)
+    // Round 3: the four-wave kernel only does the first n - 32 steps; the trailing 32 x 32 block goes through the
+    // head of the matrix' own storage to the packed kernel (two matrices per wave).  TBK_SMALL_SPLIT=0: one kernel.
+    static const bool split_on = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
+    const int n_steps = split_on ? n - 32 : n - 1;
+    // TWO waves per matrix at every size when the kernel only does the first n - 32 steps (round 3; TBK_SMALL_NW2=0:
+    // four): those are the steps with the most FMAs per reduction / barrier / scalar chain, and halving the copies of
+    // that overhead buys more than the lower occupancy costs (178 registers at 64 rows: two waves per SIMD) -- cfg2
+    // 951 -> 963 k, cfg4 8.84 -> 9.26 M k-points/s.  For the WHOLE reduction it was a wash (4.07 vs 4.14 ms, round 2).
+    static const bool two_waves = split_on && !(getenv("TBK_SMALL_NW2") && atoi(getenv("TBK_SMALL_NW2")) == 0);
+#define TBK_T4(NRV, NWV) \
+    hipLaunchKernelGGL((herm_tridiag4_kernel<NRV, NWV>), grid, dim3(NWV * 64), 0, s, d_H, n, d_D, d_Eo, n_steps, h_stride, ldd, off)
+    if (n <= 40)
+        TBK_T4(40, 2);
+    else if (n <= 48 && two_waves)
+        TBK_T4(48, 2);
+    else if (n <= 48)
+        TBK_T4(48, 4);
+    else if (n <= 56 && two_waves)
+        TBK_T4(56, 2);
+    else if (n <= 56)
+        TBK_T4(56, 4);
+    else if (two_waves)
+        TBK_T4(64, 2);
+    else
+        TBK_T4(64, 4);
+#undef TBK_T4
+    TBK_HIP(hipGetLastError());
+    if (split_on) {
+        hipLaunchKernelGGL(herm_tridiag_packed_kernel<32>, dim3((unsigned)((nk + 1) / 2)), block, 0, s, d_H, 32, nk, d_D, d_Eo,
+                           h_stride, ldd, off + n - 32);
+        TBK_HIP(hipGetLastError());
+    }
+    return TBK_OK;
+}
+
+// The tail of the streaming reduction (tbk_eig_stream.hip): the trailing 64 x 64 blocks it left at the head of the
+// n_full x n_full matrices, (d, e)[n_full - 64 ...] of every matrix.  No stage timer: the caller holds one.
+int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full) {
+    return launch_tridiag_33_64(s, d_H, 64, nk, d_D, d_E, (int64_t)n_full * n_full * 2, n_full, n_full - 64);
+}
+
+// d_de holds the tridiagonal of every matrix: d[nk][n] followed by e[nk][n]
 int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     double* d_D = d_de;
     double* d_Eo = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
-    const dim3 grid((unsigned)nk), block(64);
+    const dim3 block(64);
     const int64_t packed = (int64_t)n * n * 2;
-    if (n > 32) {
-        // columns per lane = padded size / 4: a 40-orbital matrix in the 64-row instantiation does 16 column
-        // updates per lane and step where 10 are enough (n = 48: 8.0 -> 7.2 ms per 65536 matrices)
-        // Up to 40 orbitals TWO waves per matrix (20 columns per lane, 168 registers, three waves per SIMD): the per-step
-        // overhead -- reductions, scalar chain, barriers -- is paid by two waves instead of four, 2.05 -> 1.82 ms per
-        // 32768 matrices.  Above, the register arrays of a two-wave split do not fit three waves per SIMD (hipcc spills
-        // them: 8 - 15 ms), and at two waves per SIMD the split is no faster than four waves per matrix (4.07 vs 4.14 ms
-        // at 64 orbitals): four waves.
-        // Round 3: the four-wave kernel only does the first n - 32 steps; the trailing 32 x 32 block goes through the
-        // head of the matrix' own storage to the packed kernel (two matrices per wave).  TBK_SMALL_SPLIT=0: one kernel.
-        static const bool split_on = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
-        const int n_steps = split_on ? n - 32 : n - 1;
-        // TWO waves per matrix at every size when the kernel only does the first n - 32 steps (round 3; TBK_SMALL_NW2=0:
-        // four): those are the steps with the most FMAs per reduction / barrier / scalar chain, and halving the copies of
-        // that overhead buys more than the lower occupancy costs (178 registers at 64 rows: two waves per SIMD) -- cfg2
-        // 951 -> 963 k, cfg4 8.84 -> 9.26 M k-points/s.  For the WHOLE reduction it was a wash (4.07 vs 4.14 ms, round 2).
-        static const bool two_waves = split_on && !(getenv("TBK_SMALL_NW2") && atoi(getenv("TBK_SMALL_NW2")) == 0);
-        if (n <= 40)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<40, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        else if (n <= 48 && two_waves)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<48, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        else if (n <= 48)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<48, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        else if (n <= 56 && two_waves)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<56, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        else if (n <= 56)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<56, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        else if (two_waves)
-            hipLaunchKernelGGL((herm_tridiag4_kernel<64, 2>), grid, dim3(128), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        else
-            hipLaunchKernelGGL((herm_tridiag4_kernel<64, 4>), grid, dim3(256), 0, s, d_H, n, d_D, d_Eo, n_steps);
-        TBK_HIP(hipGetLastError());
-        if (split_on) {
-            hipLaunchKernelGGL(herm_tridiag_packed_kernel<32>, dim3((unsigned)((nk + 1) / 2)), block, 0, s, d_H, 32, nk, d_D, d_Eo,
-                               packed, n, n - 32);
-            TBK_HIP(hipGetLastError());
-        }
-        return TBK_OK;
-    }
+    if (n > 32) return launch_tridiag_33_64(s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
     if (n <= 8)
         hipLaunchKernelGGL(herm_tridiag_packed_kernel<8>, dim3((unsigned)((nk + 7) / 8)), block, 0, s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
     else if (n <= 16)

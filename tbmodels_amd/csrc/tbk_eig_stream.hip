@@ -126,7 +126,11 @@ __device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1]
 // pass over the triangle needs ~2 k): four waves per matrix, twice as many matrices per CU.
 template <int NU, int NB, int ST_THREADS>
 __global__ void __launch_bounds__(ST_THREADS)
-herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E) {
+herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps) {
+    // n_steps = n - 1: the whole reduction.  n_steps = n - 64 (round 3): the first n - 64 Householder steps only; the
+    // trailing 64 x 64 block, brought up to date with the pending panel, is written over the head of this matrix' storage
+    // (row-major, leading dimension 64, upper triangle) and the register-resident kernels of tbk_eig_small.hip take over:
+    // a step costs ~17 k cycles here (a chain of barriers around a pass over memory) and ~2 k there.
     constexpr int ST_WAVES = ST_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) double st_smem[];
     constexpr int NP = 64 * NU;  // padded vector length
@@ -156,7 +160,7 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
     unsigned long long clk_prev_ = clock64();
 #endif
 
-    for (int j = 0; j < n - 1; ++j) {
+    for (int j = 0; j < n_steps; ++j) {
         // ---- 1. column j of the up-to-date matrix, from row j of the stored triangle ----
         for (int i = tid; i < NP; i += ST_THREADS) {
             d2 x = (d2){0.0, 0.0};
@@ -414,6 +418,36 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
         }
         wg_sync();
         TBK_CLK(6);
+    }
+    if (n_steps < n - 1) {
+        // hand-over: entry (i, c), i <= c, of the trailing block = stored element - the pending panel terms; everything is
+        // read into registers before anything is written (the target overlaps rows that are still being read)
+        const int s0 = n_steps;
+        constexpr int PER = 64 * 64 / ST_THREADS;
+        d2 keep[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int idx = tid + t * ST_THREADS;
+            const int i = idx >> 6, c = idx & 63;
+            d2 a = (d2){0.0, 0.0};
+            if (i <= c) {
+                a = *reinterpret_cast<const d2*>(A + ((size_t)(s0 + i) * n + s0 + c) * 2);
+                for (int b = 0; b < p; ++b) {
+                    const d2 t1 = cmulc(sV[b * NP + s0 + i], sW[b * NP + s0 + c]);
+                    const d2 t2 = cmulc(sW[b * NP + s0 + i], sV[b * NP + s0 + c]);
+                    a[0] -= t1[0] + t2[0];
+                    a[1] -= t1[1] + t2[1];
+                }
+            }
+            keep[t] = a;
+        }
+        wg_sync();
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int idx = tid + t * ST_THREADS;
+            if ((idx >> 6) <= (idx & 63)) *reinterpret_cast<d2*>(A + (size_t)idx * 2) = keep[t];
+        }
+        return;
     }
     // last diagonal element, with whatever is still pending in the panel
     if (tid == 0) {
@@ -705,7 +739,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
 }
 
 template <int NU, int NB, int ST_THREADS>
-hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E) {
+hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E, int n_steps) {
     const bool colbuf = (NU >= 5);  // see COLBUF in the kernel
     const size_t lds = (size_t)(2 * NB + 3 + (colbuf ? ST_THREADS / 64 : 0)) * 64 * NU * sizeof(d2);
     static bool raised[TBK_MAX_DEVICES] = {};
@@ -715,7 +749,7 @@ hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double*
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((herm_tridiag_stream_kernel<NU, NB, ST_THREADS>), dim3(nk), dim3(ST_THREADS), lds, s, d_H, n, d_D,
-                       d_E);
+                       d_E, n_steps);
     return hipGetLastError();
 }
 
@@ -749,16 +783,21 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
     // One instantiation per 64 columns of padded row length (work and LDS scale with the padding).  Measured
     // (tools/bench_sizes.py): four waves and a panel of 4 up to 128 orbitals (n = 80: 1.08 us per matrix against
     // 1.42 with eight waves and a panel of 8); above that panel / workgroup variants are within 2 % of each other
+    // Round 3: the kernel stops after the first n - 64 steps and the register-resident kernels finish the trailing 64 x 64
+    // block (tbk_launch_tridiag_tail64); TBK_STREAM_SPLIT=0: the whole reduction here (measurements).
+    static const bool split_on = !(getenv("TBK_STREAM_SPLIT") && atoi(getenv("TBK_STREAM_SPLIT")) == 0);
+    const int n_steps = split_on ? n - 64 : n - 1;
     if (n <= 128)
-        TBK_HIP((launch_stream<2, 4, 256>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<2, 4, 256>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else if (n <= 192)
-        TBK_HIP((launch_stream<3, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<3, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else if (n <= 256)
-        TBK_HIP((launch_stream<4, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<4, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else if (n <= 384)  // (5 and 7 chunks were measured too: no better than 6 and 8)
-        TBK_HIP((launch_stream<6, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<6, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else
-        TBK_HIP((launch_stream<8, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo)));
+        TBK_HIP((launch_stream<8, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
+    if (split_on) TBK_CHECK(tbk_launch_tridiag_tail64(s, d_H, nk, d_D, d_Eo, n));
     return TBK_OK;
 }
 

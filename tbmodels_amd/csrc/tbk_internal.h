@@ -274,6 +274,7 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
 bool tbk_eig_small_supported(int n);
 // (above 32 orbitals the head of every matrix in d_H is overwritten with its trailing 32 x 32 block: H is consumed)
 int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
+int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full);  // tbk_eig_stream.hip hands over here
 // `beside_ql`: this launch shares the chip with another QL launch (the tail of the chunk pipeline): use
 // half-size workgroups (32 KiB of LDS) that fit next to two resident 64 KiB ones.
 int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E, bool beside_ql = false);
