@@ -377,6 +377,14 @@ def test_c_abi_rejects_bad_arguments_before_touching_a_device():
     assert lib.tbk_hamilton(None, _lib.ptr(k), 1, 2, None, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
     assert lib.tbk_eigenval(None, _lib.ptr(k), 1, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
     assert lib.tbk_model_set_option(None, _lib.TBK_OPT_TIMING, 1) == _lib.TBK_ERR_ARGUMENT
+    # the several-devices entry points: no handle array, an empty one, a NULL entry
+    assert lib.tbk_eigenval_multi(None, 1, _lib.ptr(k), 1, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    assert "handles" in last()
+    holes = (ctypes.c_void_p * 2)(None, None)
+    assert lib.tbk_eigenval_multi(holes, 0, _lib.ptr(k), 1, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    assert lib.tbk_eigenval_multi(holes, 2, _lib.ptr(k), 1, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
+    assert "NULL" in last()
+    assert lib.tbk_hamilton_multi(holes, 2, _lib.ptr(k), 1, 2, None, _lib.ptr(out)) == _lib.TBK_ERR_ARGUMENT
     comm = ctypes.c_void_p()
     uid = np.zeros(128, dtype=np.uint8)
     assert lib.tbk_comm_create(0, 2, 2, _lib.ptr(uid), ctypes.byref(comm)) == _lib.TBK_ERR_ARGUMENT
@@ -385,3 +393,40 @@ def test_c_abi_rejects_bad_arguments_before_touching_a_device():
     if _lib.device_count() == 0:  # valid arguments, no device: the loud failure, not a host computation
         assert create_dense(0, 3, 2, 1, _lib.ptr(r_vec), _lib.ptr(hop), ctypes.byref(handle)) == _lib.TBK_ERR_DEVICE
         assert "no CPU path" in last()
+
+
+def test_device_list_of_a_model(monkeypatch):
+    """``Model.devices``: default from TBK_DEVICES / TBK_DEVICE, assignment re-stages, ``device`` is its first entry
+    (several GPUs behind the unchanged methods: INTEGRATION.md section 4.1)."""
+    import pickle
+
+    from tbmodels_amd import _model
+
+    monkeypatch.delenv("TBK_DEVICES", raising=False)
+    monkeypatch.delenv("TBK_DEVICE", raising=False)
+    assert _model._devices_from_env() == [0]
+    monkeypatch.setenv("TBK_DEVICE", "3")
+    assert _model._devices_from_env() == [3]
+    monkeypatch.setenv("TBK_DEVICES", "0, 2,5")
+    assert _model._devices_from_env() == [0, 2, 5]
+    model = toy_model(0.2, -0.2)
+    assert model.devices == [0, 2, 5] and model.device == 0
+    key = model._staging_key()
+    model.device = 4
+    assert model.devices == [4] and model._staging_key() != key  # the staged copies belong to a device list
+    model.devices = (1, 1)
+    assert model.devices == [1, 1]
+    with pytest.raises(ValueError):
+        model.devices = []
+    with pytest.raises(ValueError):
+        model.devices = [0, -1]
+    clone = pickle.loads(pickle.dumps(model))
+    assert clone.devices == [1, 1] and clone._handles == []
+    # states pickled before the device list existed
+    state = model.__getstate__()
+    state.pop("_devices")
+    state["device"] = 2
+    state["_handle"] = None
+    old = _model.Model.__new__(_model.Model)
+    old.__setstate__(state)
+    assert old.devices == [2] and old._handles == []
