@@ -280,6 +280,19 @@ def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
     HIP-event time of the reduction stage on its own stream."""
     eig_flops = 16.0 / 3.0 * n_orb ** 3
     eig_tf = eig_flops * matrices / (eig_ms * 1e-3) / 1e12
+    hbm = None
+    if 128 < n_orb <= 512:
+        # The two-stage reduction streams the stored triangle of the trailing matrix once per panel of 8 columns (read,
+        # rank-16 update, store, product with the next panel's V in the same visit): by construction
+        # 2 x 16 B x sum_p T(n - 8 (p + 1)) bytes per matrix, T(m) = m (m + 1) / 2 -- against 16 n^2 compulsory.  The [V | W] /
+        # V operand blocks every visit re-reads come on top (L2 / MALL resident for the most part: DESIGN.md 5.5).
+        tiles = sum((n_orb - 8 * (p + 1)) * (n_orb - 8 * (p + 1) + 1) // 2 for p in range(n_orb // 8) if n_orb - 8 * (p + 1) > 0)
+        stream_bytes = 2.0 * 16.0 * tiles
+        rate = stream_bytes * matrices / (eig_ms * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "tile_stream_bytes_per_matrix": stream_bytes, "compulsory_bytes_per_matrix": 16.0 * n_orb * n_orb,
+               "achieved": round(rate, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(rate / 8000.0, 4),
+               "note": "modelled tile traffic of stage one over the whole reduction stage time (both stages); "
+                       "PMC totals per launch: profiles/*_pmc_cfg3.txt / _cfg5.txt"}
     return {
         "kernel": ("herm_tridiag_packed_kernel" if n_orb <= 32 else
                    "herm_tridiag4_kernel (first n - 32 steps) + herm_tridiag_packed_kernel (trailing 32 x 32)" if n_orb <= 64 else
@@ -290,6 +303,7 @@ def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
         "unit": "TFLOP/s", "frac": round(eig_tf / FP64_MFMA_PEAK_TFLOPS, 4),
         "stage_ms_per_step": round(eig_ms / steps, 3),
         "note": "stage time on the reduction's stream; other stages run beside it on other streams",
+        "hbm": hbm,
     }
 
 
