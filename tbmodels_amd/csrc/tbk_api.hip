@@ -306,6 +306,24 @@ extern "C" int tbk_model_create_csr(int device, int dim, int n_orb, int64_t n_r,
             TBK_HIP(hipMemcpy(m->d_rec_r, rec_r.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
             TBK_HIP(hipMemcpy(m->d_rec_v, rec_v.data(), (size_t)nnz * 2 * sizeof(double), hipMemcpyHostToDevice));
             m->staged_bytes += nnz * (int64_t)(sizeof(int32_t) + 2 * sizeof(double));
+            const int kt = tbk_csr_tile_kpoints(n_r);
+            if (kt > 0) {
+                std::vector<int64_t> sptr;
+                std::vector<int32_t> srec_r;
+                std::vector<double> srec_v;
+                tbk_csr_schedule(m->ncol, kt, cptr, rec_r, rec_v, sptr, srec_r, srec_v);
+                m->sched_steps = sptr.back();
+                auto upload = [&](void** dst, const void* src, size_t bytes) -> int {
+                    TBK_HIP(hipMalloc(dst, std::max<size_t>(bytes, 8)));
+                    if (bytes) TBK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+                    m->staged_bytes += (int64_t)bytes;
+                    return TBK_OK;
+                };
+                TBK_CHECK(upload((void**)&m->d_sptr, sptr.data(), sptr.size() * sizeof(int64_t)));
+                TBK_CHECK(upload((void**)&m->d_srec_r, srec_r.data(), srec_r.size() * sizeof(int32_t)));
+                TBK_CHECK(upload((void**)&m->d_srec_v, srec_v.data(), srec_v.size() * sizeof(double)));
+                m->sched_kt = kt;
+            }
         }
         return TBK_OK;
     }();
@@ -336,7 +354,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     if (m->blas) (void)rocblas_destroy_handle(m->blas);
     for (hipStream_t st : streams)
         if (st) (void)hipStreamDestroy(st);
-    void* ptrs[] = {m->d_R, m->d_colmap, m->d_B, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_powers};
+    void* ptrs[] = {m->d_R, m->d_colmap, m->d_B, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_powers, m->d_sptr, m->d_srec_r, m->d_srec_v};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,

@@ -21,6 +21,9 @@
 // Roofline: HBM write bound (8 * N(N+1) B per k in TRI mode, 16 N^2 B in FULL mode).
 
 #include <algorithm>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "tbk_internal.h"
 
@@ -104,16 +107,29 @@ hk_csr_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr,
 // ------------------------------------------------------------------------------------------------
 constexpr int LDS_THREADS = 1024;  // 16 waves share one phase tile: the record walk is latency-bound
 
-template <int MODE, int CONV, int KT>
+// SCHED: the records come in the conflict-free walk order of tbk_csr_schedule -- per wave round (64 consecutive packed
+// elements) a common number of steps, srec[step][lane] = the lane's record of that step or none -- instead of every lane
+// following its own list.  The phase reads of a step then hit 16 different 16-byte slots of the LDS row in each of the
+// four 16-lane groups a ds_read_b128 is served in: one LDS cycle per group instead of ~2.2 with random rows (54 % of the
+// LDS cycles were bank conflicts, and the LDS pipe was this kernel's bound).
+template <int MODE, int CONV, int KT, bool SCHED>
 __global__ void __launch_bounds__(LDS_THREADS)
 hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr,
                   const int32_t* __restrict__ rec_r, const double* __restrict__ rec_v,
                   const int32_t* __restrict__ colmap, const double* __restrict__ kpts,
                   const double* __restrict__ pos, int dim, int ncol, int n_orb, int64_t n_r, int64_t nk,
-                  int64_t nk_pad, double* __restrict__ H) {
+                  int64_t nk_pad, double* __restrict__ H, int tiles_per_xcd, int slice_elems) {
     extern __shared__ __attribute__((aligned(16))) double sph[];  // [n_r][KT * 2 + 2]
     constexpr int LD = KT * 2 + 2;
-    const int64_t k0 = (int64_t)blockIdx.x * KT;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch): XCD x owns the k tiles [x T, (x + 1) T) and walks them SLICE by
+    // slice of `slice_elems` packed elements -- its ~64 resident workgroups then read the same ~1.4 MB of records, which
+    // stay in that XCD's 4 MB L2.  With every workgroup sweeping ALL elements for its tile the 22 MB record stream was
+    // re-read from beyond L2 by each of them (L2 hit rate 42 %, waves waiting 70 % of their time).
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int64_t tile = (int64_t)xcd * tiles_per_xcd + seq % tiles_per_xcd;
+    const int slice = seq / tiles_per_xcd;
+    const int64_t k0 = tile * KT;
+    if (k0 >= nk) return;
     for (int64_t idx = threadIdx.x; idx < n_r * KT; idx += LDS_THREADS) {
         const int64_t r = idx / KT;
         const int q = (int)(idx % KT);
@@ -122,31 +138,39 @@ hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr
     }
     __syncthreads();
     const size_t nn = (size_t)n_orb * n_orb;
-    for (int e = threadIdx.x; e < ncol; e += LDS_THREADS) {
+    const int lane = threadIdx.x & 63;
+    const int ncol_round = min((ncol + 63) & ~63, (slice + 1) * slice_elems);
+    for (int e = slice * slice_elems + threadIdx.x; e < ncol_round; e += LDS_THREADS) {
+        if (!SCHED && e >= ncol) break;
         double re[KT], im[KT];
 #pragma unroll
         for (int q = 0; q < KT; ++q) re[q] = im[q] = 0.0;
-        const int64_t beg = cptr[e], end = cptr[e + 1];
-        // the record walk is a chain of dependent L2 loads: keep the next record in flight
-        int32_t packed_n = 0;
-        d2 val_n = {0.0, 0.0};
-        if (beg < end) {
-            packed_n = rec_r[beg];
-            val_n = *reinterpret_cast<const d2*>(rec_v + 2 * beg);
-        }
-        for (int64_t t = beg; t < end; ++t) {
-            const int32_t packed = packed_n;
-            const double vr = val_n[0], vi = val_n[1];
-            if (t + 1 < end) {
-                packed_n = rec_r[t + 1];
-                val_n = *reinterpret_cast<const d2*>(rec_v + 2 * (t + 1));
+        auto accumulate = [&](int32_t packed, d2 val) {
+            const double vr = val[0], vi = val[1];
+            double ar, ai, br, bi;
+            const double* ph;
+            if (SCHED) {
+                // scheduled records: the byte offset of the phase row in the low 30 bits, the sign of the imaginary part
+                // (+1 direct, -1 transposed, 0 diagonal) as a two-bit signed code above it, diagonal values doubled at
+                // staging -- 4 VALU instructions of decoding per record instead of 12 (the kernel is VALU-bound once
+                // the LDS conflicts and the record misses are gone: 78 % busy)
+                const double sign_im = (double)(packed >> 30);
+                ar = vr;
+                ai = vi;
+                br = sign_im * vi;
+                bi = sign_im * vr;
+                ph = reinterpret_cast<const double*>(reinterpret_cast<const char*>(sph) + (packed & 0x3fffffff));
+            } else {
+                const int kind = packed >> 28;
+                const int64_t r = packed & 0x0fffffff;
+                const double sign_im = (kind == 1) ? -1.0 : ((kind == 2) ? 0.0 : 1.0);
+                const double scale_re = (kind == 2) ? 2.0 : 1.0;
+                ar = scale_re * vr;
+                ai = scale_re * vi;
+                br = sign_im * vi;
+                bi = sign_im * vr;
+                ph = sph + r * LD;
             }
-            const int kind = packed >> 28;
-            const int64_t r = packed & 0x0fffffff;
-            const double sign_im = (kind == 1) ? -1.0 : ((kind == 2) ? 0.0 : 1.0);
-            const double scale_re = (kind == 2) ? 2.0 : 1.0;
-            const double ar = scale_re * vr, ai = scale_re * vi, br = sign_im * vi, bi = sign_im * vr;
-            const double* ph = sph + r * LD;
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
                 const d2 cs = *reinterpret_cast<const d2*>(ph + 2 * q);
@@ -154,6 +178,51 @@ hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr
                 re[q] = fma(-cs[1], ai, re[q]);
                 im[q] = fma(cs[0], br, im[q]);
                 im[q] = fma(cs[1], bi, im[q]);
+            }
+        };
+        if (SCHED) {
+            // cptr = first step of every wave round; rec_r / rec_v = [step][lane] (-1: no record for the lane in the step):
+            // coalesced, the next step's records in flight.  (Storing only the active lanes of a step -- a 64-bit mask and
+            // a record offset per step, the lane's index by mbcnt -- was measured: 25.2 instead of 22.4 ms per 50 000
+            // k-points; the extra dependent loads cost more than the 38 % of padding bytes they save.)
+            const int wr = __builtin_amdgcn_readfirstlane(e >> 6);
+            const int64_t beg = cptr[wr], end = cptr[wr + 1];
+            constexpr int32_t NONE = (int32_t)0x80000000;  // code -2: no record for this lane in this step
+            // (two record slots in turn with scalar step pointers -- 9 instead of 13 non-FMA instructions per step -- were
+            // measured: 16.9 instead of 15.3 ms per 50 000 k-points; the simple form below schedules its loads better)
+            int32_t packed_n = NONE;
+            d2 val_n = {0.0, 0.0};
+            if (beg < end) {
+                packed_n = rec_r[beg * 64 + lane];
+                val_n = *reinterpret_cast<const d2*>(rec_v + 2 * (beg * 64 + lane));
+            }
+            for (int64_t t = beg; t < end; ++t) {
+                const int32_t packed = packed_n;
+                const d2 val = val_n;
+                if (t + 1 < end) {
+                    packed_n = rec_r[(t + 1) * 64 + lane];
+                    val_n = *reinterpret_cast<const d2*>(rec_v + 2 * ((t + 1) * 64 + lane));
+                }
+                if (packed != NONE) accumulate(packed, val);
+            }
+            if (e >= ncol) continue;
+        } else {
+            const int64_t beg = cptr[e], end = cptr[e + 1];
+            // the record walk is a chain of dependent L2 loads: keep the next record in flight
+            int32_t packed_n = 0;
+            d2 val_n = {0.0, 0.0};
+            if (beg < end) {
+                packed_n = rec_r[beg];
+                val_n = *reinterpret_cast<const d2*>(rec_v + 2 * beg);
+            }
+            for (int64_t t = beg; t < end; ++t) {
+                const int32_t packed = packed_n;
+                const d2 val = val_n;
+                if (t + 1 < end) {
+                    packed_n = rec_r[t + 1];
+                    val_n = *reinterpret_cast<const d2*>(rec_v + 2 * (t + 1));
+                }
+                accumulate(packed, val);
             }
         }
         const int32_t ij = colmap[e];
@@ -183,14 +252,29 @@ template <int MODE, int CONV, int KT>
 hipError_t launch_lds(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, const double* d_k,
                       const double* d_pos, double* d_H) {
     const size_t lds = (size_t)std::max<int64_t>(m->n_r, 1) * (KT * 2 + 2) * sizeof(double);
-    static bool raised[TBK_MAX_DEVICES] = {};
-    {
-        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT>), (int)(80 * 1024), raised);
+    static const bool sched_on = !(getenv("TBK_CSR_SCHED") && atoi(getenv("TBK_CSR_SCHED")) == 0);  // 0: measurements
+    const bool sched = sched_on && m->sched_kt == KT && m->d_sptr != nullptr;
+    static bool raised[2][TBK_MAX_DEVICES] = {};
+    // slices of 4 x 1024 packed elements (measured: 1 -> 18.5, 2 -> 17.0, 3 -> 16.6, 4 -> 16.1, 6 -> 18.3, 8 -> 19.8 ms per 50 000 k-points at cfg3) (TBK_CSR_SLICE_ROUNDS: measurements); one slice = the whole triangle for small models
+    static const int slice_rounds = getenv("TBK_CSR_SLICE_ROUNDS") ? std::max(1, atoi(getenv("TBK_CSR_SLICE_ROUNDS"))) : 4;
+    const int64_t n_tiles = (nk + KT - 1) / KT;
+    const int tiles_per_xcd = (int)((n_tiles + 7) / 8);
+    const int slice_elems = slice_rounds * LDS_THREADS;
+    const int n_slices = std::max(1, (((m->ncol + 63) & ~63) + slice_elems - 1) / slice_elems);
+    const dim3 grid((unsigned)(8 * (int64_t)tiles_per_xcd * n_slices)), block(LDS_THREADS);
+    if (sched) {
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, true>), (int)(80 * 1024), raised[1]);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hk_csr_lds_kernel<MODE, CONV, KT, true>), grid, block, lds, m->stream, d_A, m->d_sptr, m->d_srec_r,
+                           m->d_srec_v, m->d_colmap, d_k, d_pos, m->dim, m->ncol, m->n_orb, m->n_r, nk, nk_pad, d_H, tiles_per_xcd,
+                           slice_elems);
+    } else {
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, false>), (int)(80 * 1024), raised[0]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hk_csr_lds_kernel<MODE, CONV, KT, false>), grid, block, lds, m->stream, d_A, m->d_cptr, m->d_rec_r,
+                           m->d_rec_v, m->d_colmap, d_k, d_pos, m->dim, m->ncol, m->n_orb, m->n_r, nk, nk_pad, d_H, tiles_per_xcd,
+                           slice_elems);
     }
-    hipLaunchKernelGGL((hk_csr_lds_kernel<MODE, CONV, KT>), dim3((unsigned)((nk + KT - 1) / KT)), dim3(LDS_THREADS), lds,
-                       m->stream, d_A, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_colmap, d_k, d_pos, m->dim, m->ncol,
-                       m->n_orb, m->n_r, nk, nk_pad, d_H);
     return hipGetLastError();
 }
 
@@ -204,18 +288,132 @@ hipError_t launch_lds_mode(tbk_model* m, const double* d_A, int64_t nk, int64_t 
 
 }  // namespace
 
+// phase tile of KT k-points x all lattice vectors in <= 80 KiB of LDS (two workgroups per CU): 8, 4, 2, 1, or 0 = no fit
+int tbk_csr_tile_kpoints(int64_t n_r) {
+    const int64_t budget = 80 * 1024 / (int64_t)sizeof(double);
+    if (n_r <= 0 || n_r * 4 > budget) return 0;
+    if (n_r * 18 <= budget) return 8;
+    if (n_r * 10 <= budget) return 4;
+    if (n_r * 6 <= budget) return 2;
+    return 1;
+}
+
+// The walk order of the LDS kernel.  A ds_read_b128 of a wave is served in four groups of 16 lanes, one LDS cycle per group
+// when its 16 lanes read 16 different 16-byte slots of the 256-byte LDS row (MI355X_MICROARCH.md, LDS).  A lane reads the
+// phase row of ITS record's lattice vector r: slot (r * (kt + 1) + q) mod 16 for k-point q of the tile (rows of kt + 1
+// slots) -- the same shift q for every lane, so what decides is the class c(r) = r * (kt + 1) mod 16.  Per wave round (64
+// consecutive packed elements) and lane group this is an edge colouring of the bipartite multigraph lanes x classes, one
+// edge per record: colours = steps, and a colouring with max-degree colours always exists (Koenig); it is built here by
+// the alternating-path algorithm.  A round takes the largest of its four groups' step counts; lanes without a record in a
+// step get the code 0x80000000.  A scheduled record carries the byte offset of its phase row and a two-bit sign code instead
+// of (kind, r), diagonal values doubled.  The order of a lane's records changes (so does the last bit of the sums),
+// deterministically.
+void tbk_csr_schedule(int ncol, int kt, const std::vector<int64_t>& cptr, const std::vector<int32_t>& rec_r, const std::vector<double>& rec_v,
+                      std::vector<int64_t>& sptr, std::vector<int32_t>& srec_r, std::vector<double>& srec_v) {
+    static const int group_of_lane[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+    const int n_rounds = (ncol + 63) / 64;
+    const int spr = kt + 1;  // 16-byte slots per phase row
+    sptr.assign((size_t)n_rounds + 1, 0);
+    srec_r.clear();
+    srec_v.clear();
+    struct Edge {
+        int u, v;       // lane slot 0..15 inside the group, class 0..15
+        int64_t rec;    // index into rec_r / rec_v
+        int lane;       // lane 0..63 of the wave
+        int colour;
+    };
+    std::vector<Edge> edges;
+    std::vector<std::vector<int>> at_u, at_v;  // [vertex][colour] -> edge index or -1
+    for (int wr = 0; wr < n_rounds; ++wr) {
+        int round_steps = 0;
+        std::vector<Edge> round_edges;
+        for (int g = 0; g < 4; ++g) {
+            edges.clear();
+            int deg_u[16] = {0}, deg_v[16] = {0}, slot = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                if ((lane >> 5) * 2 + group_of_lane[lane & 31] != g) continue;
+                const int e = wr * 64 + lane;
+                const int u = slot++;
+                if (e >= ncol) continue;
+                for (int64_t t = cptr[(size_t)e]; t < cptr[(size_t)e + 1]; ++t) {
+                    const int64_t r = rec_r[(size_t)t] & 0x0fffffff;
+                    const int v = (int)((r * spr) & 15);
+                    edges.push_back(Edge{u, v, t, lane, -1});
+                    deg_u[u]++;
+                    deg_v[v]++;
+                }
+            }
+            int delta = 0;
+            for (int i = 0; i < 16; ++i) delta = std::max(delta, std::max(deg_u[i], deg_v[i]));
+            at_u.assign(16, std::vector<int>((size_t)delta, -1));
+            at_v.assign(16, std::vector<int>((size_t)delta, -1));
+            for (int ei = 0; ei < (int)edges.size(); ++ei) {
+                Edge& ed = edges[(size_t)ei];
+                int a = 0, b = 0;
+                while (at_u[(size_t)ed.u][(size_t)a] >= 0) ++a;  // free at the lane
+                while (at_v[(size_t)ed.v][(size_t)b] >= 0) ++b;  // free at the class
+                if (a != b) {
+                    // make colour a free at the class vertex: flip the a / b path that starts there with its a-edge
+                    // (in a bipartite graph it cannot come back to this edge's lane vertex, where a is free)
+                    std::vector<int> path;
+                    bool at_class = true;
+                    int vertex = ed.v, want = a;
+                    for (;;) {
+                        const int next = at_class ? at_v[(size_t)vertex][(size_t)want] : at_u[(size_t)vertex][(size_t)want];
+                        if (next < 0) break;
+                        path.push_back(next);
+                        vertex = at_class ? edges[(size_t)next].u : edges[(size_t)next].v;
+                        at_class = !at_class;
+                        want = (want == a) ? b : a;
+                    }
+                    for (int pe : path) {  // take the path's edges out ...
+                        Edge& q = edges[(size_t)pe];
+                        at_u[(size_t)q.u][(size_t)q.colour] = -1;
+                        at_v[(size_t)q.v][(size_t)q.colour] = -1;
+                    }
+                    for (int pe : path) {  // ... and put them back with the two colours exchanged
+                        Edge& q = edges[(size_t)pe];
+                        q.colour = (q.colour == a) ? b : a;
+                        at_u[(size_t)q.u][(size_t)q.colour] = pe;
+                        at_v[(size_t)q.v][(size_t)q.colour] = pe;
+                    }
+                }
+                ed.colour = a;
+                at_u[(size_t)ed.u][(size_t)a] = ei;
+                at_v[(size_t)ed.v][(size_t)a] = ei;
+            }
+            round_steps = std::max(round_steps, delta);
+            round_edges.insert(round_edges.end(), edges.begin(), edges.end());
+        }
+        const size_t base = srec_r.size();
+        srec_r.resize(base + (size_t)round_steps * 64, (int32_t)0x80000000);
+        srec_v.resize((base + (size_t)round_steps * 64) * 2, 0.0);
+        for (const Edge& ed : round_edges) {
+            const size_t at = base + (size_t)ed.colour * 64 + (size_t)ed.lane;
+            const int32_t old = rec_r[(size_t)ed.rec];
+            const int kind = old >> 28;  // 0 direct, 1 transposed, 2 diagonal
+            const uint32_t code = kind == 0 ? 1u : (kind == 1 ? 3u : 0u);  // +1, -1, 0 as a two-bit signed field
+            const uint32_t row_bytes = (uint32_t)(old & 0x0fffffff) * (uint32_t)(kt * 2 + 2) * 8u;
+            srec_r[at] = (int32_t)((code << 30) | row_bytes);
+            const double scale = kind == 2 ? 2.0 : 1.0;
+            srec_v[2 * at] = scale * rec_v[2 * (size_t)ed.rec];
+            srec_v[2 * at + 1] = scale * rec_v[2 * (size_t)ed.rec + 1];
+        }
+        sptr[(size_t)wr + 1] = sptr[(size_t)wr] + round_steps;
+    }
+}
+
 int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
                       int convention, const double* d_k, const double* d_pos, double* d_H) {
     if (nk == 0) return TBK_OK;
-    // phase tile of KT k-points x all lattice vectors in <= 80 KiB of LDS (two workgroups per CU)
-    const int64_t budget = 80 * 1024 / (int64_t)sizeof(double);
-    if (m->n_r > 0 && m->n_r * 4 <= budget) {
+    const int kt = tbk_csr_tile_kpoints(m->n_r);
+    if (kt > 0) {
         StageTimer t(m, TBK_T_HK);
-        if (m->n_r * 18 <= budget)
+        if (kt == 8)
             TBK_HIP((launch_lds_mode<8>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));
-        else if (m->n_r * 10 <= budget)
+        else if (kt == 4)
             TBK_HIP((launch_lds_mode<4>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));
-        else if (m->n_r * 6 <= budget)
+        else if (kt == 2)
             TBK_HIP((launch_lds_mode<2>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));
         else
             TBK_HIP((launch_lds_mode<1>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));

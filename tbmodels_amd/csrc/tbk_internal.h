@@ -157,6 +157,14 @@ struct tbk_model {
     int64_t* d_cptr = nullptr;   // [ncol + 1]
     int32_t* d_rec_r = nullptr;  // [nnz_rec]  (kind << 28) | r   kind: 0 direct, 1 transposed, 2 diagonal
     double* d_rec_v = nullptr;   // [nnz_rec][2]
+    // the same records in the order the LDS kernel walks them: per 64 packed elements ("wave round") a number of steps,
+    // every step one record (or none) per lane, arranged so that the 16 lanes the LDS serves together read 16 different
+    // 16-byte slots of its 256-byte row (tbk_hk_csr.hip: tbk_csr_schedule)
+    int sched_kt = 0;             // k-points per phase tile the schedule was built for (0: no schedule)
+    int64_t sched_steps = 0;
+    int64_t* d_sptr = nullptr;    // [ceil(ncol / 64) + 1] first step of every wave round
+    int32_t* d_srec_r = nullptr;  // [sched_steps][64]  (sign code << 30) | byte offset of the phase row, 0x80000000: no record
+    double* d_srec_v = nullptr;   // [sched_steps][64][2]
 
     int64_t staged_bytes = 0;
 
@@ -245,6 +253,12 @@ int tbk_launch_hk_dense_lines(tbk_model* m, const double* d_A, int64_t n_lines, 
 // tbk_hk_csr.hip
 int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, int mode,
                       int convention, const double* d_k, const double* d_pos, double* d_H);
+
+// host side of the sparse path: k-points per LDS phase tile for n_r lattice vectors (0: the tile does not fit), and the
+// conflict-free walk order of the per-element records for that tile shape
+int tbk_csr_tile_kpoints(int64_t n_r);
+void tbk_csr_schedule(int ncol, int kt, const std::vector<int64_t>& cptr, const std::vector<int32_t>& rec_r, const std::vector<double>& rec_v,
+                      std::vector<int64_t>& sptr, std::vector<int32_t>& srec_r, std::vector<double>& srec_v);
 
 // tbk_eig.hip
 int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E);    // full rocSOLVER zheevd
