@@ -191,6 +191,13 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     TBK_TRY(TBK_ROCBLAS(rocblas_set_stream(m->blas, m->stream)));
     TBK_TRY(TBK_CHECK(m->ws_flag.reserve(2 * sizeof(int))));
     TBK_TRY(TBK_HIP(hipMemsetAsync(m->ws_flag.ptr, 0, 2 * sizeof(int), m->stream)));
+    m->h_stage_bytes = size_t(320) << 10;  // one H(k) of up to 128 orbitals, or a few hundred eigenvalue rows
+    static const int stage_mode = getenv("TBK_STAGE_MODE") ? atoi(getenv("TBK_STAGE_MODE")) : 1;  // 0 off, 1 non-coherent, 2 coherent
+    if (stage_mode == 0 || hipHostMalloc(&m->h_stage, m->h_stage_bytes, stage_mode == 1 ? hipHostMallocNonCoherent : hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        m->h_stage = nullptr;  // no pinned memory: every call takes the pageable path
+        m->h_stage_bytes = 0;
+    }
 
     // packed upper-triangle map, row-major over (i <= j): consecutive e -> consecutive j
     {
@@ -352,6 +359,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
         (void)hipEventDestroy(ev.stop);
     }
     if (m->blas) (void)rocblas_destroy_handle(m->blas);
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
     for (hipStream_t st : streams)
         if (st) (void)hipStreamDestroy(st);
     void* ptrs[] = {m->d_R, m->d_colmap, m->d_B, m->d_cptr, m->d_rec_r, m->d_rec_v, m->d_powers, m->d_sptr, m->d_srec_r, m->d_srec_v};
@@ -1023,6 +1031,32 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
     TBK_ARG(convention == 2 || pos != nullptr, "convention 1 needs pos");
     TBK_HIP(hipSetDevice(m->device));
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
+    {
+        const size_t k_bytes = (size_t)nk * m->dim * sizeof(double), h_bytes = (size_t)nk * nn2 * sizeof(double);
+        const size_t p_bytes = convention == 1 ? (size_t)m->n_orb * m->dim * sizeof(double) : 0;
+        if (m->h_stage != nullptr && h_bytes <= (size_t(16) << 10) && k_bytes + p_bytes + h_bytes <= m->h_stage_bytes) {
+            // small result (one k-point of a model of up to 32 orbitals): [k | pos | H] through the pinned buffer.  Only up
+            // to 16 KiB: the asynchronous device-to-pinned copy of one 64 x 64 H(k) (64 KiB) took 200 us longer than the
+            // blocking copy into the caller's array below (measured, coherent and non-coherent pinned memory alike)
+            char* st = static_cast<char*>(m->h_stage);
+            TBK_CHECK(m->ws_k.reserve(k_bytes));
+            TBK_CHECK(m->ws_out.reserve(h_bytes));
+            std::memcpy(st, k, k_bytes);
+            TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
+            const double* d_pos = nullptr;
+            if (convention == 1) {
+                TBK_CHECK(m->ws_pos.reserve(p_bytes));
+                std::memcpy(st + k_bytes, pos, p_bytes);
+                TBK_HIP(hipMemcpyAsync(m->ws_pos.ptr, st + k_bytes, p_bytes, hipMemcpyHostToDevice, m->stream));
+                d_pos = m->ws_pos.as<double>();
+            }
+            TBK_CHECK(tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, m->ws_out.as<double>()));
+            TBK_HIP(hipMemcpyAsync(st + k_bytes + p_bytes, m->ws_out.ptr, h_bytes, hipMemcpyDeviceToHost, m->stream));
+            TBK_HIP(hipStreamSynchronize(m->stream));
+            std::memcpy(H_out, st + k_bytes + p_bytes, h_bytes);
+            return TBK_OK;
+        }
+    }
     // H leaves in chunks of 16 to 128 MiB (a quarter of the result) through two device buffers: chunk c + 1 is computed while chunk c crosses PCIe
     // (the copy into pageable memory blocks this thread, not the GPU)
     const size_t total_bytes = (size_t)nk * nn2 * sizeof(double);
@@ -1065,12 +1099,26 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
     if (nk == 0) return TBK_OK;
     TBK_ARG(k && E_out, "k / E is NULL");
     TBK_HIP(hipSetDevice(m->device));
-    TBK_CHECK(m->ws_k.reserve((size_t)nk * m->dim * sizeof(double)));
-    TBK_CHECK(m->ws_out.reserve((size_t)nk * m->n_orb * sizeof(double)));
-    TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, k, (size_t)nk * m->dim * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    const size_t k_bytes = (size_t)nk * m->dim * sizeof(double), e_bytes = (size_t)nk * m->n_orb * sizeof(double);
+    TBK_CHECK(m->ws_k.reserve(k_bytes));
+    TBK_CHECK(m->ws_out.reserve(e_bytes));
+    if (m->h_stage != nullptr && k_bytes + e_bytes + 16 <= m->h_stage_bytes) {
+        // small call: [k | E | flags] through the pinned buffer, everything enqueued, one synchronisation
+        char* st = static_cast<char*>(m->h_stage);
+        int* flag = reinterpret_cast<int*>(st + k_bytes + e_bytes);
+        std::memcpy(st, k, k_bytes);
+        TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
+        TBK_CHECK(eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>()));
+        TBK_HIP(hipMemcpyAsync(st + k_bytes, m->ws_out.ptr, e_bytes, hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipStreamSynchronize(m->stream));
+        std::memcpy(E_out, st + k_bytes, e_bytes);
+        if (flag[0] != 0 || flag[1] != 0) return tbk_eigenval_check(m);  // (rare) the ordinary path reports and resets
+        return TBK_OK;
+    }
+    TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, k, k_bytes, hipMemcpyHostToDevice, m->stream));
     TBK_CHECK(eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>()));
-    TBK_HIP(hipMemcpyAsync(E_out, m->ws_out.ptr, (size_t)nk * m->n_orb * sizeof(double),
-                           hipMemcpyDeviceToHost, m->stream));
+    TBK_HIP(hipMemcpyAsync(E_out, m->ws_out.ptr, e_bytes, hipMemcpyDeviceToHost, m->stream));
     return tbk_eigenval_check(m);  // synchronises
 }
 

@@ -200,6 +200,11 @@ struct tbk_model {
     DevBuf ws_out;
     DevBuf ws_out2;  // second device buffer of the chunked H(k) download (tbk_hamilton)
     DevBuf ws_flag;   // int[2]: {non-convergence count, non-finite count}
+    // small host-buffer calls (one k-point per call is what Z2Pack-style callers do): k, the result and the flags cross
+    // PCIe through this PINNED buffer -- asynchronous DMA copies enqueued back to back and ONE synchronisation, where
+    // three copies from / to pageable memory each cost a host-side staging round trip (~20 us apiece)
+    void* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
     DevBuf ws_part;   // split-K partial tiles of the dense H(k) kernel (small k batches)
     DevBuf ws_kfold;  // k-points of a folded run without the folded component
     DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
