@@ -629,8 +629,13 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         return cnt;
     };
 
-    const int m = tid / LPE;    // this lane's eigenvalue index
+    // (calls of a few matrices, LPE > 1: gridDim.y workgroups share a matrix, part p takes the eigenvalues p * per ..., so
+    // that the waves of ONE matrix sit on several CUs -- sixteen waves on one CU take turns on its four SIMDs, and a sweep
+    // is a serial chain per wave: 66 -> 40 us for a single 64 x 64 matrix with four parts)
+    const int m_per = (n + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int m = (int)blockIdx.y * m_per + tid / LPE;  // this lane's eigenvalue index
     const int sub = tid % LPE;  // ... and which interior point of the bracket it tests
+    const int m_end = min(n, ((int)blockIdx.y + 1) * m_per);
     int cnt_lo = 0, cnt_hi = n;  // Sturm counts at the ends of the bracket
     if (LPE == 1 && n > 64) {
         // First round shared by the whole matrix: the n lanes count at n evenly spaced points of the Gershgorin
@@ -735,7 +740,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
             hi = new_hi;
         }
     }
-    if (sub == 0 && m < n) out[mat * n + m] = ldexp(0.5 * (lo + hi), -sc_exp);
+    if (sub == 0 && m < m_end) out[mat * n + m] = ldexp(0.5 * (lo + hi), -sc_exp);
 }
 
 template <int NU, int NB, int ST_THREADS>
@@ -816,9 +821,15 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     int lpe = call_nk <= 32 ? 16 : call_nk <= 512 ? 4 : 1;
     while (lpe < 16 && n * lpe * 2 <= 64) lpe *= 2;
     while (lpe > 1 && n * lpe > 1024) lpe /= 2;
-    const unsigned threads = (unsigned)((n * lpe + 63) / 64 * 64);
+    unsigned threads = (unsigned)((n * lpe + 63) / 64 * 64);
+    // a few matrices with several lanes per eigenvalue: up to four workgroups per matrix (each still loads all of (d, e),
+    // so at least n threads), their waves on different CUs
+    unsigned parts = 1;
+    if (lpe > 1)
+        while (parts < 4 && (threads / (parts * 2)) % 64 == 0 && threads / (parts * 2) >= (unsigned)n_pad && n % (int)(parts * 2) == 0) parts *= 2;
+    threads /= parts;
 #define TBK_BISECT(L) \
-    hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
+    hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk, parts), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
     switch (lpe) {
         case 16: TBK_BISECT(16); break;
         case 8: TBK_BISECT(8); break;
