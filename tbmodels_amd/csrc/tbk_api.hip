@@ -186,6 +186,7 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_tri[b], hipEventDisableTiming)));
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_ql[b], hipEventDisableTiming)));
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_out[b], hipEventDisableTiming)));
+        if (b == 0) TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_sync, hipEventDisableTiming)));
     }
     TBK_TRY(TBK_ROCBLAS(rocblas_create_handle(&m->blas)));
     TBK_TRY(TBK_ROCBLAS(rocblas_set_stream(m->blas, m->stream)));
@@ -353,6 +354,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
         if (m->ev_tri[b]) (void)hipEventDestroy(m->ev_tri[b]);
         if (m->ev_ql[b]) (void)hipEventDestroy(m->ev_ql[b]);
         if (m->ev_out[b]) (void)hipEventDestroy(m->ev_out[b]);
+        if (b == 0 && m->ev_sync) (void)hipEventDestroy(m->ev_sync);
     }
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.start);
@@ -986,12 +988,20 @@ extern "C" int tbk_model_counter(tbk_model* m, int counter, int64_t* value) {
     return TBK_OK;
 }
 
+// Wait for everything enqueued on the main stream -- through an event.  hipStreamSynchronize on this runtime goes to sleep
+// for ~250 us in calls whose GPU work takes a few tens of microseconds (one-k hamilton / eigenval: 290 instead of 50 - 90 us
+// per call, tools/trace_single_k.py); hipEventSynchronize on an event recorded at the same point does not.
+static int wait_main_stream(tbk_model* m) {
+    TBK_HIP(hipEventRecord(m->ev_sync, m->stream));
+    TBK_HIP(hipEventSynchronize(m->ev_sync));
+    return TBK_OK;
+}
+
 extern "C" int tbk_synchronize(tbk_model* m) {
     TBK_ARG(m != nullptr, "model is NULL");
     TBK_LOCK(m);
     TBK_HIP(hipSetDevice(m->device));
-    TBK_HIP(hipStreamSynchronize(m->stream));
-    return TBK_OK;
+    return wait_main_stream(m);
 }
 
 extern "C" int tbk_eigenval_check(tbk_model* m) {
@@ -1001,7 +1011,7 @@ extern "C" int tbk_eigenval_check(tbk_model* m) {
     int flag[2] = {0, 0};
     TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost, m->stream));
     TBK_HIP(hipMemsetAsync(m->ws_flag.ptr, 0, sizeof(flag), m->stream));
-    TBK_HIP(hipStreamSynchronize(m->stream));
+    TBK_CHECK(wait_main_stream(m));
     if (flag[1] != 0) {
         tbk_set_error("array must not contain infs or NaNs");  // scipy's message for the same condition
         return TBK_ERR_NOT_FINITE;
@@ -1034,10 +1044,10 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
     {
         const size_t k_bytes = (size_t)nk * m->dim * sizeof(double), h_bytes = (size_t)nk * nn2 * sizeof(double);
         const size_t p_bytes = convention == 1 ? (size_t)m->n_orb * m->dim * sizeof(double) : 0;
-        if (m->h_stage != nullptr && h_bytes <= (size_t(16) << 10) && k_bytes + p_bytes + h_bytes <= m->h_stage_bytes) {
-            // small result (one k-point of a model of up to 32 orbitals): [k | pos | H] through the pinned buffer.  Only up
-            // to 16 KiB: the asynchronous device-to-pinned copy of one 64 x 64 H(k) (64 KiB) took 200 us longer than the
-            // blocking copy into the caller's array below (measured, coherent and non-coherent pinned memory alike)
+        if (m->h_stage != nullptr && k_bytes + p_bytes + h_bytes <= m->h_stage_bytes) {
+            // small result (one k-point: 64 KiB of H at 64 orbitals): [k | pos | H] through the pinned buffer.  The chunked
+            // download below -- a blocking copy into pageable memory -- takes 290 us per call for results of 25 - 64 KiB
+            // in a loop of one-k calls (tools/trace_single_k.py), this path 50 - 95 us whatever the size
             char* st = static_cast<char*>(m->h_stage);
             TBK_CHECK(m->ws_k.reserve(k_bytes));
             TBK_CHECK(m->ws_out.reserve(h_bytes));
@@ -1052,7 +1062,7 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
             }
             TBK_CHECK(tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, m->ws_out.as<double>()));
             TBK_HIP(hipMemcpyAsync(st + k_bytes + p_bytes, m->ws_out.ptr, h_bytes, hipMemcpyDeviceToHost, m->stream));
-            TBK_HIP(hipStreamSynchronize(m->stream));
+            TBK_CHECK(wait_main_stream(m));
             std::memcpy(H_out, st + k_bytes + p_bytes, h_bytes);
             return TBK_OK;
         }
@@ -1088,8 +1098,7 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
         TBK_HIP(hipEventSynchronize(m->ev_out[c & 1]));
         TBK_HIP(hipMemcpy(H_out + (size_t)c0 * nn2, obuf[c & 1]->ptr, (size_t)nkc * nn2 * sizeof(double), hipMemcpyDeviceToHost));
     }
-    TBK_HIP(hipStreamSynchronize(m->stream));
-    return TBK_OK;
+    return wait_main_stream(m);
 }
 
 extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E_out) {
@@ -1111,7 +1120,7 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
         TBK_CHECK(eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>()));
         TBK_HIP(hipMemcpyAsync(st + k_bytes, m->ws_out.ptr, e_bytes, hipMemcpyDeviceToHost, m->stream));
         TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        TBK_HIP(hipStreamSynchronize(m->stream));
+        TBK_CHECK(wait_main_stream(m));
         std::memcpy(E_out, st + k_bytes, e_bytes);
         if (flag[0] != 0 || flag[1] != 0) return tbk_eigenval_check(m);  // (rare) the ordinary path reports and resets
         return TBK_OK;

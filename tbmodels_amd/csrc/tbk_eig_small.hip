@@ -754,22 +754,28 @@ bool tbk_eig_small_supported(int n) { return n >= 1 && n <= 64; }
 // The register-resident reduction of nk n x n matrices (32 < n <= 64) that sit h_stride doubles apart in d_H; (d, e) of
 // matrix m to d_D / d_E + m * ldd + off.  Two launches: the first n - 32 steps (four or two waves per matrix), then the
 // trailing 32 x 32 blocks two per wave.
-static int launch_tridiag_33_64(hipStream_t s, double* d_H, int n, int64_t nk, double* d_D, double* d_Eo, int64_t h_stride, int ldd, int off) {
+static int launch_tridiag_33_64(hipStream_t s, double* d_H, int n, int64_t nk, double* d_D, double* d_Eo, int64_t h_stride, int ldd, int off,
+                                int64_t call_nk) {
     const dim3 grid((unsigned)nk), block(64);
     // columns per lane = padded size / 4: a 40-orbital matrix in the 64-row instantiation does 16 column
     // updates per lane and step where 10 are enough (n = 48: 8.0 -> 7.2 ms per 65536 matrices)
     // Round 3: the four-wave kernel only does the first n - 32 steps; the trailing 32 x 32 block goes through the
     // head of the matrix' own storage to the packed kernel (two matrices per wave).  TBK_SMALL_SPLIT=0: one kernel.
-    static const bool split_on = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
+    // Calls of a few matrices (all of them resident at once: what counts is one matrix' latency, not issue slots) keep the
+    // whole reduction in ONE launch of the four-wave kernel: a single 64 x 64 matrix 99 -> 78 us.  By the size of the CALL,
+    // not of this chunk: TBK_OPT_K_CHUNK must not change results, and the forms differ in the last bit.
+    static const bool split_env = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
+    const bool split_on = split_env && std::max(call_nk, nk) > 512;
     const int n_steps = split_on ? n - 32 : n - 1;
     // TWO waves per matrix at every size when the kernel only does the first n - 32 steps (round 3; TBK_SMALL_NW2=0:
     // four): those are the steps with the most FMAs per reduction / barrier / scalar chain, and halving the copies of
     // that overhead buys more than the lower occupancy costs (178 registers at 64 rows: two waves per SIMD) -- cfg2
     // 951 -> 963 k, cfg4 8.84 -> 9.26 M k-points/s.  For the WHOLE reduction it was a wash (4.07 vs 4.14 ms, round 2).
-    static const bool two_waves = split_on && !(getenv("TBK_SMALL_NW2") && atoi(getenv("TBK_SMALL_NW2")) == 0);
+    static const bool two_env = !(getenv("TBK_SMALL_NW2") && atoi(getenv("TBK_SMALL_NW2")) == 0);
+    const bool two_waves = split_on && two_env;
 #define TBK_T4(NRV, NWV) \
     hipLaunchKernelGGL((herm_tridiag4_kernel<NRV, NWV>), grid, dim3(NWV * 64), 0, s, d_H, n, d_D, d_Eo, n_steps, h_stride, ldd, off)
-    if (n <= 40)
+    if (n <= 40 && split_on)
         TBK_T4(40, 2);
     else if (n <= 48 && two_waves)
         TBK_T4(48, 2);
@@ -795,8 +801,8 @@ static int launch_tridiag_33_64(hipStream_t s, double* d_H, int n, int64_t nk, d
 
 // The tail of the streaming reduction (tbk_eig_stream.hip): the trailing 64 x 64 blocks it left at the head of the
 // n_full x n_full matrices, (d, e)[n_full - 64 ...] of every matrix.  No stage timer: the caller holds one.
-int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full) {
-    return launch_tridiag_33_64(s, d_H, 64, nk, d_D, d_E, (int64_t)n_full * n_full * 2, n_full, n_full - 64);
+int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full, int64_t call_nk) {
+    return launch_tridiag_33_64(s, d_H, 64, nk, d_D, d_E, (int64_t)n_full * n_full * 2, n_full, n_full - 64, call_nk);
 }
 
 // d_de holds the tridiagonal of every matrix: d[nk][n] followed by e[nk][n]
@@ -808,7 +814,7 @@ int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, dou
     StageTimer t(m, TBK_T_EIG, s);
     const dim3 block(64);
     const int64_t packed = (int64_t)n * n * 2;
-    if (n > 32) return launch_tridiag_33_64(s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
+    if (n > 32) return launch_tridiag_33_64(s, d_H, n, nk, d_D, d_Eo, packed, n, 0, m->call_nk);
     if (n <= 8)
         hipLaunchKernelGGL(herm_tridiag_packed_kernel<8>, dim3((unsigned)((nk + 7) / 8)), block, 0, s, d_H, n, nk, d_D, d_Eo, packed, n, 0);
     else if (n <= 16)

@@ -802,7 +802,7 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
         TBK_HIP((launch_stream<6, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else
         TBK_HIP((launch_stream<8, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
-    if (split_on) TBK_CHECK(tbk_launch_tridiag_tail64(s, d_H, nk, d_D, d_Eo, n));
+    if (split_on) TBK_CHECK(tbk_launch_tridiag_tail64(s, d_H, nk, d_D, d_Eo, n, m->call_nk));
     return TBK_OK;
 }
 

@@ -187,6 +187,7 @@ struct tbk_model {
     hipEvent_t ev_tri[2] = {nullptr, nullptr};  // H[buf] consumed, (d, e)[buf] written
     hipEvent_t ev_out[2] = {nullptr, nullptr};  // tbk_hamilton: chunk in ws_out / ws_out2 computed
     hipEvent_t ev_ql[2] = {nullptr, nullptr};   // (d, e)[buf] consumed, eigenvalues written
+    hipEvent_t ev_sync = nullptr;               // host waits on the main stream go through this event (tbk_api.hip)
     rocblas_handle blas = nullptr;
     DevBuf ws_phase;  // [K2][nk_pad] cos/sin rows
     DevBuf ws_H;      // [chunk][n_orb][n_orb] complex
@@ -293,7 +294,7 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
 bool tbk_eig_small_supported(int n);
 // (above 32 orbitals the head of every matrix in d_H is overwritten with its trailing 32 x 32 block: H is consumed)
 int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
-int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full);  // tbk_eig_stream.hip hands over here
+int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full, int64_t call_nk);  // tbk_eig_stream.hip hands over here
 // `beside_ql`: this launch shares the chip with another QL launch (the tail of the chunk pipeline): use
 // half-size workgroups (32 KiB of LDS) that fit next to two resident 64 KiB ones.
 int tbk_launch_ql(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E, bool beside_ql = false);
