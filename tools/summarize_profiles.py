@@ -29,9 +29,7 @@ CONFIG_NOTE = {
 
 
 def load_counters(path):
-    """kernel -> counter -> [(value, grid)] over the MEASURED step only: the profiled command runs one warm-up step and one
-    measured step with the same launches, so the first half of every (kernel, counter) series -- in dispatch order --
-    belongs to the warm-up and is dropped."""
+    """kernel -> counter -> [(dispatch id, value, grid)] for every launch of the profiled command."""
     series = collections.defaultdict(lambda: collections.defaultdict(list))
     for name in glob.glob(os.path.join(path, "*_counter_collection.csv")):
         with open(name) as handle:
@@ -41,20 +39,18 @@ def load_counters(path):
                         series[key][row["Counter_Name"]].append(
                             (int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"]), int(row["Grid_Size"])))
                         break
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for key, counters in series.items():
-        for counter, rows in counters.items():
-            rows.sort()
-            measured = rows[len(rows) // 2:] if len(rows) >= 2 else rows
-            agg[key][counter] = [(value, grid) for _, value, grid in measured]
-    return agg
+    return series
 
 
 def full_launch_average(vals):
-    """Average over the launches with the largest grid (= full k chunks)."""
-    top = max(g for _, g in vals)
-    big = [v for v, g in vals if g == top]
-    return sum(big) / len(big), len(big), top
+    """Average over the launches with the largest grid (= full k chunks) of the MEASURED step: the profiled command runs one
+    warm-up step and one measured step with the same full-size launches, so of those -- in dispatch order -- the first
+    half belongs to the warm-up and is dropped.  (The one-k calls of the line's host_api section are many small launches
+    behind the measured step: they never have the largest grid.)"""
+    top = max(g for _, _, g in vals)
+    big = sorted((d, v) for d, v, g in vals if g == top)
+    measured = big[len(big) // 2:] if len(big) >= 2 else big
+    return sum(v for _, v in measured) / len(measured), len(measured), top
 
 
 def summarize_config(tag, src, cfg):
