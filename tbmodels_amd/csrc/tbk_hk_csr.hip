@@ -82,7 +82,7 @@ hk_csr_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr,
         const int64_t kq = k0 + q;
         if (kq >= nk) break;
         double vr = re[q], vi = im[q];
-        if (CONV == 1) {
+        if (CONV == 1 && oi != oj) {  // (diagonal: conj(e_i) e_i = 1, Im stays exactly 0)
             const d2 ei = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oi) * 2);  // e[k][p] table
             const d2 ej = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oj) * 2);
             const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
@@ -232,7 +232,7 @@ hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr
             const int64_t kq = k0 + q;
             if (kq >= nk) break;
             double vr = re[q], vi = im[q];
-            if (CONV == 1) {
+            if (CONV == 1 && oi != oj) {  // (diagonal: conj(e_i) e_i = 1, Im stays exactly 0)
                 const d2 ei = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oi) * 2);  // e[k][p] table
                 const d2 ej = *reinterpret_cast<const d2*>(pos + ((size_t)kq * n_orb + oj) * 2);
                 const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];

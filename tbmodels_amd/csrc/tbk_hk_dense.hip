@@ -91,7 +91,7 @@ struct HkArgs {
 // filled once per chunk by tbk_launch_orbital_phases).
 template <int MODE, int CONV>
 __device__ __forceinline__ void store_element(const HkArgs& a, int64_t kq, int oi, int oj, double re, double im) {
-    if (CONV == 1) {
+    if (CONV == 1 && oi != oj) {  // (on the diagonal conj(e_i) e_i = 1: left alone, so that Im H[i][i] stays exactly 0)
         const d2 ei = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oi) * 2);
         const d2 ej = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oj) * 2);
         const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];

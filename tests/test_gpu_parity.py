@@ -345,6 +345,36 @@ def test_seeded_csr_vs_oracle():
     _close(dense.hamilton(k[:32]), model.hamilton(k[:32]), 1e-13)  # tests/test_sparse_dense.py
 
 
+@pytest.mark.parametrize(
+    "n_orb,n_r,fill,nk",
+    [
+        (24, 40, 0.10, 37),      # phase tile of 8 k-points; 300 packed elements: five wave rounds, the last one ragged
+        (23, 600, 0.05, 21),     # tile of 4 k-points (rows of 5 slots)
+        (16, 1500, 0.05, 9),     # tile of 2 k-points (rows of 3 slots)
+        (12, 2400, 0.08, 5),     # tile of 1 k-point (rows of 2 slots: only 8 distinct classes)
+        (70, 64, 0.003, 33),     # most packed elements without a single record
+        (9, 30, 1.0, 16),        # fully dense blocks stored as CSR: every lane's list has every lattice vector
+    ],
+)
+def test_sparse_walk_order_for_every_tile_shape(n_orb, n_r, fill, nk):
+    """The LDS kernel of the sparse path walks its records in the conflict-free order built at staging
+    (csrc/tbk_hk_csr.hip: tbk_csr_schedule, an edge colouring per 16-lane LDS group) -- for every phase-tile shape, ragged
+    last wave rounds, empty record lists and full ones: equal to the dense storage of the same model (the reference's
+    tests/test_sparse_dense.py) and to the oracle, both conventions."""
+    r_vec, r_ptr, row, col, val, pos = syn.csr_model_arrays(n_orb, n_r, syn.MODEL_SEED + 500 + n_r, fill=fill)
+    hop = syn.csr_to_dense(n_orb, r_ptr, row, col, val)
+    k = syn.random_kpoints(nk, seed=n_r)
+    sparse = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=True)
+    dense = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos, sparse=False)
+    for convention in (1, 2):
+        h_sparse = sparse.hamilton(k, convention=convention)
+        _close(h_sparse, dense.hamilton(k, convention=convention), 1e-13)
+        _close(h_sparse[:4], oracle.hamilton(r_vec, hop, k[:4], convention, pos=pos))
+        _close(h_sparse, h_sparse.conj().transpose(0, 2, 1), 0.0)  # exactly Hermitian, like H += H^H
+    _close(np.array(sparse.eigenval(k)), np.array(dense.eigenval(k)), 1e-12)
+    _close(np.array(sparse.eigenval(k[:4])), np.array(oracle.eigenval(r_vec, hop, k[:4])))
+
+
 def test_chunked_pipeline_matches_single_chunk():
     """k chunks (TBK_OPT_K_CHUNK) must not change results; order of k is preserved."""
     from tbmodels_amd import _lib
