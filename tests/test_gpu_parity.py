@@ -850,3 +850,43 @@ def test_fixed_seed_fuzz_sample():
     spec.loader.exec_module(fuzz)
     fuzz.configure(seconds=120.0, seed=20261002, cases=40)
     assert fuzz.main() == 0
+
+
+def test_repeated_small_calls_through_the_pinned_staging_buffer():
+    """One-k-point calls (the Z2Pack pattern) move k, the eigenvalues and the flag words through the handle's pinned staging
+    buffer (csrc/tbk_api.hip: tbk_eigenval): right for every k of a long loop, for other small shapes, after a larger call
+    in between (which grows the workspaces), the call counter keeps counting, and a NaN k-point still raises -- and
+    leaves the flags clean for the calls behind it."""
+    import ctypes
+
+    from tbmodels_amd import _lib
+
+    r_vec, hop, pos = syn.dense_model_arrays(20, 60, syn.MODEL_SEED + 321)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    k = syn.random_kpoints(40, seed=77)
+    ref = np.array(oracle.eigenval(r_vec, hop, k))
+
+    def calls():
+        value = ctypes.c_int64(-1)
+        _lib.check(_lib.lib().tbk_model_counter(model._staged(), _lib.TBK_CNT_EIGENVAL_CALLS, ctypes.byref(value)))
+        return value.value
+
+    for q in range(12):
+        _close(model.eigenval(k[q]), ref[q])
+    assert calls() == 12
+    for q in range(0, 12, 3):  # another shape: three k-points per call
+        _close(np.array(model.eigenval(k[q:q + 3])), ref[q:q + 3])
+    big = syn.random_kpoints(5000, seed=3)  # grows H / (d, e) / phase workspaces
+    eig_big = model.eigenval_array(big)
+    _close(eig_big[:3], np.array(oracle.eigenval(r_vec, hop, big[:3])))
+    for q in range(12, 24):
+        _close(model.eigenval(k[q]), ref[q])
+    bad = k[5].copy()
+    bad[1] = np.nan
+    with pytest.raises(ValueError):
+        model.eigenval(bad)
+    for q in range(24, 30):
+        _close(model.eigenval(k[q]), ref[q])
+    before = calls()
+    model.eigenval(k[0])
+    assert calls() == before + 1
