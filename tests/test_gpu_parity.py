@@ -611,7 +611,7 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     il = np.tril_indices(n, -1)
     poisoned[:, il[0], il[1]] = np.nan
     d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(poisoned)
-    # the two-stage kernels at every size they handle (eigenval itself takes them from 129 orbitals on); the
+    # the two-stage kernels at every size they handle (eigenval itself takes them from 161 orbitals on); the
     # production choice and the forced one-stage path are compared below
     method = _lib.TBK_REDUCE_TWO_STAGE if n > 64 else _lib.TBK_REDUCE_AUTO
     _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), method, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
@@ -655,7 +655,7 @@ def test_two_stage_and_one_stage_reductions_agree():
     import tempfile
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r_vec, hop, pos = syn.dense_model_arrays(150, 6, syn.MODEL_SEED + 321)
+    r_vec, hop, pos = syn.dense_model_arrays(200, 6, syn.MODEL_SEED + 321)  # (above the crossover at 161 orbitals)
     k = syn.random_kpoints(2600, seed=5)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     from tbmodels_amd import _lib
@@ -666,7 +666,7 @@ def test_two_stage_and_one_stage_reductions_agree():
     script = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "import tbmodels_amd; from tbmodels_amd import synthetic as syn, _lib\n"
-        "r, h, p = syn.dense_model_arrays(150, 6, syn.MODEL_SEED + 321)\n"
+        "r, h, p = syn.dense_model_arrays(200, 6, syn.MODEL_SEED + 321)\n"
         "m = tbmodels_amd.Model.from_packed(r, h, pos=p); m.set_option(_lib.TBK_OPT_K_CHUNK, 1024)\n"
         "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(2600, seed=5)))\n" % root
     )
