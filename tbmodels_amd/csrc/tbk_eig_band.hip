@@ -1117,7 +1117,7 @@ static int chase_pitch(int n) {
     return np;
 }
 
-// The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 161 orbitals on (129 until round 3): up to 128 the one-stage kernel of
+// The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 189 orbitals on (129 until round 3): up to 128 the one-stage kernel of
 // tbk_eig_stream.hip (four waves per matrix, rows of two 64-column chunks) is faster -- 0.65 vs 0.84 us per matrix at 65
 // orbitals, 1.73 vs 2.14 at 128; from 129 on the one-stage rows grow a third chunk and the order flips (3.8 vs 3.3 us at 160).
 // Both stages in ONE kernel (the workgroup goes straight on to the bulge chasing of its matrix, in the same LDS) or in
@@ -1133,9 +1133,11 @@ bool tbk_band_fused(int n) {
 
 bool tbk_eig_band_supported(int n) { return n > 64 && n <= 512; }
 bool tbk_eig_band_preferred(int n) {
-    // (round 3: the one-stage kernel hands its last 64 steps to the register-resident kernels, which moved the crossover up:
-    // 2.04 vs 2.37 us per matrix at 130 orbitals, 2.47 vs 2.57 at 144, 2.97 vs 3.02 at 160, 3.73 vs 3.53 at 176)
-    static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 161;  // measurements only
+    // (round 3: the one-stage kernel hands its last 128 steps to the register-resident kernels -- eight waves per matrix
+    // from 128 to 64, tbk_eig_small.hip -- which moved the crossover up: 1.34 vs 2.37 us per matrix at 130 orbitals, 1.96 vs
+    // 2.57 at 144, 2.56 vs 3.02 at 160; reduction stage of 4096 matrices 12.2 vs 12.7 ms at 176, 13.4 vs 13.9 at 184,
+    // 14.9 vs 14.4 at 192)
+    static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 189;  // measurements only
     return n >= from && n <= 512;
 }
 

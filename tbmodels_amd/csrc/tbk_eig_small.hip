@@ -600,6 +600,237 @@ herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// kernel 1c: 64 < n <= 128 -- EIGHT waves per matrix, the matrix in registers (round 3).  Wave (q, rh) holds columns
+// c = 4 t + q of rows 64 rh + lane: 32 complex = 128 VGPRs per lane at 128 orbitals; one workgroup is one matrix.
+// It runs the first n - 64 Householder steps and leaves the trailing 64 x 64 block at the head of the matrix' storage
+// for the kernels above (tbk_launch_tridiag_tail64), like the streaming kernel of tbk_eig_stream.hip it replaces at
+// these sizes -- there a step is a pass over memory between barriers (~17 k cycles), here ~5 k.
+//
+// What differs from kernel 1b, where every wave has all rows: sums over the rows span two waves, and a third barrier
+// per step would cost more than redundant arithmetic.
+//   * sigma (the norm of the new column below the sub-diagonal): the two waves that own the column publish the RAW
+//     column and their partial sums; behind the step's first barrier every wave forms the reflector scalars and scales
+//     its own rows (and the columns its broadcast registers stand for) itself;
+//   * rho = v^H A v: every wave reduces its rows x its columns' share of it BEFORE the second barrier and publishes it
+//     beside its partial products; behind the barrier everybody adds the eight numbers in the same order;
+//   * w at the columns of a wave's broadcast registers comes from the partial products in LDS (any wave can add the four
+//     partials of any row), not from a copy of w another wave would have to publish first.
+// ------------------------------------------------------------------------------------------------
+// the largest divisor of nt that is at most 12
+constexpr int load_batch(int nt) {
+    int best = 1;
+    for (int d = 2; d <= 12; ++d)
+        if (nt % d == 0) best = d;
+    return best;
+}
+
+template <int NC, int NW>  // padded columns (a multiple of 8, <= 128); column residues = waves per row half (4; 2 up to 96 columns)
+__global__ void __launch_bounds__(NW * 128, 2)
+herm_tridiag8_kernel(double* H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps, int64_t h_stride, int ldd, int off) {
+    constexpr int NR = 128;      // rows: two waves of 64
+    constexpr int NT = NC / NW;  // columns per lane
+    constexpr int NB = (NT + 15) / 16;
+    constexpr int TB = 2;
+    static_assert(NC % (NW * TB) == 0 && NB <= 3 && (NW == 2 || NW == 4), "column layout");
+    __shared__ d2 sx[2][NR];       // raw column of step j in sx[j & 1] (same turn-taking as kernel 1b)
+    __shared__ double ssig[2][2];  // its partial norms, one per row half
+    __shared__ d2 sp[NW][NR];      // partial products A v per column residue
+    __shared__ double srho[2 * NW];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = wv & (NW - 1), rh = wv / NW;
+    const int row = rh * 64 + lane;
+    const size_t mat = blockIdx.x;
+    double* Hm = H + mat * (size_t)h_stride;
+    double* Dm = D + mat * (size_t)ldd + off;
+    double* Em = E + mat * (size_t)ldd + off;
+
+    // statically indexed only (the next column is caught on its way through the update, and a column that needs no
+    // reflector takes the same path with v = w = 0): plain registers, no padding of the column count to 16
+    double ar[NT], ai[NT];
+    {
+        constexpr int LB = load_batch(NT);  // loads in flight together
+        const int li = min(row, n - 1);
+        static_for<0, NT / LB>([&](auto t0c) {
+            constexpr int t0 = decltype(t0c)::value * LB;
+            d2 raw[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int c = min(NW * (t0 + u) + q, n - 1);
+                const int lo = min(li, c), hi = max(li, c);
+                raw[u] = *reinterpret_cast<const d2*>(Hm + ((size_t)lo * n + hi) * 2);
+            }
+            static_for<0, LB>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int c = NW * (t0 + u) + q;
+                const bool inside = row < n && c < n;
+                ar[t0 + u] = inside ? raw[u][0] : 0.0;
+                ai[t0 + u] = inside ? (c >= row ? raw[u][1] : -raw[u][1]) : 0.0;
+            });
+        });
+    }
+
+    // the two waves that hold column jc hand it out as it is, with their share of sum |x_i|^2 over the rows below the
+    // sub-diagonal; d[jc] is the diagonal entry
+    auto publish = [&](int jc, double xr, double xi) {
+        if (row == jc) Dm[jc] = xr;
+        const bool below = (row > jc + 1) && (row < n);
+        const double part = wave_sum(below ? (xr * xr + xi * xi) : 0.0);
+        sx[jc & 1][row] = (d2){xr, xi};
+        if (lane == 0) ssig[jc & 1][rh] = part;
+    };
+    if (q == 0) publish(0, ar[0], ai[0]);
+    int bc_col[NB];  // the columns this lane's broadcast registers stand for: NW * (16 b + lane % 16) + q
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bc_col[b] = NW * (16 * b + (lane & 15)) + q;
+
+    for (int j = 0; j < n_steps; ++j) {
+        wg_sync();  // B1: sx, ssig of column j
+        const int jn = j + 1;
+        const d2 xme = sx[j & 1][row];
+        const d2 al = sx[j & 1][jn];
+        const double sigma = ssig[j & 1][0] + ssig[j & 1][1];
+        d2 xb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xb[b] = sx[j & 1][min(bc_col[b], NR - 1)];
+        const bool own_next = (jn & (NW - 1)) == q && jn != n_steps;  // (column n_steps is the next kernel's)
+        const int tn = own_next ? jn / NW : -1;
+        const double alr = al[0], ali = al[1];
+        const bool ident = sigma == 0.0 && ali == 0.0;  // already reduced: H = I, this step changes nothing
+        double root, rroot;
+        fast_sqrt_rsqrt(ident ? 1.0 : alr * alr + ali * ali + sigma, root, rroot);
+        const double beta = -copysign(root, alr);
+        const double rbeta = -copysign(rroot, alr);
+        const double qr = alr - beta, qi = ali;
+        const double qn = fast_rcp(ident ? 1.0 : qr * qr + qi * qi);
+        const double sr = ident ? 0.0 : qr * qn, si = ident ? 0.0 : -qi * qn;  // 1 / (alpha - beta)
+        const double tr = ident ? 0.0 : (beta - alr) * rbeta, ti = ident ? 0.0 : -ali * rbeta;
+        const double one = ident ? 0.0 : 1.0;
+        if (wv == 0 && lane == 0) Em[j] = ident ? alr : beta;
+        double vr = 0.0, vi = 0.0;
+        if (row > jn && row < n) {
+            vr = xme[0] * sr - xme[1] * si;
+            vi = xme[0] * si + xme[1] * sr;
+        } else if (row == jn) {
+            vr = one;
+        }
+        d2 vb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c = bc_col[b];
+            vb[b] = (d2){0.0, 0.0};
+            if (c > jn && c < n)
+                vb[b] = (d2){xb[b][0] * sr - xb[b][1] * si, xb[b][0] * si + xb[b][1] * sr};
+            else if (c == jn)
+                vb[b] = (d2){one, 0.0};
+        }
+
+        // partial p = A v over this wave's rows and columns
+        double par[2] = {0.0, 0.0}, pai[2] = {0.0, 0.0};
+        static_for<0, NT / TB>([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value * TB;
+            if (NW * (tb + TB) - 1 > j) {
+                static_for<0, TB>([&](auto uc) {
+                    constexpr int t = tb + decltype(uc)::value;
+                    fmac_bc<t & 15>(par[t & 1], vb[t >> 4][0], ar[t]);
+                    fmac_bc<t & 15>(pai[t & 1], vb[t >> 4][1], ar[t]);
+                    fnmac_bc<t & 15>(par[t & 1], vb[t >> 4][1], ai[t]);
+                    fmac_bc<t & 15>(pai[t & 1], vb[t >> 4][0], ai[t]);
+                });
+            }
+        });
+        {
+            const double p_r = par[0] + par[1], p_i = pai[0] + pai[1];
+            sp[q][row] = (d2){p_r, p_i};
+            const double share = wave_sum((row > j && row < n) ? (p_r * vr + p_i * vi) : 0.0);
+            if (lane == 0) srho[wv] = share;
+        }
+        wg_sync();  // B2: partial products and shares of rho of all eight waves
+        double ur = 0.0, ui = 0.0, rho = 0.0;
+        double ubr[NB], ubi[NB];
+        {
+            d2 t[NW], tb2[NB][NW];
+            double rs[2 * NW];
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) t[w2] = sp[w2][row];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) tb2[b][w2] = sp[w2][min(bc_col[b], NR - 1)];
+#pragma unroll
+            for (int w2 = 0; w2 < 2 * NW; ++w2) rs[w2] = srho[w2];
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) {
+                ur += t[w2][0];
+                ui += t[w2][1];
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                ubr[b] = ubi[b] = 0.0;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {
+                    ubr[b] += tb2[b][w2][0];
+                    ubi[b] += tb2[b][w2][1];
+                }
+                if (!(bc_col[b] > j && bc_col[b] < n)) ubr[b] = ubi[b] = 0.0;
+            }
+#pragma unroll
+            for (int w2 = 0; w2 < 2 * NW; ++w2) rho += rs[w2];
+            if (!(row > j && row < n)) ur = ui = 0.0;
+        }
+        // w = tau u - (|tau|^2 rho / 2) v  (kernel 1b)
+        const double a2 = -0.5 * (tr * tr + ti * ti) * rho;
+        const double wr = fma(a2, vr, ur * tr - ui * ti);
+        const double wi = fma(a2, vi, ur * ti + ui * tr);
+        d2 wb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            wb[b] = (d2){fma(a2, vb[b][0], ubr[b] * tr - ubi[b] * ti), fma(a2, vb[b][1], ubr[b] * ti + ubi[b] * tr)};
+
+        // A -= v w^H + w v^H on this wave's rows and columns; the owners of column j + 1 catch it on the way
+        double nxr = 0.0, nxi = 0.0;
+        static_for<0, NT / TB>([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value * TB;
+            if (NW * (tb + TB) - 1 > j) {
+                static_for<0, TB>([&](auto uc) {
+                    constexpr int t = tb + decltype(uc)::value;
+                    double r = ar[t], m = ai[t];
+                    fnmac_bc<t & 15>(r, wb[t >> 4][0], vr);
+                    fnmac_bc<t & 15>(m, wb[t >> 4][0], vi);
+                    fnmac_bc<t & 15>(r, wb[t >> 4][1], vi);
+                    fmac_bc<t & 15>(m, wb[t >> 4][1], vr);
+                    fnmac_bc<t & 15>(r, vb[t >> 4][0], wr);
+                    fnmac_bc<t & 15>(m, vb[t >> 4][0], wi);
+                    fnmac_bc<t & 15>(r, vb[t >> 4][1], wi);
+                    fmac_bc<t & 15>(m, vb[t >> 4][1], wr);
+                    ar[t] = r;
+                    ai[t] = m;
+                    if (t == tn) {  // uniform -- and kept a branch (the asm statement): as selects this was 4 VALU issues
+                        nxr = r;    // per column and step, a sixth of the loop
+                        nxi = m;
+                        asm volatile("" : "+v"(nxr), "+v"(nxi));
+                    }
+                });
+            }
+        });
+        if (own_next) publish(jn, nxr, nxi);
+    }
+    // hand-over: entry (i, c), i >= c, of the trailing block goes to the upper-triangle slot (c, i) of a 64 x 64 row-major
+    // matrix at the head of this matrix' storage, conjugated (both triangles are up to date here; the loads of H were
+    // consumed before the first barrier)
+    {
+        const int s0 = n_steps;
+        const int ldt = n - n_steps;
+        static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int c = NW * t + q;
+            if (c >= s0 && c < n && row >= c && row < n)
+                *reinterpret_cast<d2*>(Hm + ((size_t)(c - s0) * ldt + (row - s0)) * 2) = (d2){ar[t], -ai[t]};
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel 2: implicit QL with Wilkinson shift on 64 tridiagonals per wave (one per lane)
 // ------------------------------------------------------------------------------------------------
 
@@ -803,6 +1034,37 @@ static int launch_tridiag_33_64(hipStream_t s, double* d_H, int n, int64_t nk, d
 // n_full x n_full matrices, (d, e)[n_full - 64 ...] of every matrix.  No stage timer: the caller holds one.
 int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full, int64_t call_nk) {
     return launch_tridiag_33_64(s, d_H, 64, nk, d_D, d_E, (int64_t)n_full * n_full * 2, n_full, n_full - 64, call_nk);
+}
+
+// The first n - 64 Householder steps of nk n x n matrices, 64 < n <= 128, in the eight-wave register kernel; the trailing
+// 64 x 64 blocks are left at the head of every matrix' storage for tbk_launch_tridiag_tail64.  (d, e)[0 .. n - 65] of
+// matrix m to d_D / d_E + m * ldd + off.
+bool tbk_eig_reg128_supported(int n) {
+    static const bool on = !(getenv("TBK_REG128") && atoi(getenv("TBK_REG128")) == 0);  // measurements: 0 = streaming kernel
+    return on && n > 64 && n <= 128;
+}
+int tbk_launch_tridiag_reg128(hipStream_t s, double* d_H, int n, int64_t nk, double* d_D, double* d_E, int64_t h_stride, int ldd, int off) {
+    const dim3 grid((unsigned)nk);
+#define TBK_T8(NCV, NWV) \
+    hipLaunchKernelGGL((herm_tridiag8_kernel<NCV, NWV>), grid, dim3(NWV * 128), 0, s, d_H, n, d_D, d_E, n - 64, h_stride, ldd, off)
+    // up to 96 orbitals FOUR waves per matrix (two column residues: 48 complex per lane, ~250 registers): two matrices
+    // per CU, so that one's barriers and scalar chains run under the other's FMAs (TBK_REG128_NW2=0: eight waves)
+    static const bool nw2 = !(getenv("TBK_REG128_NW2") && atoi(getenv("TBK_REG128_NW2")) == 0);
+    if (n <= 80 && nw2)
+        TBK_T8(80, 2);
+    else if (n <= 80)
+        TBK_T8(80, 4);
+    else if (n <= 96 && nw2)
+        TBK_T8(96, 2);
+    else if (n <= 96)
+        TBK_T8(96, 4);
+    else if (n <= 112)
+        TBK_T8(112, 4);
+    else
+        TBK_T8(128, 4);
+#undef TBK_T8
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
 }
 
 // d_de holds the tridiagonal of every matrix: d[nk][n] followed by e[nk][n]

@@ -127,10 +127,11 @@ __device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1]
 template <int NU, int NB, int ST_THREADS>
 __global__ void __launch_bounds__(ST_THREADS)
 herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D, double* __restrict__ E, int n_steps) {
-    // n_steps = n - 1: the whole reduction.  n_steps = n - 64 (round 3): the first n - 64 Householder steps only; the
-    // trailing 64 x 64 block, brought up to date with the pending panel, is written over the head of this matrix' storage
-    // (row-major, leading dimension 64, upper triangle) and the register-resident kernels of tbk_eig_small.hip take over:
-    // a step costs ~17 k cycles here (a chain of barriers around a pass over memory) and ~2 k there.
+    // n_steps = n - 1: the whole reduction.  n_steps = n - T, T = 64 or 128 (round 3): the first n - T Householder steps
+    // only; the trailing T x T block, brought up to date with the pending panel, is written over the head of this matrix'
+    // storage (row-major, leading dimension T, upper triangle) and the register-resident kernels of tbk_eig_small.hip take
+    // over: a step costs ~17 k cycles here (a chain of barriers around a pass over memory), ~7 k in the eight-wave
+    // kernel (128 -> 64) and ~2 k in the kernels below 64.
     constexpr int ST_WAVES = ST_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) double st_smem[];
     constexpr int NP = 64 * NU;  // padded vector length
@@ -420,32 +421,40 @@ herm_tridiag_stream_kernel(double* __restrict__ H, int n, double* __restrict__ D
         TBK_CLK(6);
     }
     if (n_steps < n - 1) {
-        // hand-over: entry (i, c), i <= c, of the trailing block = stored element - the pending panel terms; everything is
-        // read into registers before anything is written (the target overlaps rows that are still being read)
+        // hand-over: entry (i, c), i <= c, of the trailing T x T block = stored element - the pending panel terms, written
+        // row-major with leading dimension T over the head of the matrix' storage.  The target overlaps rows that are
+        // still to be read, but target index t = i T + c always lies below its source index (s0 + i) n + s0 + c: in
+        // batches of ascending t, each read into registers before it is written, nothing is overwritten before it is read.
         const int s0 = n_steps;
-        constexpr int PER = 64 * 64 / ST_THREADS;
-        d2 keep[PER];
+        const int T = n - n_steps;
+        const int lgT = 31 - __builtin_clz((unsigned)T);  // T = 64 or 128
+        constexpr int PER = 8;
+        for (int base = 0; base < T * T; base += PER * ST_THREADS) {
+            d2 keep[PER];
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int idx = tid + t * ST_THREADS;
-            const int i = idx >> 6, c = idx & 63;
-            d2 a = (d2){0.0, 0.0};
-            if (i <= c) {
-                a = *reinterpret_cast<const d2*>(A + ((size_t)(s0 + i) * n + s0 + c) * 2);
-                for (int b = 0; b < p; ++b) {
-                    const d2 t1 = cmulc(sV[b * NP + s0 + i], sW[b * NP + s0 + c]);
-                    const d2 t2 = cmulc(sW[b * NP + s0 + i], sV[b * NP + s0 + c]);
-                    a[0] -= t1[0] + t2[0];
-                    a[1] -= t1[1] + t2[1];
+            for (int t = 0; t < PER; ++t) {
+                const int idx = base + tid + t * ST_THREADS;
+                const int i = idx >> lgT, c = idx & (T - 1);
+                d2 a = (d2){0.0, 0.0};
+                if (i <= c && i < T) {
+                    a = *reinterpret_cast<const d2*>(A + ((size_t)(s0 + i) * n + s0 + c) * 2);
+                    for (int b = 0; b < p; ++b) {
+                        const d2 t1 = cmulc(sV[b * NP + s0 + i], sW[b * NP + s0 + c]);
+                        const d2 t2 = cmulc(sW[b * NP + s0 + i], sV[b * NP + s0 + c]);
+                        a[0] -= t1[0] + t2[0];
+                        a[1] -= t1[1] + t2[1];
+                    }
                 }
+                keep[t] = a;
             }
-            keep[t] = a;
-        }
-        wg_sync();
+            wg_sync();
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int idx = tid + t * ST_THREADS;
-            if ((idx >> 6) <= (idx & 63)) *reinterpret_cast<d2*>(A + (size_t)idx * 2) = keep[t];
+            for (int t = 0; t < PER; ++t) {
+                const int idx = base + tid + t * ST_THREADS;
+                const int i = idx >> lgT, c = idx & (T - 1);
+                if (i <= c && i < T) *reinterpret_cast<d2*>(A + (size_t)idx * 2) = keep[t];
+            }
+            // (no barrier here: the sources of later batches lie above every target written so far)
         }
         return;
     }
@@ -791,8 +800,13 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
     // Round 3: the kernel stops after the first n - 64 steps and the register-resident kernels finish the trailing 64 x 64
     // block (tbk_launch_tridiag_tail64); TBK_STREAM_SPLIT=0: the whole reduction here (measurements).
     static const bool split_on = !(getenv("TBK_STREAM_SPLIT") && atoi(getenv("TBK_STREAM_SPLIT")) == 0);
-    const int n_steps = split_on ? n - 64 : n - 1;
-    if (n <= 128)
+    // above 128 orbitals: this kernel goes down to the trailing 128 x 128 block, the eight-wave register kernel to
+    // 64 x 64 (TBK_REG128=0: this kernel down to 64)
+    const bool via128 = split_on && n > 128 && tbk_eig_reg128_supported(128);
+    const int n_steps = via128 ? n - 128 : split_on ? n - 64 : n - 1;
+    if (split_on && tbk_eig_reg128_supported(n))  // round 3: 65 .. 128 orbitals never leave the registers
+        TBK_CHECK(tbk_launch_tridiag_reg128(s, d_H, n, nk, d_D, d_Eo, (int64_t)n * n * 2, n, 0));
+    else if (n <= 128)
         TBK_HIP((launch_stream<2, 4, 256>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else if (n <= 192)
         TBK_HIP((launch_stream<3, 8, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
@@ -802,6 +816,7 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
         TBK_HIP((launch_stream<6, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
     else
         TBK_HIP((launch_stream<8, 4, 512>(s, (unsigned)nk, d_H, n, d_D, d_Eo, n_steps)));
+    if (via128) TBK_CHECK(tbk_launch_tridiag_reg128(s, d_H, 128, nk, d_D, d_Eo, (int64_t)n * n * 2, n, n - 128));
     if (split_on) TBK_CHECK(tbk_launch_tridiag_tail64(s, d_H, nk, d_D, d_Eo, n, m->call_nk));
     return TBK_OK;
 }

@@ -294,6 +294,8 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
 bool tbk_eig_small_supported(int n);
 // (above 32 orbitals the head of every matrix in d_H is overwritten with its trailing 32 x 32 block: H is consumed)
 int tbk_launch_tridiag(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de);
+bool tbk_eig_reg128_supported(int n);  // 64 < n <= 128: the eight-wave register kernel does the first n - 64 steps
+int tbk_launch_tridiag_reg128(hipStream_t s, double* d_H, int n, int64_t nk, double* d_D, double* d_E, int64_t h_stride, int ldd, int off);
 int tbk_launch_tridiag_tail64(hipStream_t s, double* d_H, int64_t nk, double* d_D, double* d_E, int n_full, int64_t call_nk);  // tbk_eig_stream.hip hands over here
 // `beside_ql`: this launch shares the chip with another QL launch (the tail of the chunk pipeline): use
 // half-size workgroups (32 KiB of LDS) that fit next to two resident 64 KiB ones.

@@ -611,7 +611,7 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     il = np.tril_indices(n, -1)
     poisoned[:, il[0], il[1]] = np.nan
     d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(poisoned)
-    # the two-stage kernels at every size they handle (eigenval itself takes them from 161 orbitals on); the
+    # the two-stage kernels at every size they handle (eigenval itself takes them from 189 orbitals on); the
     # production choice and the forced one-stage path are compared below
     method = _lib.TBK_REDUCE_TWO_STAGE if n > 64 else _lib.TBK_REDUCE_AUTO
     _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), method, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
@@ -655,7 +655,7 @@ def test_two_stage_and_one_stage_reductions_agree():
     import tempfile
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r_vec, hop, pos = syn.dense_model_arrays(200, 6, syn.MODEL_SEED + 321)  # (above the crossover at 161 orbitals)
+    r_vec, hop, pos = syn.dense_model_arrays(200, 6, syn.MODEL_SEED + 321)  # (above the crossover at 189 orbitals)
     k = syn.random_kpoints(2600, seed=5)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     from tbmodels_amd import _lib
@@ -676,6 +676,47 @@ def test_two_stage_and_one_stage_reductions_agree():
         subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=300)
         other = np.load(out)
     assert 0.0 < np.abs(other - here).max() < 1e-11  # a different algorithm, the same spectrum
+
+
+@pytest.mark.parametrize("n_orb,switch", [(72, "TBK_REG128"), (96, "TBK_REG128_NW2"), (128, "TBK_REG128"), (150, "TBK_REG128"), (230, "TBK_REG128")])
+def test_register_cascade_agrees_with_the_streaming_kernel(n_orb, switch):
+    """65-128 orbitals never leave the registers (herm_tridiag8_kernel: four waves per matrix up to 96 orbitals, eight
+    above; 128 -> 64 rows), and above 128 the streaming kernel hands over its trailing 128 x 128 block.  TBK_REG128=0
+    (read once per process) keeps the streaming kernel down to 64 rows, TBK_REG128_NW2=0 the eight-wave form at every
+    size: same eigenvalues to rounding on a batch of several rounds of workgroups, and the oracle's on a sample.
+    (230 orbitals: the one-stage path on request, TBK_BAND=0 in both processes.)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nk = 1500 if n_orb <= 150 else 600
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import tbmodels_amd; from tbmodels_amd import synthetic as syn\n"
+        "r, h, p = syn.dense_model_arrays(%d, 5, syn.MODEL_SEED + 77)\n"
+        "m = tbmodels_amd.Model.from_packed(r, h, pos=p)\n"
+        "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(%d, seed=9)))\n" % (root, n_orb, nk)
+    )
+    results = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for value in (None, "0"):
+            out = os.path.join(tmp, "e%s.npy" % value)
+            env = dict(os.environ)
+            env.pop(switch, None)
+            if n_orb > 188:
+                env["TBK_BAND"] = "0"
+            if value is not None:
+                env[switch] = value
+            subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=300)
+            results.append(np.load(out))
+    assert results[0].shape == (nk, n_orb)
+    assert 0.0 < np.abs(results[0] - results[1]).max() < 1e-11  # different kernels, the same spectrum
+    r_vec, hop, _ = syn.dense_model_arrays(n_orb, 5, syn.MODEL_SEED + 77)
+    k = syn.random_kpoints(nk, seed=9)
+    idx = np.random.default_rng(3).choice(nk, 6, replace=False)
+    _close(results[0][idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
 def test_wave_solver_rejects_large_n():
