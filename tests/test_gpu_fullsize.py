@@ -227,7 +227,7 @@ def test_config4_grid_slabs_match_whole():
     assert np.abs(np.concatenate(again).reshape(-1, 16) - np.concatenate(parts)).max() == 0.0  # and deterministic
 
 
-@pytest.mark.parametrize("n_orb,n_r,n_k,reps", [(64, 256, 100_000, 12), (40, 64, 70_000, 8), (128, 32, 12_288, 6), (256, 16, 4_096, 4)])
+@pytest.mark.parametrize("n_orb,n_r,n_k,reps", [(64, 256, 100_000, 12), (40, 64, 70_000, 8), (96, 32, 24_576, 8), (128, 32, 12_288, 6), (256, 16, 4_096, 4)])
 def test_repeated_runs_are_bit_identical(n_orb, n_r, n_k, reps):
     """Fixed summation orders everywhere (no floating-point atomics): the same call gives the same bits every time.
     A race between the waves of a reduction workgroup or between the streams of the chunk pipeline shows up here
@@ -248,7 +248,9 @@ def test_two_stage_reduction_is_race_free(n_orb, n_k, reps):
     """The two-stage reduction (csrc/tbk_eig_band.hip) has a dozen phases per panel that meet at workgroup barriers and
     share LDS; a missing meeting shows up as a WRONG matrix once in ~10^5 (round 2: the last QR step's partial sums
     were overwritten by a wave that had run ahead -- 2 rows in 500 000, off by 1e-2).  Many repetitions of one call:
-    every row must come out bit-identical every time, and right."""
+    every row must come out bit-identical every time, and right.  (130 and 150 orbitals take the one-stage cascade since
+    round 3 -- streaming kernel, eight-wave register kernel, 64-row and packed kernels, each handing its trailing block
+    to the next through the head of the matrix' storage: the same kind of meeting points.)"""
     r_vec, hop, pos = syn.dense_model_arrays(n_orb, 16, syn.MODEL_SEED + n_orb)
     k = syn.random_kpoints(n_k, seed=n_orb)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
