@@ -307,6 +307,82 @@ def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
     }
 
 
+def hk_roofline_entry(arrays, n_orb, n_r, dim, stage_ms, stage_n, k_total, config, construct_only=False, peak_measured=None,
+                      with_traffic=False):
+    """The H(k) kernel of a config against the roofline that bounds it: executed FP64 flops of the MFMA
+    contraction for dense hoppings, compulsory output bytes against 8 TB/s for sparse ones.  stage_ms / stage_n: HIP-event
+    time and launches of the "hk" stage over the timed steps; k_total: k-points those steps evaluated."""
+    hk_launches = max(1, stage_n["hk"])
+    hk_ms_avg = stage_ms["hk"] / hk_launches
+    k_per_launch = k_total / hk_launches
+    secs = hk_ms_avg * 1e-3
+    if arrays["kind"] == "dense":
+        f_k = 8.0 * n_orb * n_orb * n_r + 2.0 * n_orb * n_orb  # SURVEY 8d: algorithmic flops per k-point
+        f_exec = 8.0 * (n_orb * (n_orb + 1) / 2) * n_r          # what the symmetrised contraction executes
+        algorithmic = f_k * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
+        executed = f_exec * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
+        traffic, traffic_src = (None, None)
+        if with_traffic:
+            traffic, traffic_src = measured_traffic("hk_dense", k_per_launch)
+        roofline = {
+            "kernel": "hk_dense_kernel", "bound": "mfma",
+            # the flops the matrix pipe EXECUTES: the staged operand is real and symmetrised, only the packed
+            # upper triangle is contracted (DESIGN.md section 3) -- half of SURVEY 8d's 8 N^2 N_R per k-point
+            "achieved": round(executed, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / FP64_MFMA_PEAK_TFLOPS, 4),
+            "peak_measured": peak_measured,
+            "frac_of_peak_measured": round(executed / peak_measured, 4) if peak_measured else None,
+            "achieved_algorithmic": round(algorithmic, 3),
+            "algorithmic_speedup": round(f_k / f_exec, 4),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE+WRITE_SIZE)",
+            "traffic_source": traffic_src,
+            "traffic_note": "builder-run PMC constant from profiles/ rescaled to this run's k-points per launch -- "
+                            "bench.py cannot read PMC counters; not a counter of this run" if traffic else None,
+            "hbm_frac": round(traffic / secs / 8.0e12, 4) if traffic and hk_ms_avg > 0 else None,
+            "algorithmic_bytes_per_launch": (16.0 * n_orb * (n_orb + 1) / 2 + 8 * dim) * k_per_launch
+                                            + 16.0 * n_orb * n_orb * n_r,
+            "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
+            "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
+        }
+        if config in ("cfg1", "cfg4"):
+            # mesh planes are evaluated on the folded model (csrc/tbk_fold.hip): the contraction executes ~13x
+            # fewer flops than the direct sum these figures price (cfg1: a handful of latency-bound launches)
+            roofline["note"] = ("folded / latency-bound evaluation: the flop figures would price the UNFOLDED sum, which the "
+                                "matrix pipe does not execute -- no fraction of peak is reported for this config; its "
+                                "dominant kernel is the n <= 64 reduction (DESIGN.md section 5.4 / 5.6)")
+            for key in ("achieved", "frac", "frac_of_peak_measured", "hbm_frac"):
+                roofline[key] = None
+        return roofline
+    # sparse: every packed element of H(k) is written once, 16 bytes (TRI mode: the upper triangle the eigensolver
+    # reads; FULL for hamilton()), plus the k-point itself -- SURVEY 8d's B_k without the solver's re-read
+    out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not construct_only else n_orb * n_orb)
+    b_k = out_bytes + 8 * dim
+    achieved = b_k * k_per_launch / secs / 1e9 if hk_ms_avg > 0 else 0.0
+    return {
+        "kernel": "hk_csr_lds_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
+        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+        "algorithmic_bytes_per_kpoint": b_k,
+        "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
+    }
+
+
+def single_k_latency(lib, model, k_slab, n_orb, calls=128, warm=8):
+    """Wall-clock of ONE-k-point calls on host buffers -- what Z2Pack-style callers do (_tb_model.py:1103-1108)."""
+    one_h = np.empty((1, n_orb, n_orb), dtype=np.complex128)
+    one_e = np.empty((1, n_orb))
+    single = {}
+    nk = len(k_slab)
+    for name, call in (("hamilton", lambda q: lib.tbk_hamilton(model, _lib.ptr(k_slab[q:q + 1]), 1, 2, None, _lib.ptr(one_h))),
+                       ("eigenval", lambda q: lib.tbk_eigenval(model, _lib.ptr(k_slab[q:q + 1]), 1, _lib.ptr(one_e)))):
+        for q in range(warm):
+            _lib.check(call(q % nk))
+        t1 = time.perf_counter()
+        for q in range(warm, warm + calls):
+            _lib.check(call(q % nk))
+        single[name] = round((time.perf_counter() - t1) / calls * 1e6, 1)
+    return single
+
+
 def config_kpoints(name, nk, dim):
     if name == "cfg1":
         return np.ascontiguousarray(synthetic.uniform_grid(10)[:nk])
@@ -315,7 +391,7 @@ def config_kpoints(name, nk, dim):
     return np.ascontiguousarray(np.random.default_rng(synthetic.K_SEED).random((nk, dim)))
 
 
-def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup=1):
+def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup=1, cpu_all=None):
     """
     One of the other BASELINE configs at its FULL size on this GPU, after the main clock and outside ``ms_per_step``:
     `steps` timed passes of tbk_eigenval_device_hint over the config's k list (resident in HBM), the stage times, the
@@ -353,16 +429,26 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         launches = (ctypes.c_int64 * _lib.TBK_T_COUNT)()
         _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
         stage_ms = {stage_name: ms[i] for i, stage_name in enumerate(_lib.STAGE_NAMES)}
+        stage_n = {stage_name: launches[i] for i, stage_name in enumerate(_lib.STAGE_NAMES)}
         eig = np.empty((nk, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig), d_e, eig.nbytes))
+        single = None
+        if os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
+            # (a one-k call at 512 orbitals takes ~10 ms: fewer of them)
+            single = single_k_latency(lib, model, k, n_orb, calls=32 if n_orb > 128 else 128, warm=4 if n_orb > 128 else 8)
+            _lib.check(lib.tbk_get_timing(model, None, None, 1))
     finally:
         lib.tbk_device_free(device, d_k)
         lib.tbk_device_free(device, d_e)
         if own:
             lib.tbk_model_destroy(model)
     trace_err = trace_identity_error(arrays, k, eig)
-    sample = {"cfg1": 64, "cfg3": 4, "cfg4": 16, "cfg5": 1}.get(name, 8)
-    _, _, cpu_eig = cpu_baseline(arrays, k, sample)  # the oracle as the checker
+    # the oracle as checker AND as this config's CPU baseline (cfg1 in full, a bounded sample of the
+    # others, linear in NK; one process = the reference's own usage).  TBK_BENCH_CPU_LIGHT=1: the checker's few rows only.
+    light = os.environ.get("TBK_BENCH_CPU_LIGHT") == "1"
+    sample = ({"cfg1": 64, "cfg3": 4, "cfg4": 16, "cfg5": 1} if light else
+              {"cfg1": 1000, "cfg3": 48, "cfg4": 256, "cfg5": 4}).get(name, 8)
+    cpu_rate, cpu_dt, cpu_eig = cpu_baseline(arrays, k, sample)
     parity = float(np.abs(cpu_eig - eig[:len(cpu_eig)]).max())
     entry = {
         "workload": "%s: %s N_orb=%d N_R=%d, %d %s k-points, eigenval (H(k)+eig), 1 GPU"
@@ -371,6 +457,15 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         "ms_per_step": round(elapsed / steps * 1e3, 3),
         "stage_ms_per_step": {key: round(v / steps, 3) for key, v in stage_ms.items()},
         "eig_roofline": eig_roofline_entry(n_orb, nk * steps, stage_ms["eig"], steps) if stage_ms["eig"] > 0 else None,
+        "roofline": hk_roofline_entry(arrays, n_orb, n_r, dim, stage_ms, stage_n, nk * steps, name),
+        "cpu_baseline": {
+            "value": round(cpu_rate, 3), "unit": "k-points/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d k-points of this workload, oracle/tbk_oracle.py (NumPy loop over R + scipy eigvalsh), "
+                      "one process, %.1f s" % (sample, nk, cpu_dt),
+            "host_cpus": os.cpu_count(),
+        },
+        "cpu_baseline_all_cores": cpu_all,
+        "single_k_us": single,
         "max_abs_err_vs_oracle": parity, "oracle_sample": sample,
         "max_trace_identity_err_4096_rows": trace_err,
         "model_build_and_staging_s": round(build_s, 2),
@@ -378,6 +473,116 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
     if not (parity <= 1e-10 and trace_err <= 1e-10):
         raise SystemExit("parity failure in %s: %r" % (name, entry))
     return entry
+
+
+def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays, steps=3, warmup=1):
+    """cfg4 at N ranks (every rank calls this): rank r evaluates rows slab_bounds(10^6, N, r) of the 100^3 mesh.  One step =
+    tbk_eigenval_device_gather (slab eigenvalues + pipelined all-gather into the [N][per][n] result on every rank) +
+    a wait for the communicator's stream; barrier on both sides of the timed steps, MAX over ranks.  Returns rank 0's
+    entry for ``configs.cfg4`` (None elsewhere)."""
+    from tbmodels_amd.sharding import slab_bounds  # pylint: disable=import-outside-toplevel
+
+    total = 100 ** 3
+    lo, hi = slab_bounds(total, world, rank)
+    per = -(-total // world)
+    k = np.ascontiguousarray(synthetic.grid_slab(100, lo, hi))
+    pointers = []
+
+    def dmalloc(nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(lib.tbk_device_malloc(device, max(int(nbytes), 8), ctypes.byref(p)))
+        pointers.append(p)
+        return p
+
+    def sync():
+        _lib.check(lib.tbk_comm_synchronize(comm))
+        _lib.check(lib.tbk_synchronize(model))
+
+    class _Alone:  # N = 1 (TBK_BENCH_FORCE_COMM=1): no process group
+        @staticmethod
+        def barrier():
+            return None
+
+        @staticmethod
+        def allreduce_max(x):
+            return x
+
+        @staticmethod
+        def all_gather_array(a):
+            return [a]
+
+    if group is None:
+        group = _Alone()
+    try:
+        d_k = dmalloc(k.nbytes)
+        d_all = dmalloc(world * per * n_orb * 8)
+        d_st = dmalloc(world * 8)
+        _lib.check(lib.tbk_memcpy_h2d(device, d_k, _lib.ptr(k), k.nbytes))
+        _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 0))
+
+        def step():
+            _lib.check(lib.tbk_eigenval_device_gather(comm, model, d_k, _lib.ptr(k), hi - lo, per, 0, d_all, d_st))
+
+        for _ in range(warmup):
+            step()
+        sync()
+        group.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        group.barrier()
+        elapsed = group.allreduce_max(time.perf_counter() - t0)
+        # one more step, split: this rank's kernels alone, then what the pipelined call adds on top (the exposed gather)
+        group.barrier()
+        t1 = time.perf_counter()
+        _lib.check(lib.tbk_eigenval_device_hint(model, d_k, _lib.ptr(k), hi - lo, d_all))
+        _lib.check(lib.tbk_synchronize(model))
+        compute_ms = (time.perf_counter() - t1) * 1e3
+        group.barrier()
+        t1 = time.perf_counter()
+        step()
+        sync()
+        call_ms = (time.perf_counter() - t1) * 1e3
+        parts = group.all_gather_array(np.array([compute_ms, call_ms]))
+        status = np.empty(world)
+        _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(status), d_st, status.nbytes))
+        if status.max() != 0:
+            raise SystemExit("cfg4 strong-scaling leg: status words %r" % (status,))
+        if rank != 0:
+            return None
+        # checks on rank 0, over rows of EVERY rank's slab: trace identity on 4096 rows of the whole mesh, oracle on the
+        # first rows of the first and the last slab
+        eig = np.empty((world * per, n_orb))
+        _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig), d_all, eig.nbytes))
+        k_all = synthetic.grid_slab(100, 0, total)
+        trace_err = trace_identity_error(arrays, k_all, eig[:total])
+        last_lo = slab_bounds(total, world, world - 1)[0]
+        rows = np.r_[0:8, last_lo:last_lo + 8]
+        _, _, cpu_eig = cpu_baseline(arrays, k_all[rows], len(rows))
+        parity = float(np.abs(cpu_eig - eig[rows]).max())
+        n_ranks = ctypes.c_int(0)
+        _lib.check(lib.tbk_comm_ranks(comm, ctypes.byref(n_ranks), None))
+        entry = {
+            "workload": "cfg4: dense N_orb=%d N_R=%d, 100^3 uniform mesh in %d contiguous slabs (one per GPU), eigenval + RCCL "
+                        "all-gather of the eigenvalues to every rank (pipelined behind the k chunks)" % (n_orb, len(arrays["R"]), world),
+            "value": round(total * steps / elapsed, 1), "unit": "k-points/s", "scaling": "strong", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "rccl_ranks": n_ranks.value, "kpoints_per_rank": per,
+            "per_rank": {"compute_ms": [round(float(p[0]), 3) for p in parts],
+                         "call_with_gather_ms": [round(float(p[1]), 3) for p in parts],
+                         "exposed_gather_ms": [round(float(p[1] - p[0]), 3) for p in parts],
+                         "note": "one extra step per rank: the slab's kernels alone (tbk_eigenval_device_hint), then the "
+                                 "pipelined call (tbk_eigenval_device_gather + wait): the difference is what the gather adds"},
+            "max_abs_err_vs_oracle": parity, "oracle_sample": len(rows),
+            "max_trace_identity_err_4096_rows": trace_err,
+        }
+        if not (parity <= 1e-10 and trace_err <= 1e-10):
+            raise SystemExit("parity failure in the cfg4 strong-scaling leg: %r" % (entry,))
+        return entry
+    finally:
+        for p in pointers:
+            lib.tbk_device_free(device, p)
 
 
 def main():
@@ -421,9 +626,17 @@ def main():
     k_slab = np.ascontiguousarray(k_slab)
 
     cpu_all = None
+    cpu_all_other = {}
+    per_proc_all = {"cfg1": 64, "cfg2": 256, "cfg3": 24, "cfg4": 256, "cfg5": 2}  # ~5-10 s each
+    run_others = (world == 1 and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr
+                  and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1")
     if rank == 0 and world == 1 and args.cpu_sample != 0 and not args.construct_only:
-        per_proc = {"cfg1": 64, "cfg2": 256, "cfg3": 24, "cfg4": 256, "cfg5": 2}[args.config]  # ~5-10 s
-        cpu_all = cpu_baseline_all_cores(arrays, k_slab, per_proc)
+        cpu_all = cpu_baseline_all_cores(arrays, k_slab, per_proc_all[args.config])
+        if run_others and os.environ.get("TBK_BENCH_CPU_LIGHT") != "1":
+            # all-core row of the sparse config too; it forks, so it runs here, before the GPU is touched
+            arrays3 = build_model_arrays("cfg3")
+            cpu_all_other["cfg3"] = cpu_baseline_all_cores(arrays3, config_kpoints("cfg3", CONFIGS["cfg3"][3], 3), per_proc_all["cfg3"])
+            del arrays3
 
     lib = _lib.lib()
     if _lib.device_count() < 1:
@@ -577,8 +790,15 @@ def main():
         per_rank = {"compute_ms": [round(float(p[0]), 3) for p in parts],
                     "allgather_ms": [round(float(p[1]), 3) for p in parts],
                     "note": "one step, not overlapped: eigenval on the rank's slab, then the RCCL all-gather alone"}
+    # --- N > 1, after the clock: BASELINE config 4, the one STRONG-scaling config -- the 100^3 mesh of the staged model in
+    # `world` contiguous slabs, every rank's slab evaluated into its rows of the full result with the RCCL all-gather of
+    # finished row blocks pipelined behind the k chunks (tbk_eigenval_device_gather), the gather INSIDE the timing ---------
+    strong = None
+    if comm is not None and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr \
+            and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1":  # (N = 1 with TBK_BENCH_FORCE_COMM=1: a one-rank communicator)
+        strong = strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays)
     host_api = None
-    if world == 1 and rank == 0 and not args.construct_only:
+    if world == 1 and rank == 0 and not args.construct_only and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
         # SURVEY 8(d) "Evidence": wall-clock through the drop-in surface -- host k in, host eigenvalues out (H2D of k,
         # all kernels, the non-finite check, D2H), i.e. tbk_eigenval, what Model.eigenval_array calls; plus the
         # reference's return type (a Python list of row arrays, _tb_model.py:1148-1150)
@@ -592,17 +812,7 @@ def main():
         dt_list = time.perf_counter() - t1
         del as_list
         # Z2Pack-style callers evaluate ONE k-point per call (_tb_model.py:1103-1108): wall-clock of such calls
-        one_h = np.empty((1, n_orb, n_orb), dtype=np.complex128)
-        one_e = np.empty((1, n_orb))
-        single = {}
-        for name, call in (("hamilton", lambda q: lib.tbk_hamilton(model, _lib.ptr(k_slab[q:q + 1]), 1, 2, None, _lib.ptr(one_h))),
-                           ("eigenval", lambda q: lib.tbk_eigenval(model, _lib.ptr(k_slab[q:q + 1]), 1, _lib.ptr(one_e)))):
-            for q in range(8):
-                _lib.check(call(q))
-            t1 = time.perf_counter()
-            for q in range(8, 136):
-                _lib.check(call(q))
-            single[name] = round((time.perf_counter() - t1) / 128 * 1e6, 1)
+        single = single_k_latency(lib, model, k_slab, n_orb, calls=32 if n_orb > 128 else 128, warm=4 if n_orb > 128 else 8)
         host_api = {
             "value": round(nk_gpu / dt_call, 1), "unit": "k-points/s", "ms_per_call": round(dt_call * 1e3, 3),
             "single_k_us": single,
@@ -635,59 +845,9 @@ def main():
     if rank == 0:
         total_k = world * nk_gpu * args.steps
         value = total_k / elapsed
-        # algorithmic work per k-point, SURVEY.md section 8(d): dense 8 N^2 N_R + 2 N^2 flops
-        if arrays["kind"] == "dense":
-            f_k = 8.0 * n_orb * n_orb * n_r + 2.0 * n_orb * n_orb
-            f_exec = 8.0 * (n_orb * (n_orb + 1) / 2) * n_r  # what the symmetrised contraction executes
-        else:
-            nnz = int(arrays["r_ptr"][-1])
-            f_k = 8.0 * nnz + 2.0 * n_orb * n_orb
-            f_exec = f_k
-        hk_launches = max(1, stage_n["hk"])
-        hk_ms_avg = stage_ms["hk"] / hk_launches
-        k_per_launch = nk_gpu * args.steps / hk_launches
-        if arrays["kind"] == "dense":
-            secs = hk_ms_avg * 1e-3
-            algorithmic = f_k * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
-            executed = f_exec * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
-            traffic, traffic_src = (None, None)
-            if args.config == "cfg2" and not args.nr:
-                traffic, traffic_src = measured_traffic("hk_dense", k_per_launch)
-            roofline = {
-                "kernel": "hk_dense_kernel", "bound": "mfma",
-                # the flops the matrix pipe EXECUTES: the staged operand is real and symmetrised, only the packed
-                # upper triangle is contracted -- half of SURVEY 8d's 8 N^2 N_R per k-point
-                "achieved": round(executed, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(executed / FP64_MFMA_PEAK_TFLOPS, 4),
-                "peak_measured": peak_measured,
-                "frac_of_peak_measured": round(executed / peak_measured, 4) if peak_measured else None,
-                "achieved_algorithmic": round(algorithmic, 3),
-                "algorithmic_speedup": round(f_k / f_exec, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE+WRITE_SIZE)",
-                "traffic_source": traffic_src,
-                "hbm_frac": round(traffic / secs / 8.0e12, 4) if traffic and hk_ms_avg > 0 else None,
-                "algorithmic_bytes_per_launch": (16.0 * n_orb * (n_orb + 1) / 2 + 8 * dim) * k_per_launch
-                                                + 16.0 * n_orb * n_orb * n_r,
-                "flops_per_kpoint_algorithmic": f_k, "flops_per_kpoint_executed": f_exec,
-                "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
-            }
-            if args.config == "cfg4":
-                # mesh planes are evaluated on the folded model (csrc/tbk_fold.hip): the contraction executes ~13x
-                # fewer flops than the direct sum these figures price
-                roofline["note"] = ("folded evaluation: the flop figures would price the UNFOLDED sum, which the matrix "
-                                    "pipe does not execute -- no fraction of peak is reported for this config; its "
-                                    "dominant kernel is the n <= 64 reduction (DESIGN.md section 5.4 / 5.6)")
-                for key in ("achieved", "frac", "frac_of_peak_measured", "hbm_frac"):
-                    roofline[key] = None
-        else:
-            out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not args.construct_only else n_orb * n_orb)
-            b_k = out_bytes + 8 * dim
-            achieved = b_k * k_per_launch / (hk_ms_avg * 1e-3) / 1e9 if hk_ms_avg > 0 else 0.0
-            roofline = {
-                "kernel": "hk_csr_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
-                "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
-            }
+        roofline = hk_roofline_entry(arrays, n_orb, n_r, dim, stage_ms, stage_n, nk_gpu * args.steps, args.config,
+                                     construct_only=args.construct_only, peak_measured=peak_measured,
+                                     with_traffic=(args.config == "cfg2" and not args.nr))
 
         # the reduction to tridiagonal form (the dominant kernel of the configs above 64 orbitals): (16/3) n^3 flops per
         # matrix (eigensolve, values only) over the HIP-event time of the reduction stage on its own stream
@@ -717,13 +877,16 @@ def main():
         # the other BASELINE configs at full size, after the clock (not part of value / ms_per_step): the cfg2 model on
         # the 100^3 mesh (cfg4, this GPU's share at N = 1 = the whole mesh) reuses the staged handle
         other = None
-        if (world == 1 and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr
-                and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1"):
+        if run_others:
             other = {}
             _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_AUTO))
             other["cfg4"] = run_other_config(lib, device, "cfg4", model=model, arrays=arrays)
             for name in ("cfg1", "cfg3", "cfg5"):
-                other[name] = run_other_config(lib, device, name)
+                other[name] = run_other_config(lib, device, name, cpu_all=cpu_all_other.get(name))
+            if strong is not None:
+                other["cfg4_one_rank_communicator"] = strong
+        elif strong is not None:
+            other = {"cfg4": strong}
         result = {
             "metric": "k-points/sec (H(k)+eig) at N_orb=%d, N_R=%d" % (n_orb, n_r) if not args.construct_only
                       else "k-points/sec (H(k) construction only) at N_orb=%d, N_R=%d" % (n_orb, n_r),

@@ -153,6 +153,10 @@ int tbk_kdotp_create(int device, int dim, int n_orb, int64_t n_p, const int32_t*
 void tbk_kdotp_destroy(tbk_kdotp* m);
 int tbk_kdotp_hamilton(tbk_kdotp* m, const double* k, int64_t nk, double* H_out);
 int tbk_kdotp_eigenval(tbk_kdotp* m, const double* k, int64_t nk, double* E_out);
+/* The same on several devices from one process: staged copies of ONE k.p model, contiguous k slabs, one host thread
+ * per non-empty slab -- tbk_eigenval_multi / tbk_hamilton_multi for kdotp.py:51-100. */
+int tbk_kdotp_eigenval_multi(tbk_kdotp* const* handles, int n_handles, const double* k, int64_t nk, double* E_out);
+int tbk_kdotp_hamilton_multi(tbk_kdotp* const* handles, int n_handles, const double* k, int64_t nk, double* H_out);
 
 /* Model.construct_kdotp (_tb_model.py:942-982): Taylor coefficients of H(k) around k0 for n_p power
  * tuples.  powers: int32 [n_p][dim]; prefactor: double [n_p][2] = (2 pi i)^{|p|} / prod p_d! as (re, im);
@@ -194,6 +198,24 @@ int tbk_comm_allgather_f64_overlapped(tbk_comm* c, tbk_model* m, const double* d
                                       int64_t count, int slot);
 int tbk_comm_wait_slot(tbk_comm* c, tbk_model* m, int slot);
 int tbk_comm_synchronize(tbk_comm* c);
+/* Agreement in front of a sharded call: every rank contributes `status` (0 = ready to take part), verdict[world]
+ * (HOST) receives every rank's word.  One 8-byte all-gather through buffers the communicator owns since its
+ * creation; synchronous.  A rank whose staging / allocation failed reports it HERE, and nobody enters the data
+ * collectives (a rank raising alone in front of a collective leaves its peers hanging in it). */
+int tbk_comm_agree(tbk_comm* c, int status, double* verdict);
+/* One sharded eigenvalue call with the gather pipelined behind the k chunks (replaces the per-process body of a
+ * multiprocessing farm over Model.eigenval, _tb_model.py:1134-1150; k-points are independent, :1111-1123).
+ * Every rank calls it with the SAME `per` (slab length in k-points = ceil(NK / world)) and its own nk <= per k-points
+ * (d_k / h_k as in tbk_eigenval_device_hint).  d_all[world][per][n_orb] (device) receives the eigenvalues of ALL ranks in
+ * rank = caller order: this rank's rows are computed in place, and while later k chunks compute, finished blocks of
+ * rows are all-gathered on the communicator's stream and moved to their places; rows nk..per of a short slab are
+ * zero.  host_status != 0: this rank computes nothing and reports that status (a failure in front of the call).
+ * d_status_all[world] (device) receives every rank's tbk_status as doubles (the solvers' non-finite / convergence
+ * flags included; they are consumed) -- the last collective of the call, so every rank sees the same verdict.
+ * Everything is enqueued: tbk_comm_synchronize(c) waits for the result, and `m`'s main stream waits for the gathers
+ * before any later call touches the buffers. */
+int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const double* d_k, const double* h_k, int64_t nk, int64_t per,
+                               int host_status, double* d_all, double* d_status_all);
 
 /* ---- microbenchmark: sustained v_mfma_f64_16x16x4_f64 rate of the device (TFLOP/s) -------- */
 int tbk_mfma_f64_peak(int device, double* tflops);

@@ -63,6 +63,8 @@ SIGNATURES = {
     "tbk_kdotp_destroy": (None, [_vp]),
     "tbk_kdotp_hamilton": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "tbk_kdotp_eigenval": (_c_int, [_vp, _vp, _c_i64, _vp]),
+    "tbk_kdotp_eigenval_multi": (_c_int, [_vp, _c_int, _vp, _c_i64, _vp]),
+    "tbk_kdotp_hamilton_multi": (_c_int, [_vp, _c_int, _vp, _c_i64, _vp]),
     "tbk_kdotp_coefficients": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _vp]),
     "tbk_device_malloc": (_c_int, [_c_int, _c_i64, _pp]),
     "tbk_device_free": (_c_int, [_c_int, _vp]),
@@ -78,6 +80,8 @@ SIGNATURES = {
     "tbk_comm_allgather_f64_overlapped": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int]),
     "tbk_comm_wait_slot": (_c_int, [_vp, _vp, _c_int]),
     "tbk_comm_synchronize": (_c_int, [_vp]),
+    "tbk_comm_agree": (_c_int, [_vp, _c_int, _vp]),
+    "tbk_eigenval_device_gather": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
     "tbk_mfma_f64_peak": (_c_int, [_c_int, ctypes.POINTER(ctypes.c_double)]),
 }
 

@@ -186,7 +186,9 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_tri[b], hipEventDisableTiming)));
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_ql[b], hipEventDisableTiming)));
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_out[b], hipEventDisableTiming)));
-        if (b == 0) TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_sync, hipEventDisableTiming)));
+        // (release to system scope: results of small calls are read by the CPU from non-coherent pinned memory right
+        // behind hipEventSynchronize on this event -- with a default event that visibility is the runtime's choice)
+        if (b == 0) TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_sync, hipEventDisableTiming | hipEventReleaseToSystem)));
     }
     TBK_TRY(TBK_ROCBLAS(rocblas_create_handle(&m->blas)));
     TBK_TRY(TBK_ROCBLAS(rocblas_set_stream(m->blas, m->stream)));
@@ -628,7 +630,12 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
             TBK_CHECK(tbk_launch_tridiag(m, m->stream, d_H, nk, d_de));
         else
             TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream, d_H, nk, d_de));
-        return launch_tridiag_eigenvalues(m, m->stream, d_de, nk, d_E, false, small_call);
+        TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream, d_de, nk, d_E, false, small_call));
+        if (m->chunk_done) {
+            TBK_HIP(hipEventRecord(m->ev_ql[0], m->stream));
+            TBK_CHECK(m->chunk_done(0, nk, m->ev_ql[0]));
+        }
+        return TBK_OK;
     }
     int64_t prev_c0 = 0, prev_nkc = 0, c0 = 0;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -668,6 +675,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
                                                  d_E + (size_t)prev_c0 * n, false, small_call,
                                                  two_stage ? m->ws_bandmat[b ^ 1].ptr : nullptr));
             TBK_HIP(hipEventRecord(m->ev_ql[b ^ 1], m->stream_ql));
+            if (m->chunk_done) TBK_CHECK(m->chunk_done(prev_c0, prev_nkc, m->ev_ql[b ^ 1]));
         }
         prev_c0 = c0;
         prev_nkc = nkc;
@@ -681,6 +689,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
                                              d_E + (size_t)prev_c0 * n, n_chunks > 1,
                                              small_call || n_chunks > 1, two_stage ? m->ws_bandmat[b].ptr : nullptr));
         TBK_HIP(hipEventRecord(m->ev_ql[b], m->stream_eig));
+        if (m->chunk_done) TBK_CHECK(m->chunk_done(prev_c0, prev_nkc, m->ev_ql[b]));
     }
     // later work on the main stream (gather, D2H, the next call) sees the finished eigenvalues
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) TBK_HIP(hipStreamWaitEvent(m->stream, m->ev_ql[b], 0));
@@ -929,9 +938,13 @@ static int eigenval_device_solve(tbk_model* m, const double* d_k, const double* 
         return eigenval_wave_pipeline(m, d_k, nk, d_E);
     }
 
-    const int64_t chunk = choose_chunk(m, nk, true);
+    int64_t chunk = choose_chunk(m, nk, true);
     const size_t nn2 = (size_t)m->n_orb * m->n_orb * 2;
-    // rocSOLVER path: TBK_EIG_ROCSOLVER, or n_orb > 512
+    // rocsolver_zheevd_strided_batched faulted (memory access fault inside the library) on 2048 matrices of 768 / 1024
+    // orbitals -- 1.2e9 / 2.1e9 complex elements in one call -- and ran 2048 x 640 (8.4e8): calls are kept below 2^29
+    // elements
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, (int64_t(1) << 29) / std::max<int64_t>(1, (int64_t)m->n_orb * m->n_orb)));
+    // rocSOLVER path: TBK_EIG_ROCSOLVER, or n_orb above the own solvers' range
     for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
         const int64_t nkc = std::min(chunk, nk - c0);
         const int64_t nk_pad = phase_ld(nkc);

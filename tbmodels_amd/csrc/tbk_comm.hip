@@ -8,6 +8,8 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -21,6 +23,11 @@ struct tbk_comm {
     hipStream_t stream = nullptr;  // collectives that overlap the next batch's kernels run here
     hipEvent_t ready = nullptr;    // "the send buffer is complete" on the model's stream
     hipEvent_t done[2] = {nullptr, nullptr};  // gather of buffer slot 0 / 1 finished
+    // chunk-pipelined gather of one call (tbk_eigenval_device_gather)
+    double* d_stage = nullptr;      // [world][block rows * n_orb] landing area of one block's all-gather
+    size_t stage_bytes = 0;
+    double* d_status = nullptr;     // [1 + world] this rank's status word, then everybody's
+    hipEvent_t tail = nullptr;      // "the main stream has everything of the call behind it"
 };
 
 #define TBK_NCCL(expr)                                                                           \
@@ -67,7 +74,9 @@ extern "C" int tbk_comm_create(int device, int world_size, int rank, const void*
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->tail, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void**)&c->d_status, (size_t)(1 + world_size) * sizeof(double)) != hipSuccess) {
         tbk_set_error("cannot create the communicator's stream / event");
         tbk_comm_destroy(c);
         return TBK_ERR_DEVICE;
@@ -84,6 +93,9 @@ extern "C" void tbk_comm_destroy(tbk_comm* c) {
     if (c->ready) (void)hipEventDestroy(c->ready);
     for (hipEvent_t e : c->done)
         if (e) (void)hipEventDestroy(e);
+    if (c->tail) (void)hipEventDestroy(c->tail);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_status) (void)hipFree(c->d_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -151,4 +163,145 @@ extern "C" int tbk_comm_synchronize(tbk_comm* c) {
     TBK_HIP(hipSetDevice(c->device));
     TBK_HIP(hipStreamSynchronize(c->stream));
     return TBK_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// One sharded eigenvalue call with the gather pipelined behind the k chunks (BASELINE config 4: the 10^6-point mesh
+// in 8 slabs is 13 ms of kernels per rank -- a 3 ms all-gather at the end of the call, with nothing to hide under,
+// would be a fifth of the step).
+//
+// d_all is the RESULT in caller order: [world][per][n_orb], rank r's slab at row r * per.  This rank evaluates its
+// nk <= per k-points straight into its own rows; the slab is cut into blocks of B rows (B from per and n_orb alone, so
+// every rank cuts alike whatever its chunk pipeline does), and as soon as the chunk pipeline has enqueued the
+// eigenvalues of a whole block (tbk_model::chunk_done) the communicator's stream waits for that chunk's event, gathers
+// the block from every rank into a landing area ([rank][block], what ncclAllGather writes) and a copy kernel moves the
+// ranks' pieces to their rows of d_all -- while the next chunk computes.  Only the last block's gather is exposed.
+// Rows nk..per of a short slab are zero.  The status word (this rank's `host_status`, else what the solvers' flag words
+// say: non-finite / no convergence) is gathered LAST, one double per rank, so that every rank sees every rank's status
+// and all raise alike; d_status_all[world] (device) receives it.  Everything is enqueued; tbk_comm_synchronize waits.
+// Reference invariants: k-points are independent (_tb_model.py:1111-1123), results in the order of k (:1148-1150).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256) gather_place_kernel(const double2* __restrict__ stage, double2* __restrict__ all, int64_t block_pairs,
+                                                           int64_t slab_pairs, int64_t offset_pairs) {
+    // piece r of the landing area -> rows [r * per + b0, ...) of the result; 16 bytes per thread and trip
+    const int r = blockIdx.y;
+    const double2* src = stage + (size_t)r * block_pairs;
+    double2* dst = all + (size_t)r * slab_pairs + offset_pairs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < block_pairs; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+__global__ void status_word_kernel(int* __restrict__ flag, int host_status, double* __restrict__ word) {
+    int st = host_status;
+    if (st == 0 && flag != nullptr) st = flag[1] != 0 ? TBK_ERR_NOT_FINITE : (flag[0] != 0 ? TBK_ERR_NO_CONVERGENCE : 0);
+    if (flag != nullptr) flag[0] = flag[1] = 0;
+    *word = (double)st;
+}
+
+}  // namespace
+
+int64_t tbk_gather_block_rows(int64_t per, int n_orb) {
+    // ~4 MiB per rank and block (8192 rows at 64 orbitals): small enough that the exposed last gather is a few hundred
+    // microseconds at 8 ranks, large enough that a gather is bandwidth, not latency; an even row count (16-byte copies)
+    int64_t rows = std::max<int64_t>(64, (int64_t(4) << 20) / (8 * (int64_t)std::max(n_orb, 1)));
+    // TBK_GATHER_BLOCK_ROWS: tests / measurements only (every rank of a run must see the same value)
+    if (const char* env = getenv("TBK_GATHER_BLOCK_ROWS"))
+        if (atoll(env) > 0) rows = atoll(env);
+    rows = std::min(rows, std::max<int64_t>(per, 1));
+    return rows;
+}
+
+// Agreement in front of a sharded call: every rank contributes its status (0 = ready), everybody receives all of them
+// on the HOST -- one 8-byte all-gather through buffers that exist since tbk_comm_create, so nothing of it can fail on
+// one rank alone.  Synchronous (the caller decides on the verdict before it enters the data collectives).
+extern "C" int tbk_comm_agree(tbk_comm* c, int status, double* verdict) {
+    TBK_ARG(c != nullptr && verdict != nullptr, "comm / verdict is NULL");
+    TBK_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(status_word_kernel, dim3(1), dim3(1), 0, c->stream, (int*)nullptr, status, c->d_status);
+    TBK_HIP(hipGetLastError());
+    TBK_NCCL(ncclAllGather(c->d_status, c->d_status + 1, 1, ncclDouble, c->comm, c->stream));
+    TBK_HIP(hipMemcpyAsync(verdict, c->d_status + 1, (size_t)c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    return TBK_OK;
+}
+
+extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const double* d_k, const double* h_k, int64_t nk, int64_t per,
+                                          int host_status, double* d_all, double* d_status_all) {
+    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
+    TBK_ARG(per >= 0 && nk >= 0 && nk <= per, "need 0 <= nk <= per");
+    TBK_ARG(d_all != nullptr || per == 0, "result is NULL");
+    TBK_ARG(d_status_all != nullptr, "status array is NULL");
+    TBK_ARG(m->device == c->device, "model and communicator live on different devices");
+    TBK_LOCK(m);  // the hook below belongs to this call alone
+    TBK_HIP(hipSetDevice(c->device));
+    const int64_t n = m->n_orb;
+    const int64_t slab = per * n;                       // doubles per rank
+    const int64_t B = tbk_gather_block_rows(per, (int)n);
+    const int64_t n_blocks = per > 0 ? (per + B - 1) / B : 0;
+    double* mine = d_all + (size_t)c->rank * slab;
+    const bool compute = host_status == 0 && nk > 0;
+    // rows this rank does not compute are zero (short or empty slab, or a rank that arrives with a failure)
+    const int64_t first_idle = compute ? nk : 0;
+    if (per > first_idle)
+        TBK_HIP(hipMemsetAsync(mine + (size_t)first_idle * n, 0, (size_t)(per - first_idle) * n * sizeof(double), m->stream));
+    const size_t want = (size_t)c->world * (size_t)B * n * sizeof(double);
+    if (want > c->stage_bytes) {  // (grow-only; the first call of a shape pays the allocation)
+        if (c->d_stage) TBK_HIP(hipFree(c->d_stage));
+        c->d_stage = nullptr;
+        c->stage_bytes = 0;
+        TBK_HIP(hipMalloc((void**)&c->d_stage, want));
+        c->stage_bytes = want;
+    }
+    int64_t next_block = 0;
+    const bool ranged = m->timing;
+    auto send_blocks = [&](int64_t rows_done) -> int {  // every block that ends at or before rows_done
+        while (next_block < n_blocks && std::min(per, (next_block + 1) * B) <= rows_done) {
+            const int64_t b0 = next_block * B, rows = std::min(per, b0 + B) - b0;
+            const int64_t count = rows * n;
+            if (ranged) tbk_range_push("tbk:allgather_eigenvalues(block)");
+            const ncclResult_t r = ncclAllGather(mine + (size_t)b0 * n, c->d_stage, (size_t)count, ncclDouble, c->comm, c->stream);
+            if (ranged) tbk_range_pop();
+            TBK_NCCL(r);
+            if (((count | slab | (b0 * n)) & 1) == 0) {  // 16-byte copies when every piece starts on an even double
+                const int64_t pairs = count / 2;
+                const unsigned gx = (unsigned)std::min<int64_t>((pairs + 255) / 256, 512);
+                hipLaunchKernelGGL(gather_place_kernel, dim3(gx, (unsigned)c->world), dim3(256), 0, c->stream,
+                                   reinterpret_cast<const double2*>(c->d_stage), reinterpret_cast<double2*>(d_all), pairs, slab / 2,
+                                   b0 * n / 2);
+                TBK_HIP(hipGetLastError());
+            } else {
+                for (int r2 = 0; r2 < c->world; ++r2)
+                    TBK_HIP(hipMemcpyAsync(d_all + (size_t)r2 * slab + (size_t)b0 * n, c->d_stage + (size_t)r2 * count,
+                                           (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            }
+            ++next_block;
+        }
+        return TBK_OK;
+    };
+    int rc = TBK_OK;
+    if (compute) {
+        m->chunk_done = [&](int64_t c0, int64_t nkc, hipEvent_t done) -> int {
+            // rows below c0 + nkc of this rank's slab are final once `done` has fired (chunks complete in order)
+            TBK_HIP(hipStreamWaitEvent(c->stream, done, 0));
+            return send_blocks(c0 + nkc);
+        };
+        rc = tbk_eigenval_device_hint(m, d_k, h_k, nk, mine);
+        m->chunk_done = nullptr;
+    }
+    // whatever is left -- the zero rows of a short slab, paths without chunk events (rocSOLVER), a call that failed on
+    // the way: the peers are waiting in the same sequence of collectives -- goes behind the main stream
+    TBK_HIP(hipEventRecord(c->tail, m->stream));
+    TBK_HIP(hipStreamWaitEvent(c->stream, c->tail, 0));
+    const int rc2 = send_blocks(per);
+    const int status = host_status != 0 ? host_status : (rc != TBK_OK ? rc : rc2);
+    hipLaunchKernelGGL(status_word_kernel, dim3(1), dim3(1), 0, c->stream, m->ws_flag.as<int>(), status, c->d_status);
+    TBK_HIP(hipGetLastError());
+    TBK_NCCL(ncclAllGather(c->d_status, c->d_status + 1, 1, ncclDouble, c->comm, c->stream));
+    TBK_HIP(hipMemcpyAsync(d_status_all, c->d_status + 1, (size_t)c->world * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    // the next call on the model's streams must not overwrite rows a gather is still reading
+    TBK_HIP(hipEventRecord(c->done[0], c->stream));
+    TBK_HIP(hipStreamWaitEvent(m->stream, c->done[0], 0));
+    return rc != TBK_OK ? rc : rc2;
 }

@@ -639,7 +639,6 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
                     asm volatile("" ::: "memory");
                     TBK_CLK(9);
-                    d4 p1 = (d4){0.0, 0.0, 0.0, 0.0}, p2 = p1, q1 = p1, q2 = p1;
                     if (diag) {
                         // Hermitian tile of which only the upper part is valid: operand element [i = lrow][j = lq + 4 sg]
                         // is the transposed copy where i <= j, the conjugate of the accumulator element otherwise
@@ -648,33 +647,30 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                             const bool upper = lrow <= lq + 4 * sg;
                             const double ar = upper ? ttre[sg] : tre[sg];
                             const double ai = upper ? ttim[sg] : -tim[sg];
-                            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, own_b[sg], p1, 0, 0, 0);
-                            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, own_b[sg], p2, 0, 0, 0);
+                            own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, own_b[sg], own1, 0, 0, 0);
+                            own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, own_b[sg], own2, 0, 0, 0);
                         }
-                        own1 += p1;
-                        own2 += p2;
                     } else {
-                        // row part  X_Ir += tile Vn_Jc ;  column part  X_Jc += tile^H Vn_Ir
-                        const double* b_col = own_is_row ? par_b : own_b;  // Vn of the column block
-                        const double* b_row = own_is_row ? own_b : par_b;  // Vn of the row block
-#pragma unroll
-                        for (int sg = 0; sg < 4; ++sg) {
-                            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], b_col[sg], p1, 0, 0, 0);
-                            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], b_col[sg], p2, 0, 0, 0);
-                            q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], b_row[sg], q1, 0, 0, 0);
-                            q2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], b_row[sg], q2, 0, 0, 1);  // conj
-                        }
-                        d4 o1, o2;
+                        // row part  X_Ir += tile Vn_Jc ;  column part  X_Jc += tile^H Vn_Ir.  The own block's part is
+                        // accumulated by the MFMAs themselves (round 4: separate product registers added afterwards were
+                        // 16 more live registers and 8 more vector-unit adds per visit); the partner's part goes to LDS
+                        d4 o1 = (d4){0.0, 0.0, 0.0, 0.0}, o2 = o1;
                         if (own_is_row) {
-                            own1 += p1;
-                            own2 += p2;
-                            o1 = q1;
-                            o2 = q2;
+#pragma unroll
+                            for (int sg = 0; sg < 4; ++sg) {
+                                own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], par_b[sg], own1, 0, 0, 0);
+                                own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], par_b[sg], own2, 0, 0, 0);
+                                o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], own_b[sg], o1, 0, 0, 0);
+                                o2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], own_b[sg], o2, 0, 0, 1);  // conj
+                            }
                         } else {
-                            own1 += q1;
-                            own2 += q2;
-                            o1 = p1;
-                            o2 = p2;
+#pragma unroll
+                            for (int sg = 0; sg < 4; ++sg) {
+                                o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], own_b[sg], o1, 0, 0, 0);
+                                o2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], own_b[sg], o2, 0, 0, 0);
+                                own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], par_b[sg], own1, 0, 0, 0);
+                                own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], par_b[sg], own2, 0, 0, 1);  // conj
+                            }
                         }
                         // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
                         double* xs = reinterpret_cast<double*>(sX);
@@ -921,6 +917,16 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
                 }
             }
+            // hand-over of Vn (LDS or global) HERE, in front of the T block: nobody reads it before the pass, and with the
+            // rows of V dead the eight lanes that build T (28 Gram sums + tau + a row of T: 176 registers) fit
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int i_row = row_of(rr);
+                if (i_row < npad) {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) sVn[(size_t)i_row * PB + c] = vn[rr][c];
+                }
+            }
             wg_finish<NW>(56, sPart, sTot, tid);
             // lane a of the first wave builds row a of T: T[a][c] = -tau_c sum_{c2 = a}^{c - 1} T[a][c2] G[c2][c]
             if (tid < PB) {
@@ -947,15 +953,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
         }
         TBK_CLK(2);
-        // ---- hand over: Vn (LDS or global), X cleared, the consumed pending rows zeroed ----
-#pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const int i_row = row_of(rr);
-            if (i_row < npad) {
-#pragma unroll
-                for (int c = 0; c < PB; ++c) sVn[(size_t)i_row * PB + c] = vn[rr][c];
-            }
-        }
+        // ---- hand over: X cleared, the consumed pending rows zeroed (Vn went out in front of the T block) ----
         // (X is cleared in linear order: a thread clearing its own row of 128 bytes shares its banks with every second
         // lane -- the V stores above pay that, the rows being the threads' own)
         for (int i = tid; i < npad * PB; i += NT) sX[i] = (d2){0.0, 0.0};
@@ -1042,10 +1040,22 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 tb[k] = sT[16 * k + (lane & 15)];
                 sb[k] = sS[16 * k + (lane & 15)];
             }
+            if (ROWS > 1) asm volatile("" ::: "memory");  // (the re-reads below stay behind the Gram sums above)
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) {
                 if (!__any(qr_row[rr])) continue;  // wave-uniform
                 const int i_row = row_of(rr);
+                if (ROWS > 1) {
+                    // two rows per thread: the rows of X and V are read again, one row at a time -- held over the Gram
+                    // sums and the S block, both rows' 32 complex numbers (128 registers) beside T, S and the products
+                    // pushed 36 dwords of loop invariants into scratch memory
+                    const int i_read = min(i_row, npad - 1);
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        xr[rr][c] = qr_row[rr] ? sX[(size_t)i_read * PB + c] : (d2){0.0, 0.0};
+                        vr[rr][c] = qr_row[rr] ? sVn[(size_t)i_read * PB + c] : (d2){0.0, 0.0};
+                    }
+                }
                 d2 xt[PB], vs[PB];
                 static_for<0, PB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
@@ -1166,7 +1176,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
-    static bool raised[2][TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised[2][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
     do {                                                                                                                        \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NTV, ROWSV, VNL>), 160 * 1024, raised[SLOT])); \
@@ -1200,7 +1210,7 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
         // four sweeps per wave: a sweep is ~n / 8 steps long and sweeps start two ticks apart
         const int nw4 = env_nw ? env_nw : (n <= 128 ? 2 : n <= 256 ? 4 : 8);
         const size_t lds4 = (size_t)16 * np * 16 + (size_t)nw4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
-        static bool raised4[3][TBK_MAX_DEVICES] = {};
+        static std::atomic<bool> raised4[3][TBK_MAX_DEVICES] = {};
 #define TBK_CHASE4(NWV, SLOT)                                                                                             \
     do {                                                                                                                  \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4_kernel<NWV>), 160 * 1024, raised4[SLOT]));   \

@@ -704,7 +704,13 @@ herm_tridiag8_kernel(double* H, int n, double* __restrict__ D, double* __restric
         const double qr = alr - beta, qi = ali;
         const double qn = fast_rcp(ident ? 1.0 : qr * qr + qi * qi);
         const double sr = ident ? 0.0 : qr * qn, si = ident ? 0.0 : -qi * qn;  // 1 / (alpha - beta)
-        const double tr = ident ? 0.0 : (beta - alr) * rbeta, ti = ident ? 0.0 : -ali * rbeta;
+        double tr = ident ? 0.0 : (beta - alr) * rbeta, ti = ident ? 0.0 : -ali * rbeta;
+        if (NT * 4 > 176) {
+            // tau is the same in every lane and lives across the partial products and the second barrier: with 192 matrix
+            // registers per lane (<96, 2>) it moves to scalar registers (the last 8 bytes of scratch memory of this kernel)
+            tr = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(tr)), __builtin_amdgcn_readfirstlane(__double2loint(tr)));
+            ti = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(ti)), __builtin_amdgcn_readfirstlane(__double2loint(ti)));
+        }
         const double one = ident ? 0.0 : 1.0;
         if (wv == 0 && lane == 0) Em[j] = ident ? alr : beta;
         double vr = 0.0, vi = 0.0;
@@ -749,12 +755,16 @@ herm_tridiag8_kernel(double* H, int n, double* __restrict__ D, double* __restric
         double ur = 0.0, ui = 0.0, rho = 0.0;
         double ubr[NB], ubi[NB];
         {
+            // (all reads of a batch in flight together, then the sums.  With 48 columns per lane -- <96, 2>: 192 matrix
+            // registers -- the reads go out in two batches: in one, their 36 landing registers pushed 13 dwords of the
+            // matrix into scratch memory)
+            constexpr int B0 = (NT * 4 > 176 && NB > 1) ? 1 : NB;  // broadcast registers summed in the first batch
             d2 t[NW], tb2[NB][NW];
             double rs[2 * NW];
 #pragma unroll
             for (int w2 = 0; w2 < NW; ++w2) t[w2] = sp[w2][row];
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < B0; ++b)
 #pragma unroll
                 for (int w2 = 0; w2 < NW; ++w2) tb2[b][w2] = sp[w2][min(bc_col[b], NR - 1)];
 #pragma unroll
@@ -765,7 +775,14 @@ herm_tridiag8_kernel(double* H, int n, double* __restrict__ D, double* __restric
                 ui += t[w2][1];
             }
 #pragma unroll
+            for (int w2 = 0; w2 < 2 * NW; ++w2) rho += rs[w2];
+#pragma unroll
             for (int b = 0; b < NB; ++b) {
+                if (b >= B0) {  // a later batch of one: requested behind the sums of the batch before it
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2) tb2[b][w2] = sp[w2][min(bc_col[b], NR - 1)];
+                }
                 ubr[b] = ubi[b] = 0.0;
 #pragma unroll
                 for (int w2 = 0; w2 < NW; ++w2) {
@@ -774,8 +791,6 @@ herm_tridiag8_kernel(double* H, int n, double* __restrict__ D, double* __restric
                 }
                 if (!(bc_col[b] > j && bc_col[b] < n)) ubr[b] = ubi[b] = 0.0;
             }
-#pragma unroll
-            for (int w2 = 0; w2 < 2 * NW; ++w2) rho += rs[w2];
             if (!(row > j && row < n)) ur = ui = 0.0;
         }
         // w = tau u - (|tau|^2 rho / 2) v  (kernel 1b)

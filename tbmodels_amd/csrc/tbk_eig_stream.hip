@@ -756,7 +756,7 @@ template <int NU, int NB, int ST_THREADS>
 hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double* d_D, double* d_E, int n_steps) {
     const bool colbuf = (NU >= 5);  // see COLBUF in the kernel
     const size_t lds = (size_t)(2 * NB + 3 + (colbuf ? ST_THREADS / 64 : 0)) * 64 * NU * sizeof(d2);
-    static bool raised[TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
     {
         hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&herm_tridiag_stream_kernel<NU, NB, ST_THREADS>), (int)lds,
                                            raised);

@@ -254,7 +254,7 @@ hipError_t launch_lds(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
     const size_t lds = (size_t)std::max<int64_t>(m->n_r, 1) * (KT * 2 + 2) * sizeof(double);
     static const bool sched_on = !(getenv("TBK_CSR_SCHED") && atoi(getenv("TBK_CSR_SCHED")) == 0);  // 0: measurements
     const bool sched = sched_on && m->sched_kt == KT && m->d_sptr != nullptr;
-    static bool raised[2][TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised[2][TBK_MAX_DEVICES] = {};
     // slices of 4 x 1024 packed elements (measured: 1 -> 18.5, 2 -> 17.0, 3 -> 16.6, 4 -> 16.1, 6 -> 18.3, 8 -> 19.8 ms per 50 000 k-points at cfg3) (TBK_CSR_SLICE_ROUNDS: measurements); one slice = the whole triangle for small models
     static const int slice_rounds = getenv("TBK_CSR_SLICE_ROUNDS") ? std::max(1, atoi(getenv("TBK_CSR_SLICE_ROUNDS"))) : 4;
     const int64_t n_tiles = (nk + KT - 1) / KT;

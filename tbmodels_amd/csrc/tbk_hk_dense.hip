@@ -518,8 +518,8 @@ template <int MODE, int CONV>
 int launch(tbk_model* m, const HkArgs& a0, int grid) {
     hipStream_t s = m->stream;
     const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
-    static bool raised[TBK_MAX_DEVICES] = {};
-    static bool raised_split[TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised_split[TBK_MAX_DEVICES] = {};
     TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised));
     TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds, raised_split));
     HkArgs a = a0;

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -68,13 +70,15 @@ void tbk_set_error(const char* fmt, ...);
 // ------------------------------------------------------------------------------------------------
 constexpr int TBK_MAX_DEVICES = 64;
 
-inline hipError_t tbk_raise_lds_limit(const void* kernel, int bytes, bool (&done)[TBK_MAX_DEVICES]) {
+// (the flags are atomics: two handles on one device -- Model.devices = [0, 0] -- launch from two host threads)
+using tbk_flag_row = std::atomic<bool>[TBK_MAX_DEVICES];
+inline hipError_t tbk_raise_lds_limit(const void* kernel, int bytes, tbk_flag_row& done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < TBK_MAX_DEVICES && done[dev]) return hipSuccess;
+    if (dev >= 0 && dev < TBK_MAX_DEVICES && done[dev].load(std::memory_order_acquire)) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && dev >= 0 && dev < TBK_MAX_DEVICES) done[dev] = true;
+    if (e == hipSuccess && dev >= 0 && dev < TBK_MAX_DEVICES) done[dev].store(true, std::memory_order_release);
     return e;
 }
 
@@ -211,6 +215,10 @@ struct tbk_model {
     DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
     DevBuf ws_band;   // two-stage reduction: pending [V | W] panel of every matrix of a chunk
     DevBuf ws_bandmat[2];  // ... and the band matrices between its stages (one per chunk in flight)
+    // Set for the duration of one eigenvalue call by tbk_eigenval_device_gather (tbk_comm.hip): the chunk pipeline calls it
+    // whenever the eigenvalues of rows [c0, c0 + nkc) of the call have been enqueued, with an event recorded behind
+    // them -- the all-gather of finished rows leaves on the communicator's stream while later chunks compute.
+    std::function<int(int64_t c0, int64_t nkc, hipEvent_t done)> chunk_done;
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};

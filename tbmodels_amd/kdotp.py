@@ -13,6 +13,7 @@ import threading
 import numpy as np
 
 from . import _lib, _outbuf
+from ._model import _devices_from_env
 
 __all__ = ("KdotpModel",)
 
@@ -30,34 +31,71 @@ class KdotpModel:
         self.taylor_coefficients = {
             tuple(key): np.array(mat, dtype=complex) for key, mat in taylor_coefficients.items()
         }
-        self._handle = None
+        self._handles = []
         self._staged_key = None
         self._pinned = False
         self._call_lock = threading.RLock()
-        self.device = 0
+        self._devices = _devices_from_env()
 
     def __getstate__(self):
         state = dict(self.__dict__)
-        state["_handle"] = None
+        state["_handles"] = []
         state["_staged_key"] = None
         state.pop("_call_lock", None)
         return state
 
     def __setstate__(self, state):
+        legacy_device = state.pop("device", None)  # states written before a k.p model could sit on several devices
+        state.pop("_handle", None)
         self.__dict__.update(state)
+        self._handles = []
+        if "_devices" not in state:
+            self._devices = [int(legacy_device)] if legacy_device is not None else _devices_from_env()
         self._call_lock = threading.RLock()
 
     def __del__(self):
         self._drop_staging()
 
+    # ------------------------------------------------------------------ devices (the surface of ``Model.devices``)
+    @property
+    def device(self):
+        """The (first) GPU this model evaluates on; assigning an index makes it the only one."""
+        return self._devices[0]
+
+    @device.setter
+    def device(self, index):
+        self.devices = [int(index)]
+
+    @property
+    def devices(self):
+        """
+        GPU indices this model is staged on.  With more than one, ``hamilton`` / ``eigenval`` cut the k list into
+        contiguous slabs, one per entry, and every device fills its rows of the result (``tbk_kdotp_eigenval_multi``) -- the
+        single call of a single process of ``kdotp.py:51-100``.  Default: ``TBK_DEVICES`` / ``TBK_DEVICE`` / device 0; an
+        index may repeat.
+        """
+        return list(self._devices)
+
+    @devices.setter
+    def devices(self, indices):
+        indices = [int(i) for i in indices]
+        if not indices or any(i < 0 for i in indices):
+            raise ValueError("devices must be a non-empty list of GPU indices, got {!r}".format(indices))
+        if indices != getattr(self, "_devices", None):
+            self._drop_staging()
+        self._devices = indices
+
+    @property
+    def _handle(self):
+        return self._handles[0] if self._handles else None
+
     def _drop_staging(self):
-        handle = getattr(self, "_handle", None)
-        if handle is not None:
+        handles, self._handles = getattr(self, "_handles", []), []
+        for handle in handles:
             try:
                 _lib.lib().tbk_kdotp_destroy(handle)
             except Exception:  # pylint: disable=broad-except
                 pass
-        self._handle = None
         self._staged_key = None
 
     def pin_staging(self, pinned=True):
@@ -86,7 +124,7 @@ class KdotpModel:
             arr = np.ascontiguousarray(mat, dtype=np.complex128)
             keys.append(arr.shape)
             update(arr.view(np.uint8).reshape(-1).data)
-        return (int(self.device), tuple(keys), digest())
+        return (tuple(self._devices), tuple(keys), digest())
 
     def _shape(self):
         if not self.taylor_coefficients:
@@ -95,30 +133,44 @@ class KdotpModel:
         return len(key), mat.shape[0]
 
     def _staged(self):
+        """The ``tbk_kdotp*`` on the first device (re-staged when the coefficients changed)."""
         with self._call_lock:
-            return self._staged_locked()
+            return self._staged_locked()[0]
 
     def _staged_locked(self):
+        """One ``tbk_kdotp*`` per entry of ``self.devices``."""
         key = None
-        if self._handle is not None and not self._pinned:
+        if self._handles and not self._pinned:
             key = self._staging_key()
             if key != self._staged_key:
                 self._drop_staging()
-        if self._handle is None:
+        if not self._handles:
             key = key if key is not None else self._staging_key()
             dim, size = self._shape()
             keys = list(self.taylor_coefficients.keys())
             powers = np.array(keys, dtype=np.int32).reshape(len(keys), dim)
             coeffs = np.ascontiguousarray(np.stack([self.taylor_coefficients[k] for k in keys]), dtype=np.complex128)
-            handle = ctypes.c_void_p()
-            _lib.check(
-                _lib.lib().tbk_kdotp_create(
-                    self.device, dim, size, len(keys), _lib.ptr(powers), _lib.ptr(coeffs), ctypes.byref(handle)
-                )
-            )
-            self._handle = handle
+            handles = []
+            try:
+                for device in self._devices:  # the coefficients are replicated: every device holds the whole model
+                    handle = ctypes.c_void_p()
+                    _lib.check(
+                        _lib.lib().tbk_kdotp_create(
+                            device, dim, size, len(keys), _lib.ptr(powers), _lib.ptr(coeffs), ctypes.byref(handle)
+                        )
+                    )
+                    handles.append(handle)
+            except Exception:
+                for handle in handles:
+                    _lib.lib().tbk_kdotp_destroy(handle)
+                raise
+            self._handles = handles
             self._staged_key = key
-        return self._handle
+        return self._handles
+
+    def _handle_array(self):
+        handles = self._staged_locked()
+        return (ctypes.c_void_p * len(handles))(*[h.value for h in handles]), len(handles)
 
     def _k_array(self, k):
         dim, _ = self._shape()
@@ -139,7 +191,8 @@ class KdotpModel:
         _, size = self._shape()
         out = _outbuf.empty((k_array.shape[0], size, size), np.complex128)
         with self._call_lock:  # re-validating the staged copy and the call are one step for other threads
-            _lib.check(_lib.lib().tbk_kdotp_hamilton(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
+            handles, n_handles = self._handle_array()
+            _lib.check(_lib.lib().tbk_kdotp_hamilton_multi(handles, n_handles, _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
         return out[0] if single else out
 
     def eigenval(self, k):
@@ -153,7 +206,8 @@ class KdotpModel:
         _, size = self._shape()
         out = _outbuf.empty((k_array.shape[0], size), np.float64)
         with self._call_lock:
-            _lib.check(_lib.lib().tbk_kdotp_eigenval(self._staged(), _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
+            handles, n_handles = self._handle_array()
+            _lib.check(_lib.lib().tbk_kdotp_eigenval_multi(handles, n_handles, _lib.ptr(k_array), k_array.shape[0], _lib.ptr(out)))
         return out[0] if single else out
 
     # ------------------------------------------------------------------ HDF5 (``tbmodels.kdotp_model``)

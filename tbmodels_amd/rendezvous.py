@@ -37,8 +37,11 @@ def _run_token():
         return token
     run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
     if run_id and run_id != "none" and os.environ.get("MASTER_PORT"):
-        # a launcher-wide id: also right when the ranks are started through per-rank wrapper shells (no shared parent)
-        return "%s-%s" % (run_id, os.environ["MASTER_PORT"])
+        # a launcher-wide id: also right when the ranks are started through per-rank wrapper shells (no shared parent).
+        # The restart count tells the worker generations of ONE elastic run apart (``--max-restarts``: same id, same
+        # port, same directory -- and the files of the generation that crashed are still there).  A re-run that reuses
+        # --rdzv-id and the port after a crash is told apart by FileGroup's first exchange (a nonce, below).
+        return "%s-%s-r%s" % (run_id, os.environ["MASTER_PORT"], os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
     ppid = os.getppid()
     start = "0"
     try:
@@ -72,6 +75,77 @@ class FileGroup:
         self._met = False     # one exchange with every peer has completed
         self._mine = []       # (sequence number, path) of the files this rank wrote and has not removed yet
         os.makedirs(path, exist_ok=True)
+        self._fresh = self.world == 1  # the hand-shake below has given this launch its own name space
+
+    # -- a name space no earlier launch can have written into ------------------------------------
+    def _handshake(self):
+        """
+        The run token alone does not tell a launch from an earlier one that used the same token -- a re-run with the same
+        ``--rdzv-id`` and port after a crash, whose last exchange and broadcast files (an old RCCL id!) are still in the
+        directory.  So the first exchange is a two-way hand-shake on fresh random numbers: every peer r writes
+        ``<token>.hi.r<r>`` with a nonce P_r of its own; rank 0 keeps publishing ``<token>.hello`` = (its nonce N, the
+        P_r it currently sees); a peer accepts a hello only if it carries ITS nonce -- such a hello was written after this
+        peer started, by this launch's rank 0 -- and acknowledges inside the name space ``<token>-<N>``, which rank 0
+        waits for.  From then on every file name carries ``<token>-<N>``: stale files cannot match.
+        """
+        base = self.token
+        deadline = time.monotonic() + self.first_timeout_s
+
+        def write(name, text):
+            tmp = os.path.join(self.path, ".%s.%d.tmp" % (name, self.rank))
+            with open(tmp, "w") as handle:
+                handle.write(text)
+            os.replace(tmp, os.path.join(self.path, name))
+
+        def read(name):
+            try:
+                with open(os.path.join(self.path, name)) as handle:
+                    return handle.read()
+            except OSError:
+                return None
+
+        def expired(what):
+            if time.monotonic() > deadline:
+                raise TimeoutError(
+                    "rendezvous: rank %d of %d waited %.0f s for %s (run token %r, directory %r: every rank of a launch "
+                    "must see the same two -- set TBK_RDZV_TOKEN / TBK_RDZV_DIR when the ranks do not share a parent "
+                    "process)" % (self.rank, self.world, self.first_timeout_s, what, base, self.path))
+            time.sleep(self.poll_s)
+
+        nonce = os.urandom(8).hex()
+        if self.rank == 0:
+            space = "%s-%s" % (base, nonce)
+            seen = None
+            while True:
+                peers = [read("%s.hi.r%d" % (base, r)) or "" for r in range(1, self.world)]
+                if peers != seen:
+                    write("%s.hello" % base, " ".join([nonce] + [p or "-" for p in peers]))
+                    seen = peers
+                if all(read("%s.ack.r%d" % (space, r)) is not None for r in range(1, self.world)):
+                    break
+                expired("the peers' acknowledgements")
+            for name in os.listdir(self.path):  # the hand-shake files of this launch, and whatever older launches left
+                stale = (name.startswith(base + ".") or name.startswith(base + "-")) and not name.startswith(space + ".")
+                if stale or name.startswith(space + ".ack."):
+                    try:
+                        os.unlink(os.path.join(self.path, name))
+                    except OSError:
+                        pass
+            write("%s.go" % space, "1")
+            self._mine.append((0, os.path.join(self.path, "%s.go" % space)))
+        else:
+            write("%s.hi.r%d" % (base, self.rank), nonce)
+            while True:
+                hello = (read("%s.hello" % base) or "").split()
+                if len(hello) == self.world and hello[self.rank] == nonce:
+                    break
+                expired("rank 0's hello")
+            space = "%s-%s" % (base, hello[0])
+            write("%s.ack.r%d" % (space, self.rank), "1")
+            while read("%s.go" % space) is None:
+                expired("rank 0's go")
+        self.token = space
+        self._fresh = True
 
     # -- primitives ---------------------------------------------------------------------------
     def _put(self, name, data):
@@ -115,6 +189,8 @@ class FileGroup:
         self._mine = keep
 
     def _next(self, tag):
+        if not self._fresh:
+            self._handshake()
         self._seq += 1
         return "%s.%06d" % (tag, self._seq)
 

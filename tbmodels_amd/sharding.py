@@ -148,47 +148,56 @@ class ShardedEigenval:
     def _device_gather_locked(self, k, start, stop, per, n_k, n_orb):
         lib = _lib.lib()
         dev = self.device
-        # What a rank sends: its slab's eigenvalues and ONE status word behind them.  Every rank goes through the same
-        # collectives whatever happens locally -- a rank that raised before the all-gather (or after it, on a NaN in its
-        # own slab only) would leave the others hanging in the next collective -- and the status travels IN the gather:
-        # no host-side collective on the data path (it was an allreduce through the rendezvous files per call).
-        count = per * n_orb + 1
+        # Step 1, agreement: everything that can fail on ONE rank in front of the collectives -- the communicator's
+        # id exchange aside, which every rank walks alike: staging the model, growing the device buffers -- happens
+        # inside the try, and its outcome is all-gathered as one status word per rank (8 bytes through buffers the
+        # communicator owns since its creation) before anybody enters the data collectives.  A rank that raised on
+        # its own in front of the gather used to leave its peers hanging in it.
         comm = self._communicator()  # first call: a host broadcast of the RCCL id, taken by every rank alike
-        d_send = self._buffer("send", count * 8)
-        d_recv = self._buffer("recv", self.world * count * 8)
-        status, message, failure, handle = 0, "", None, None
-        try:  # local trouble (staging, allocation, a NaN k-point) becomes this rank's status word
+        failure, handle, d_k, d_all, d_status, k_slab = None, None, None, None, None, None
+        try:
             handle = self.model._staged()  # pylint: disable=protected-access
+            d_all = self._buffer("all", self.world * per * n_orb * 8)
+            d_status = self._buffer("status", self.world * 8)
             if stop > start:
                 k_slab = np.ascontiguousarray(k[start:stop])
                 d_k = self._buffer("k", k_slab.nbytes)
                 _lib.check(lib.tbk_memcpy_h2d(dev, d_k, _lib.ptr(k_slab), k_slab.nbytes))
-                # the host slab goes along as the structure hint: mesh slabs are folded (include/tbk.h)
-                _lib.check(lib.tbk_eigenval_device_hint(handle, d_k, _lib.ptr(k_slab), stop - start, d_send))
-                _lib.check(lib.tbk_eigenval_check(handle))  # synchronises; non-finite / non-converged flags of THIS rank
         except Exception as exc:  # pylint: disable=broad-except
             failure = exc
-            status = _status_of(exc)
-            message = str(exc)
-        word = np.array([float(status)])
-        tail = ctypes.c_void_p(d_send.value + per * n_orb * 8)
-        _lib.check(lib.tbk_memcpy_h2d(dev, tail, _lib.ptr(word), 8))
-        # (without a staged handle the gather runs on the communicator's own stream)
-        _lib.check(lib.tbk_comm_allgather_f64(comm, handle, d_send, d_recv, count))
-        _lib.check(lib.tbk_comm_synchronize(comm) if handle is None else lib.tbk_synchronize(handle))
-        out = np.empty((self.world, count), dtype=np.float64)
-        _lib.check(lib.tbk_memcpy_d2h(dev, _lib.ptr(out), d_recv, out.nbytes))
+        verdict = np.zeros(self.world)
+        _lib.check(lib.tbk_comm_agree(comm, _status_of(failure), _lib.ptr(verdict)))
         if failure is not None:
             raise failure
-        worst = int(out[:, -1].max())
+        if verdict.max() != 0:
+            bad = int(np.argmax(verdict))
+            _raise_status(int(verdict[bad]), "rank %d failed (status %d) while preparing its k slab" % (bad, int(verdict[bad])))
+        # Step 2, the call: this rank's slab is evaluated into its rows of the result, finished blocks of rows leave on
+        # the communicator's stream while later k chunks compute (tbk_eigenval_device_gather), the solvers' flags travel
+        # as the LAST collective -- a NaN in one rank's slab raises on every rank, after the same collectives.  The host
+        # slab goes along as the structure hint: mesh slabs are folded (include/tbk.h).
+        local = lib.tbk_eigenval_device_gather(comm, handle, d_k, _lib.ptr(k_slab) if k_slab is not None else None,
+                                               stop - start, per, 0, d_all, d_status)
+        local_message = _lib.last_error() if local != 0 else ""
+        _lib.check(lib.tbk_comm_synchronize(comm))  # ONE wait: eigenvalues of every rank and the verdict are in place
+        _lib.check(lib.tbk_memcpy_d2h(dev, _lib.ptr(verdict), d_status, verdict.nbytes))
+        worst = int(verdict.max())
         if worst != 0:
-            bad = int(np.argmax(out[:, -1]))
+            bad = int(np.argmax(verdict))
+            if bad == self.rank and local_message:
+                _raise_status(worst, local_message)
+            if bad == self.rank and worst == _lib.TBK_ERR_NOT_FINITE:
+                _raise_status(worst, "array must not contain infs or NaNs")  # scipy's message (tbk_eigenval_check)
             _raise_status(worst, "rank %d failed (status %d) while evaluating its k slab" % (bad, worst))
-        return out[:, :-1].reshape(self.world * per, n_orb)[:n_k].copy()
+        out = np.empty((self.world * per, n_orb), dtype=np.float64)
+        _lib.check(lib.tbk_memcpy_d2h(dev, _lib.ptr(out), d_all, out.nbytes))
+        return out[:n_k].copy() if n_k != len(out) else out
 
 
 def _status_of(exc):
     """The ``tbk_status`` that `_lib.check` maps to the type of `exc` (the inverse of :func:`_raise_status`)."""
+    if exc is None:
+        return 0
     if isinstance(exc, np.linalg.LinAlgError):
         return _lib.TBK_ERR_NO_CONVERGENCE
     if isinstance(exc, ValueError):

@@ -176,6 +176,95 @@ def test_overlapped_allgather_with_a_chunked_pipeline(small_model):
             lib.tbk_device_free(0, p)
 
 
+def _gather_call(lib, comm, handle, k, per, block_rows, chunk, host_status=0):
+    """One tbk_eigenval_device_gather call of a world-1 communicator: (all rows [per][n], status words, return code)."""
+    n_orb = 12
+    buffers = []
+
+    def dmalloc(nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(lib.tbk_device_malloc(0, max(nbytes, 8), ctypes.byref(p)))
+        buffers.append(p)
+        return p
+
+    os.environ["TBK_GATHER_BLOCK_ROWS"] = str(block_rows)
+    try:
+        k = np.ascontiguousarray(k)
+        d_k = dmalloc(k.nbytes)
+        d_all = dmalloc(per * n_orb * 8)
+        d_st = dmalloc(8)
+        junk = np.full((per, n_orb), 7.5)
+        _lib.check(lib.tbk_memcpy_h2d(0, d_all, _lib.ptr(junk), junk.nbytes))
+        if len(k):
+            _lib.check(lib.tbk_memcpy_h2d(0, d_k, _lib.ptr(k), k.nbytes))
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, chunk))
+        rc = lib.tbk_eigenval_device_gather(comm, handle, d_k, _lib.ptr(k) if len(k) else None, len(k), per, host_status, d_all, d_st)
+        _lib.check(lib.tbk_comm_synchronize(comm))
+        out = np.empty((per, n_orb))
+        status = np.empty(1)
+        _lib.check(lib.tbk_memcpy_d2h(0, _lib.ptr(out), d_all, out.nbytes))
+        _lib.check(lib.tbk_memcpy_d2h(0, _lib.ptr(status), d_st, 8))
+        return out, status, rc
+    finally:
+        os.environ.pop("TBK_GATHER_BLOCK_ROWS", None)
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 0))
+        for p in buffers:
+            lib.tbk_device_free(0, p)
+
+
+def test_chunk_pipelined_gather_equals_the_in_stream_gather(small_model):
+    """``tbk_eigenval_device_gather``: blocks of finished rows leave on the communicator's stream while later k chunks
+    compute, land in a [rank][block] area and are moved to their rows -- bit for bit what the plain call with the same
+    chunking writes, on a random list and on a ragged mesh slab (folded through the hint), for block sizes that do and do
+    not divide the chunks, for a short slab (zero rows behind it) and an empty one; a NaN k-point travels as the status
+    word and the flags are consumed; a rank that arrives with a failure computes nothing and reports it."""
+    model, r_vec, hop = small_model
+    lib = _lib.lib()
+    handle = model._staged()
+    uid = np.zeros(128, dtype=np.uint8)
+    _lib.check(lib.tbk_comm_unique_id(_lib.ptr(uid)))
+    comm = ctypes.c_void_p()
+    _lib.check(lib.tbk_comm_create(0, 1, 0, _lib.ptr(uid), ctypes.byref(comm)))
+    try:
+        rand = syn.random_kpoints(20_011, seed=31)
+        slab = _grid((4, 40, 40))[211:5903]
+        for k in (rand, slab):
+            nk = len(k)
+            for chunk, block in ((4096, 1000), (4096, 4096), (0, 777), (4096, 10 ** 9), (8192, 3001)):
+                _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, chunk))
+                plain = model.eigenval_array(k)  # same handle, same chunking: the same kernels on the same rows
+                _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 0))
+                out, status, rc = _gather_call(lib, comm, handle, k, nk, block, chunk)
+                assert rc == 0 and status[0] == 0
+                assert np.array_equal(out, plain), (nk, chunk, block)
+        idx = np.random.default_rng(5).choice(len(slab), 16, replace=False)  # (`out` is the mesh slab's result here)
+        assert np.abs(out[idx] - np.array(oracle.eigenval(r_vec, hop, slab[idx]))).max() <= TOL
+        # short slab: nk < per -> zero rows behind the computed ones; empty slab: all zero
+        out, status, rc = _gather_call(lib, comm, handle, rand[:5000], 6001, 1024, 2048)
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 2048))
+        plain = model.eigenval_array(rand[:5000])
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 0))
+        assert rc == 0 and status[0] == 0 and np.array_equal(out[:5000], plain) and not out[5000:].any()
+        out, status, rc = _gather_call(lib, comm, handle, rand[:0], 300, 128, 0)
+        assert rc == 0 and status[0] == 0 and not out.any()
+        # a NaN k-point: the status word says so, the flags are consumed (tbk_eigenval_check is clean afterwards)
+        bad = rand[:3000].copy()
+        bad[1234, 2] = np.nan
+        out, status, rc = _gather_call(lib, comm, handle, bad, 3000, 512, 1024)
+        assert rc == 0 and int(status[0]) == _lib.TBK_ERR_NOT_FINITE
+        _lib.check(lib.tbk_eigenval_check(handle))
+        # a rank that arrives with a failure: nothing computed, its status gathered
+        out, status, rc = _gather_call(lib, comm, handle, rand[:1000], 1000, 256, 0, host_status=_lib.TBK_ERR_MEMORY)
+        assert int(status[0]) == _lib.TBK_ERR_MEMORY and not out.any()
+        verdict = np.full(1, -1.0)
+        _lib.check(lib.tbk_comm_agree(comm, 3, _lib.ptr(verdict)))
+        assert verdict[0] == 3.0
+        _lib.check(lib.tbk_comm_agree(comm, 0, _lib.ptr(verdict)))
+        assert verdict[0] == 0.0
+    finally:
+        lib.tbk_comm_destroy(comm)
+
+
 # ------------------------------------------------------------------------------------------------
 # one process, several devices, unchanged methods
 # ------------------------------------------------------------------------------------------------
@@ -286,3 +375,30 @@ def test_bench_starts_its_own_ranks_and_fails_for_rccl_reasons_on_one_gpu():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and "host all-gather" in line["config"]["collective"]
+
+
+def test_kdotp_model_on_a_device_list():
+    """``KdotpModel.devices`` (kdotp.py:51-100 behind several GPUs): ``[0, 0]`` = two staged copies, two host threads; equal to
+    the single-device result and to the oracle; pickling keeps the list and drops the handles; one k-point uses one slab."""
+    rng = np.random.default_rng(17)
+    coeffs = {}
+    for key in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (2, 0, 0), (1, 1, 0), (0, 1, 2)]:
+        a = rng.normal(size=(6, 6)) + 1j * rng.normal(size=(6, 6))
+        coeffs[key] = a + a.conj().T
+    single = tbmodels_amd.KdotpModel(coeffs)
+    twin = pickle.loads(pickle.dumps(single))
+    twin.devices = [0, 0]
+    assert twin.devices == [0, 0] and twin.device == 0
+    k = rng.uniform(-0.3, 0.3, size=(4001, 3))
+    e1, e2 = single.eigenval_array(k), twin.eigenval_array(k)
+    assert len(twin._handles) == 2
+    assert np.abs(e1 - e2).max() < 1e-12
+    powers = np.array(list(coeffs.keys()))
+    ref = np.array(oracle.kdotp_eigenval(powers, np.stack([coeffs[tuple(p)] for p in powers]), k[:32]))
+    assert np.abs(e2[:32] - ref).max() <= TOL
+    assert np.array_equal(twin.hamilton(k[:301]), single.hamilton(k[:301]))
+    assert twin.eigenval(k[0]).shape == (6,) and isinstance(twin.eigenval(k[:3]), list)
+    again = pickle.loads(pickle.dumps(twin))
+    assert again.devices == [0, 0] and again._handles == []
+    with pytest.raises(ValueError):
+        twin.devices = []

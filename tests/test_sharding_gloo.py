@@ -148,6 +148,14 @@ def test_failure_on_one_rank_is_raised_on_every_rank(tmp_path):
     rdzv.mkdir()
     for name in ("ag.000001.r0", "ag.000001.r1", "bc.000001", "stale-run.ag.000001.r1"):
         (rdzv / name).write_bytes(b"\xff" * 8)  # leftovers of a crashed run (old naming and another token)
+    # ... and of a crashed run with THIS token (a re-run with the same --rdzv-id and port): its hand-shake, its
+    # broadcast (an old RCCL id) and its last exchange -- the fresh name space of the hand-shake keeps them out, and rank
+    # 0 removes them
+    (rdzv / "this-run.hello").write_text("0123456789abcdef fedcba9876543210")
+    (rdzv / "this-run.hi.r1").write_text("fedcba9876543210")
+    for name in ("this-run-0123456789abcdef.go", "this-run-0123456789abcdef.bc.000001", "this-run-0123456789abcdef.ag.000002.r1",
+                 "this-run.bc.000001", "this-run.ag.000001.r0"):
+        (rdzv / name).write_bytes(b"\xff" * 8)
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_failing_worker, args=(rank, 2, str(tmp_path), "this-run")) for rank in range(2)]
     for proc in procs:

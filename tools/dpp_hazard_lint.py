@@ -9,6 +9,11 @@ recogniser does not look inside asm blocks, and gfx9 hardware does not interlock
   (its first source), needs 2 wait states in between;
 * a VALU instruction that writes EXEC, followed by any DPP instruction, needs 5.
 
+The walk follows control flow: local labels come from ``llvm-objdump --symbolize-operands``, a label's predecessors are
+the fall-through instruction and every branch that names it (loop back edges included), and ``v_permlane16_swap`` /
+``v_permlane32_swap`` / ``v_swap_b32`` count as writers of BOTH their operands.  The same pass reads the code objects'
+metadata and reports every kernel with a private segment (``.private_segment_fixed_size`` != 0: register spills).
+
 Putting ``s_nop`` into the asm string costs +10 % on the n <= 64 reduction (measured), so the built objects are
 checked instead: every ``*.o`` of ``tbmodels_amd/csrc`` is unbundled (``objcopy`` of ``.hip_fatbin`` +
 ``clang-offload-bundler``), disassembled (``llvm-objdump -d``), and each DPP FMA's predecessors are inspected.  Wait
@@ -41,8 +46,8 @@ def _vgprs(operand):
     return set(range(int(found.group(1)), int(found.group(2)) + 1))
 
 
-def disassemble(obj_path, workdir):
-    """llvm-objdump text of the gfx950 code object inside a host object / shared library, or None."""
+def unbundle(obj_path, workdir):
+    """Path of the gfx950 code object inside a host object / shared library, or None."""
     fatbin = os.path.join(workdir, "x.fatbin")
     code = os.path.join(workdir, "x.co")
     for path in (fatbin, code):
@@ -54,23 +59,65 @@ def disassemble(obj_path, workdir):
     subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fatbin,
                     "--targets=" + TARGET, "--output=" + code], check=True, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL)
-    return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", code], check=True, stdout=subprocess.PIPE,
+    return code
+
+
+def disassemble(obj_path, workdir):
+    """llvm-objdump text of the gfx950 code object inside a host object / shared library, or None.  Branch targets are
+    symbolised (``--symbolize-operands``: ``s_cbranch_scc1 L7`` and a ``<L7>:`` line at the target) -- plain ``-d`` prints
+    no local labels at all, and the scan then runs straight through branches and never sees a loop's back edge."""
+    code = unbundle(obj_path, workdir)
+    if code is None:
+        return None
+    return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--symbolize-operands", code], check=True,
+                          stdout=subprocess.PIPE, universal_newlines=True).stdout
+
+
+def kernel_resources(obj_path, workdir):
+    """{kernel symbol: {"scratch": private_segment_fixed_size, "vgpr": .vgpr_count, "sgpr": .sgpr_count}} from the code
+    object's metadata notes."""
+    code = unbundle(obj_path, workdir)
+    if code is None:
+        return {}
+    text = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", code], check=True, stdout=subprocess.PIPE,
                           universal_newlines=True).stdout
+    out, fields = {}, {}
+    for line in text.splitlines():
+        found = re.match(r"\s*-?\s*\.(name|private_segment_fixed_size|vgpr_count|sgpr_count|agpr_count):\s*(\S+)", line)
+        if not found:
+            if line.strip().startswith("- .") and fields.get("name"):  # next kernel record
+                pass
+            continue
+        key, value = found.group(1), found.group(2)
+        if key == "name" and "name" in fields and "private_segment_fixed_size" in fields:
+            out[fields["name"]] = fields
+            fields = {}
+        fields[key] = value if key == "name" else int(value)
+        if all(k in fields for k in ("name", "private_segment_fixed_size", "vgpr_count", "sgpr_count")):
+            out[fields["name"]] = {"scratch": fields["private_segment_fixed_size"], "vgpr": fields["vgpr_count"],
+                                   "sgpr": fields["sgpr_count"], "agpr": fields.get("agpr_count", 0)}
+            fields = {}
+    return out
+
+
+_UNCONDITIONAL = ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64")
+_TWO_DESTINATIONS = ("v_permlane16_swap", "v_permlane32_swap", "v_swap_b32")
 
 
 def parse(text):
-    """[(kernel, [(mnemonic, [operands])...])]: instructions per function, branch targets marked as ('<label>', [])."""
+    """[(kernel, instrs, labels)]: instrs = [(mnemonic, [operands])...]; labels = {name: index of the instruction the label
+    stands in front of}."""
     kernels = []
     current = None
     for line in text.splitlines():
         head = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
         if head:
             name = head.group(1)
-            if name.startswith("L") or name.startswith(".L"):  # a local label inside a function: a control-flow merge
+            if re.match(r"^\.?L\d+$", name):  # a local label inside a function: a branch target
                 if current is not None:
-                    current[1].append(("<label>", []))
+                    current[2][name] = len(current[1])
             else:
-                current = (name, [])
+                current = (name, [], {})
                 kernels.append(current)
             continue
         if current is None or "//" not in line:
@@ -84,40 +131,77 @@ def parse(text):
     return kernels
 
 
+def _written_vgprs(mnemonic, operands):
+    """VGPRs a VALU instruction writes: its first operand -- and the second one too for the swaps (v_permlane16_swap /
+    v_permlane32_swap / v_swap_b32 exchange lanes of BOTH registers)."""
+    if not operands:
+        return set()
+    written = _vgprs(operands[0].split()[0])
+    if mnemonic.startswith(_TWO_DESTINATIONS) and len(operands) > 1:
+        written |= _vgprs(operands[1].split()[0])
+    return written
+
+
+def _is_dpp_fma(mnemonic, operands):
+    return mnemonic.startswith("v_fmac_f64_dpp") or (mnemonic.startswith("v_fmac_f64") and any("row_newbcast" in o for o in operands))
+
+
 def lint(text):
-    """List of (kernel, index, message) for every DPP FMA with a too-close VALU producer."""
+    """List of (kernel, index, message) for every DPP FMA with a too-close VALU producer on ANY path into it: the walk
+    goes backwards through fall-through predecessors and through every branch that targets a label on the way."""
     problems = []
-    for kernel, instrs in parse(text):
+    for kernel, instrs, labels in parse(text):
+        targets = {}  # instruction index -> indices of the branches that jump there
         for idx, (mnemonic, operands) in enumerate(instrs):
-            if not (mnemonic.startswith("v_fmac_f64_dpp") or mnemonic.startswith("v_fmac_f64") and any("row_newbcast" in o for o in operands)):
+            if (mnemonic.startswith("s_cbranch") or mnemonic == "s_branch") and operands and operands[0] in labels:
+                targets.setdefault(labels[operands[0]], []).append(idx)
+
+        def predecessors(idx):
+            preds = list(targets.get(idx, []))
+            if idx > 0 and not instrs[idx - 1][0].startswith(_UNCONDITIONAL):
+                preds.append(idx - 1)
+            return preds
+
+        for idx, (mnemonic, operands) in enumerate(instrs):
+            if not _is_dpp_fma(mnemonic, operands) or len(operands) < 2:
                 continue
             # operands: dst, src0 (the DPP-read one, may carry a neg modifier), src1 + dpp controls
-            if len(operands) < 2:
-                continue
             dpp_src = _vgprs(operands[1].split()[0])
-            states = 0
-            for back in range(idx - 1, max(-1, idx - 8), -1):
-                prev, prev_ops = instrs[back]
-                if prev == "<label>":
-                    break  # predecessors on other paths are not visible here: the compiler's own scheduling applies
-                if prev == "s_nop":
-                    states += int(prev_ops[0], 0) + 1 if prev_ops else 1
+            seen = set()
+            stack = [(p, 0) for p in predecessors(idx)]
+            while stack:
+                at, states = stack.pop()
+                if (at, states) in seen or states >= 5:
                     continue
-                if prev.startswith("v_") and prev_ops:
-                    written = _vgprs(prev_ops[0].split()[0])
-                    if states < 2 and written & dpp_src and not prev.startswith("v_cmp"):
-                        problems.append((kernel, idx, "%s writes %s %d wait state(s) before %s reads it through DPP"
-                                         % (prev, prev_ops[0], states, mnemonic)))
-                    if states < 5 and (prev.startswith("v_cmpx") or prev_ops[0].split()[0] in ("exec", "exec_lo", "exec_hi")):
-                        problems.append((kernel, idx, "%s writes EXEC %d wait state(s) before %s" % (prev, states, mnemonic)))
-                states += 1
-                if states >= 5:
-                    break
-    return problems
+                seen.add((at, states))
+                prev, prev_ops = instrs[at]
+                if prev == "s_nop":
+                    after = states + (int(prev_ops[0], 0) + 1 if prev_ops else 1)
+                else:
+                    if prev.startswith("v_") and prev_ops:
+                        if states < 2 and _written_vgprs(prev, prev_ops) & dpp_src and not prev.startswith("v_cmp"):
+                            problems.append((kernel, idx, "%s writes %s %d wait state(s) before %s reads it through DPP"
+                                             % (prev, ", ".join(prev_ops[:2]), states, mnemonic)))
+                        if prev.startswith("v_cmpx") or prev_ops[0].split()[0] in ("exec", "exec_lo", "exec_hi"):
+                            problems.append((kernel, idx, "%s writes EXEC %d wait state(s) before %s" % (prev, states, mnemonic)))
+                    after = states + 1
+                for p in predecessors(at):
+                    stack.append((p, after))
+    return sorted(set(problems), key=lambda item: (item[0], item[1], item[2]))
 
 
 def count_dpp(text):
-    return sum(1 for _, instrs in parse(text) for m, ops in instrs if m.startswith("v_fmac_f64") and any("row_newbcast" in o for o in ops))
+    return sum(1 for _, instrs, _ in parse(text) for m, ops in instrs if _is_dpp_fma(m, ops))
+
+
+def spills(objects, workdir):
+    """[(object, kernel, scratch bytes, vgprs)] for every kernel with a private segment (spills or indexed local arrays)."""
+    found = []
+    for obj in objects:
+        for name, res in sorted(kernel_resources(obj, workdir).items()):
+            if res["scratch"] != 0:
+                found.append((os.path.basename(obj), name, res["scratch"], res["vgpr"]))
+    return found
 
 
 def main(argv):
@@ -138,8 +222,11 @@ def main(argv):
             print("%-28s %6d DPP FMAs, %d hazard(s)" % (os.path.basename(obj), n, len(problems)))
             for kernel, idx, message in problems[:20]:
                 print("    %s [%d]: %s" % (kernel[:60], idx, message))
+        spilled = spills(objects, workdir)
     print("total: %d DPP FMAs, %d hazard(s)" % (total, bad))
-    return 1 if bad else 0
+    for obj, name, scratch, vgpr in spilled:
+        print("scratch: %s %s: %d B per thread (%d VGPRs)" % (obj, name, scratch, vgpr))
+    return 1 if bad or spilled else 0
 
 
 if __name__ == "__main__":
