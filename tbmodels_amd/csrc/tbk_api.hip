@@ -668,9 +668,12 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         TBK_HIP(hipEventRecord(m->ev_tri[b], m->stream_eig));
 
         if (c >= 1) {  // tridiagonal stage of the previous chunk, alongside this chunk's reduction
-            TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
+            // TBK_CHASE_EARLY=1 (measurements): ... alongside this chunk's H(k) already -- it starts as soon as its own
+            // reduction is done
+            static const bool early = getenv("TBK_CHASE_EARLY") && atoi(getenv("TBK_CHASE_EARLY")) != 0;
+            if (!(early && two_stage)) TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
             // (d, e) of the previous chunk: implied by ev_hk unless H(c) was built beside that reduction
-            if (h_overlap) TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b ^ 1], 0));
+            if (h_overlap || (early && two_stage)) TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b ^ 1], 0));
             TBK_CHECK(launch_tridiag_eigenvalues(m, m->stream_ql, debuf[b ^ 1]->as<double>(), prev_nkc,
                                                  d_E + (size_t)prev_c0 * n, false, small_call,
                                                  two_stage ? m->ws_bandmat[b ^ 1].ptr : nullptr));
@@ -1150,9 +1153,10 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
 extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, int method, double* d, double* e,
                                       double* H_reduced) {
     TBK_ARG(nk >= 0, "nk < 0");
-    TBK_ARG(n_orb >= 1 && n_orb <= 512, "n_orb must be in [1, 512] (larger matrices go through rocSOLVER as a whole)");
+    TBK_ARG(n_orb >= 1 && n_orb <= 1024, "n_orb must be in [1, 1024] (larger matrices go through rocSOLVER as a whole)");
     TBK_ARG(method >= TBK_REDUCE_AUTO && method <= TBK_REDUCE_TWO_STAGE, "unknown reduction method");
-    TBK_ARG(method != TBK_REDUCE_TWO_STAGE || tbk_eig_band_supported(n_orb), "the two-stage reduction handles 64 < n_orb <= 512");
+    TBK_ARG(method != TBK_REDUCE_TWO_STAGE || tbk_eig_band_supported(n_orb), "the two-stage reduction handles 64 < n_orb <= 1024");
+    TBK_ARG(method != TBK_REDUCE_ONE_STAGE || n_orb <= 512, "the one-stage reduction handles n_orb <= 512");
     if (nk == 0) return TBK_OK;
     TBK_ARG(H && d && e, "H / d / e is NULL");
     tbk_model* m = nullptr;

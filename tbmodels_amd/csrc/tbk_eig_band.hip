@@ -50,6 +50,11 @@ __device__ unsigned long long tbk_band_clock[32];
 #define TBK_TILE_NT 0
 #endif
 
+// Ablation switches for tools/band_ablate.sh (TIMING ONLY: each makes the results wrong; never defined in the library build).
+// They price the levers of the tile pass before anything is built on them (round 4):
+//   TBK_ABLATE_OPERANDS  every visit reads the partner's [V | W] / Vn operand blocks of ONE fixed block (always cached)
+//   TBK_ABLATE_BARRIER   no workgroup barrier per step of the pass
+//   TBK_ABLATE_STORES    the updated tiles are never stored (an upper bound for ANY scheme that defers the update)
 constexpr int PB = 8;    // panel height = band half-width
 constexpr int TS = 16;   // MFMA tile edge
 
@@ -214,16 +219,37 @@ __device__ __forceinline__ d2 sum_a2(d2 v) { return (d2){sum_a(v[0]), sum_a(v[1]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double sum_a8(double v) { return sum_a(v); }  // over the 8 lanes that share (slot, h)
 
+// the 16 working diagonals of the second stage, in LDS or in global memory: view[i] is element i either way
+template <bool GLOBAL>
+struct BandView {
+    d2* lds;
+    d2* glob;
+    __device__ __forceinline__ d2& operator[](size_t i) const {
+        if constexpr (GLOBAL)  // uniform base + 32-bit byte offset (a matrix' diagonals are < 4 GiB): scalar-base addressing
+            return *reinterpret_cast<d2*>(reinterpret_cast<char*>(glob) + (unsigned)((unsigned)i * 16u));
+        else
+            return lds[i];
+    }
+};
+
 // The body of the second stage for the calling workgroup's matrix: `band` = compact band (9 complex per row), or, when
 // it is null, the band is read from the upper triangle of the row-major matrix Hm itself (the fused kernel).  `smem` is
 // the workgroup's dynamic LDS (16 np complex + NW * 64 complex + n ints); Dm / Em receive the tridiagonal.
-template <int NW, bool FROM_H, int CALLER = 0>  // (one instantiation per calling kernel: each is inlined into it -- with two
-// callers of one instantiation hipcc keeps a real function call: 248 registers and a stack frame in both)
+// GBAND != nullptr (above 512 orbitals: 16 diagonals of 1024 columns are 264 KiB, more than a CU's LDS): the diagonals live
+// in that global buffer instead -- L2-resident, 264 KiB per matrix in flight -- and only the scratch and the schedule
+// stay in LDS.  Same code: a wave's own accesses are ordered, the steps of a tick touch disjoint cells, and every tick
+// ends on wg_sync (s_waitcnt vmcnt(0) + barrier: the workgroup's stores are visible to its other waves, same CU).
+template <int NW, bool FROM_H, int CALLER = 0, bool GLOBAL = false>  // (one instantiation per calling kernel: each is inlined
+// into it -- with two callers of one instantiation hipcc keeps a real function call: 248 registers and a stack frame in both)
 __device__ inline void chase4_body(const d2* __restrict__ band, const double* __restrict__ Hm, double* smem, int n, int np,
-                                            int stagger, double* __restrict__ Dm, double* __restrict__ Em) {
+                                            int stagger, double* __restrict__ Dm, double* __restrict__ Em, d2* gband = nullptr) {
     constexpr int NSLOT = 4 * NW;
-    d2* sL = reinterpret_cast<d2*>(smem);                           // [16][np]
-    d2* sScr = sL + (size_t)16 * np;                                // [NW][4 slots][16]: y (8) and x (8) by row
+    // (two differently typed views of the diagonals: the address space is a compile-time fact -- picked at run time the
+    // accesses were flat instructions and 24 more registers)
+    d2* const sLl = reinterpret_cast<d2*>(smem);
+    d2* const sLg = gband;
+    const BandView<GLOBAL> sL{sLl, sLg};
+    d2* sScr = GLOBAL ? reinterpret_cast<d2*>(smem) : sLl + (size_t)16 * np;  // [NW][4 slots][16]: y (8) and x (8) by row
     int* sStart = reinterpret_cast<int*>(sScr + NW * 64);           // [n] first tick of every sweep
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -232,7 +258,7 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
     d2* scr = sScr + (wave * 4 + g) * 16;
 
     for (int i = tid; i < 16 * np; i += NW * 64) sL[i] = (d2){0.0, 0.0};
-    __syncthreads();
+    wg_sync();
     for (int i = tid; i < n * (PB + 1); i += NW * 64) {
         const int j = i / (PB + 1), dd = i % (PB + 1);
         if (j + dd < n) {
@@ -315,7 +341,10 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
                 d2 n_va, n_vb[4], n_tau;
                 double beta;
                 reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
-                lds_fence();
+                if (GLOBAL)
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else
+                    lds_fence();
                 if (starting) {
                     va = n_va;
                     tau = n_tau;
@@ -420,6 +449,7 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
             wg_sync();
         }
     }
+    wg_sync();
     for (int j = tid; j < n; j += NW * 64) {
         Dm[j] = sL[j][0];
         double e = 0.0;
@@ -437,6 +467,17 @@ band_chase4_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, 
     extern __shared__ __attribute__((aligned(16))) double bc_smem[];
     const size_t mat = blockIdx.x;
     chase4_body<NW, false>(band_all + mat * (size_t)n * (PB + 1), nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
+}
+
+// above 512 orbitals: the 16 working diagonals in global memory, behind the compact band of the same matrix
+// (band_stride complex numbers per matrix: n (PB + 1) compact + 16 np working)
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+band_chase4g_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
+    const size_t mat = blockIdx.x;
+    d2* band = band_all + mat * band_stride;
+    chase4_body<NW, false, 1, true>(band, nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n, band + (size_t)n * (PB + 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,8 +499,8 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 // instantiation <512, 1, true> measured 31.7 us per 512 x 512 matrix against 29.7 and is no longer built).
 template <int NT, int ROWS, bool VN_LDS>
 __global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
-band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all, int np,
-                   int stagger, double* __restrict__ D, double* __restrict__ E) {
+band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
+                   size_t band_stride, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double br_smem[];
     const int tid = threadIdx.x;
@@ -536,14 +577,22 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             o.Jc = o.own_is_row ? o.I2 : o.I;
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) {
+#ifdef TBK_ABLATE_OPERANDS
+                const d2 v2 = VW[((size_t)I0 * 4 + sg) * 64 + lane];
+#else
                 const d2 v2 = VW[((size_t)o.I2 * 4 + sg) * 64 + lane];
+#endif
                 o.par.re[sg] = v2[0];
                 o.par.im[sg] = v2[1];
             }
             if (!VN_LDS) {
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg)
+#ifdef TBK_ABLATE_OPERANDS
+                    o.pb[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(I0 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+#else
                     o.pb[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(o.I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+#endif
             }
             // clamped addresses; rows / columns beyond n are masked when the tile is used
             const int gc = o.Jc * TS + lrow;
@@ -610,7 +659,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gr = Ir * TS + lq + 4 * r;
+#ifdef TBK_ABLATE_STORES
+                        if (gr < n && gc < n && tre[r] == 1.2345e300) {
+#else
                         if (gr < n && gc < n) {
+#endif
                             if (TBK_TILE_NT)
                                 __builtin_nontemporal_store((d2){tre[r], tim[r]}, Hat(gr, gc));
                             else
@@ -686,8 +739,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
             TBK_CLK(10);
             // the step's meeting point: LDS only (this wave's tile stores drain in the background)
+#ifndef TBK_ABLATE_BARRIER
             lds_fence();
             __syncthreads();
+#endif
             TBK_CLK(11);
             if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
                 if (wave + NW * q < na) {
@@ -1095,11 +1150,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // fused: this workgroup goes straight on to the second stage of its matrix, in the same LDS -- on a CU the
         // other workgroup is then in some phase of ITS matrix, and the matrix-pipe, memory and vector-issue phases of
         // the two overlap (two chase workgroups side by side are both limited by instruction issue)
-        chase4_body<NW, true, NT * 8 + ROWS>(nullptr, H, br_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
+        chase4_body<NW, true, NT * 16 + ROWS * 2 + (VN_LDS ? 1 : 0)>(nullptr, H, br_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
         return;
     }
     {
-        d2* band = band_all + mat * (size_t)n * (PB + 1);
+        d2* band = band_all + mat * band_stride;
         for (int idx = tid; idx < n * (PB + 1); idx += NT) {
             const int i = idx / (PB + 1), dd = idx - i * (PB + 1);
             band[idx] = (i + dd < n) ? *Hat(i, i + dd) : (d2){0.0, 0.0};
@@ -1127,6 +1182,16 @@ static int chase_pitch(int n) {
     return np;
 }
 
+bool tbk_band_fused(int n);
+constexpr int BAND_MAXN = 1024;  // two rows per thread of 512 threads; X (8 complex per row) is 128 KiB of LDS there
+constexpr int BAND_LDS_CHASE_MAXN = 512;  // above: the chase keeps its 16 diagonals in global memory
+// TBK_CHASE_GLOBAL=1 (measurements): the global-memory chase at every size that runs it as its own launch -- 9 KiB of LDS
+// and 158 registers per wave instead of 133 KiB at 512 orbitals, so its workgroups fit beside those of other kernels
+static bool chase_global(int n) {
+    static const bool forced = getenv("TBK_CHASE_GLOBAL") && atoi(getenv("TBK_CHASE_GLOBAL")) != 0;
+    return n > BAND_LDS_CHASE_MAXN || (forced && !tbk_band_fused(n));
+}
+
 // The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 189 orbitals on (129 until round 3): up to 128 the one-stage kernel of
 // tbk_eig_stream.hip (four waves per matrix, rows of two 64-column chunks) is faster -- 0.65 vs 0.84 us per matrix at 65
 // orbitals, 1.73 vs 2.14 at 128; from 129 on the one-stage rows grow a third chunk and the order flips (3.8 vs 3.3 us at 160).
@@ -1141,17 +1206,21 @@ bool tbk_band_fused(int n) {
     return forced >= 0 ? forced != 0 : n <= 256;
 }
 
-bool tbk_eig_band_supported(int n) { return n > 64 && n <= 512; }
+bool tbk_eig_band_supported(int n) { return n > 64 && n <= BAND_MAXN; }
 bool tbk_eig_band_preferred(int n) {
     // (round 3: the one-stage kernel hands its last 128 steps to the register-resident kernels -- eight waves per matrix
     // from 128 to 64, tbk_eig_small.hip -- which moved the crossover up: 1.34 vs 2.37 us per matrix at 130 orbitals, 1.96 vs
     // 2.57 at 144, 2.56 vs 3.02 at 160; reduction stage of 4096 matrices 12.2 vs 12.7 ms at 176, 13.4 vs 13.9 at 184,
     // 14.9 vs 14.4 at 192)
     static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 189;  // measurements only
-    return n >= from && n <= 512;
+    return n >= from && n <= BAND_MAXN;
 }
 
-size_t tbk_band_bytes_per_matrix(int n) { return (size_t)n * (PB + 1) * sizeof(d2); }
+// the compact band between the stages (9 complex per row) and, above 512 orbitals, the second stage's 16 working
+// diagonals behind it
+size_t tbk_band_bytes_per_matrix(int n) {
+    return ((size_t)n * (PB + 1) + (chase_global(n) ? (size_t)16 * chase_pitch(n) : 0)) * sizeof(d2);
+}
 
 // Stage one: the upper triangle of every d_H matrix is overwritten; d_vw: scratch of tbk_band_scratch_per_matrix(n)
 // bytes per matrix; d_band receives the band, tbk_band_bytes_per_matrix(n) bytes per matrix.
@@ -1164,7 +1233,13 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // workgroups still fit a CU (76 KiB each at 512 orbitals) -- with 512 threads / V in LDS only one did and nothing
     // overlapped its serial phases (31.7 instead of 29.7 us per 512 x 512 matrix; that instantiation is gone)
     const bool vn_lds = n <= 256;
-    constexpr int nw = 4;
+    // Calls of a few matrices (one k-point per call is what Z2Pack-style callers do, _tb_model.py:1103-1108): every matrix has
+    // a CU to itself anyway, so it gets EIGHT waves and one row per thread -- twice the waves on the tile pass, half the
+    // rows per thread in the thread-per-row phases.  By the size of the CALL (TBK_OPT_K_CHUNK must not change a result:
+    // the partial sums of eight waves differ from those of four in the last bit).  TBK_BAND_WIDE=0: off (measurements).
+    static const bool wide_env = !(getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 0);
+    const bool wide = wide_env && n <= 512 && std::max<int64_t>(m->call_nk, nk) <= 128;
+    const int nw = (n > 512 || wide) ? 8 : 4;
     size_t lds = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
     // d_de_fused: the workgroup runs the second stage too (same LDS) and writes (d, e) itself; d_band is not used
     const int np = chase_pitch(n);
@@ -1176,17 +1251,23 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
-    static std::atomic<bool> raised[2][TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised[5][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
     do {                                                                                                                        \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NTV, ROWSV, VNL>), 160 * 1024, raised[SLOT])); \
         hipLaunchKernelGGL((band_reduce_kernel<NTV, ROWSV, VNL>), dim3((unsigned)nk), dim3(NTV), lds, s, d_H, n, d_VW, d_VN,      \
-                           static_cast<d2*>(d_band), np, 2, d_D, d_E);                                                          \
+                           static_cast<d2*>(d_band), tbk_band_bytes_per_matrix(n) / sizeof(d2), np, 2, d_D, d_E);               \
     } while (0)
-    if (vn_lds)
+    if (wide && vn_lds)
+        TBK_REDUCE(512, 1, true, 3);
+    else if (wide)
+        TBK_REDUCE(512, 1, false, 4);
+    else if (vn_lds)
         TBK_REDUCE(256, 1, true, 0);
-    else
+    else if (n <= 512)
         TBK_REDUCE(256, 2, false, 1);
+    else  // 513 .. 1024 orbitals (round 4): eight waves, two rows per thread, one workgroup per CU (X alone is 128 KiB)
+        TBK_REDUCE(512, 2, false, 2);
 #undef TBK_REDUCE
     TBK_HIP(hipGetLastError());
     return TBK_OK;
@@ -1199,6 +1280,21 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
     double* d_D = d_de;
     double* d_E = d_de + (size_t)nk * n;
     StageTimer t(m, TBK_T_EIG, s);
+    if (chase_global(n)) {
+        const int np = chase_pitch(n);
+        // 32 sweeps in flight, two steps apart, from 512 orbitals on (a sweep is n / 8 >= 64 steps long); 16 below
+        static const int env_nwg = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
+        const int nwg = env_nwg ? env_nwg : (n <= 256 ? 4 : 8);
+        const size_t ldsg = (size_t)nwg * 64 * 16 + (size_t)n * sizeof(int) + 16;
+        d2* d_b = static_cast<d2*>(const_cast<void*>(d_band));
+        const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
+        if (nwg <= 4)
+            hipLaunchKernelGGL(band_chase4g_kernel<4>, dim3((unsigned)nk), dim3(256), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
+        else
+            hipLaunchKernelGGL(band_chase4g_kernel<8>, dim3((unsigned)nk), dim3(512), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
+        TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    }
     {
         const int np = chase_pitch(n);
         // Consecutive sweeps run `stagger` chase steps apart: 2 is the closest that keeps the steps of one tick on

@@ -769,7 +769,9 @@ hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double*
 
 }  // namespace
 
-bool tbk_eig_stream_supported(int n) { return n > 64 && n <= ST_MAXN; }
+// sizes the own solvers of this file and of tbk_eig_band.hip cover between them: the one-stage kernel here up to 512
+// orbitals, the two-stage reduction up to 1024 (round 4; rocSOLVER above)
+bool tbk_eig_stream_supported(int n) { return n > 64 && (n <= ST_MAXN || tbk_eig_band_supported(n)); }
 
 // two-stage reduction (tbk_eig_band.hip) unless TBK_BAND=0 asks for the one-stage kernel of this file
 bool tbk_eig_two_stage(const tbk_model* m) {
@@ -777,6 +779,7 @@ bool tbk_eig_two_stage(const tbk_model* m) {
         const char* v = getenv("TBK_BAND");
         return v == nullptr || atoi(v) != 0;
     }();
+    if (m->n_orb > ST_MAXN) return tbk_eig_band_supported(m->n_orb);  // above 512 orbitals there is no one-stage kernel
     return band && tbk_eig_band_preferred(m->n_orb);
 }
 
@@ -784,6 +787,10 @@ bool tbk_eig_two_stage(const tbk_model* m) {
 int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, double* d_de, int method) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
+    if (n > ST_MAXN && method == TBK_REDUCE_ONE_STAGE) {
+        tbk_set_error("the one-stage reduction handles n_orb <= %d (n_orb = %d)", ST_MAXN, n);
+        return TBK_ERR_ARGUMENT;
+    }
     if (method == TBK_REDUCE_TWO_STAGE || (method == TBK_REDUCE_AUTO && tbk_eig_two_stage(m))) {  // both stages in order on this stream (single-chunk calls, tbk_tridiagonal_reduce)
         TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
         if (tbk_band_fused(n)) return tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, nullptr, d_de);

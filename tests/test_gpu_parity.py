@@ -507,7 +507,8 @@ def _onsite_model(mat):
 
 @pytest.mark.parametrize("solver", ["auto", "rocsolver"])
 @pytest.mark.parametrize(
-    "n", [1, 2, 3, 8, 9, 12, 13, 16, 17, 32, 33, 40, 48, 49, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 200, 256, 257, 300, 384, 385, 512, 520]
+    "n", [1, 2, 3, 8, 9, 12, 13, 16, 17, 32, 33, 40, 48, 49, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 200, 256, 257, 300, 384, 385, 512,
+          513, 520, 768, 1000, 1024, 1030]
 )
 def test_eigensolver_structured_matrices(solver, n):
     """
@@ -517,10 +518,10 @@ def test_eigensolver_structured_matrices(solver, n):
     """
     from tbmodels_amd import _lib
 
-    if solver == "rocsolver" and n > 64 and n not in (65, 128, 256):
+    if solver == "rocsolver" and n > 64 and n not in (65, 128, 256, 520):
         pytest.skip("rocSOLVER path sampled at a few sizes only (slow)")
-    if solver == "rocsolver" and n > 512:
-        pytest.skip("above 512 orbitals 'auto' is the rocSOLVER path already")
+    if solver == "rocsolver" and n > 1024:
+        pytest.skip("above 1024 orbitals 'auto' is the rocSOLVER path already")
 
     rng = np.random.default_rng(100 + n)
     rand = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
@@ -582,7 +583,7 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
-@pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512])
+@pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512, 513, 700, 1024])
 def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     """``tbk_tridiagonal_reduce``: the reduction stage of the eigensolver alone (scipy's eigvalsh at _tb_model.py:1149 is
     this plus the tridiagonal stage) on random Hermitian batches whose lower triangle is poisoned with NaN -- only the
@@ -601,7 +602,7 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
 
     lib = _lib.lib()
     rng = np.random.default_rng(1000 + n)
-    nk = 9
+    nk = 9 if n <= 512 else 5
     m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
     h = (m + m.conj().transpose(0, 2, 1)) / 2
     h[1] *= 1e-30  # no absolute thresholds
@@ -635,12 +636,15 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), method, _lib.ptr(d2), _lib.ptr(e2), None))
     assert np.array_equal(d, d2) and np.array_equal(e, e2)
     for other in (_lib.TBK_REDUCE_AUTO, _lib.TBK_REDUCE_ONE_STAGE):  # every path: the same spectrum
+        if other == _lib.TBK_REDUCE_ONE_STAGE and n > 512:  # the one-stage kernel stops at 512 orbitals
+            assert lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(poisoned), other, _lib.ptr(d2), _lib.ptr(e2), None) == _lib.TBK_ERR_ARGUMENT
+            continue
         _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), other, _lib.ptr(d2), _lib.ptr(e2), None))
         for i in range(nk):
             ref = np.linalg.eigvalsh(h[i])
             got = la.eigvalsh_tridiagonal(d2[i], e2[i, :-1]) if n > 1 else d2[i]
             assert np.abs(got - ref).max() <= 1e-13 * n * np.abs(ref).max(), (other, i)
-    bad = lib.tbk_tridiagonal_reduce(0, 513, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
+    bad = lib.tbk_tridiagonal_reduce(0, 1025, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
     assert bad == _lib.TBK_ERR_ARGUMENT
     if n <= 64:
         assert lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(poisoned), 2, _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
