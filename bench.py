@@ -548,7 +548,7 @@ def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arra
         status = np.empty(world)
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(status), d_st, status.nbytes))
         if status.max() != 0:
-            raise SystemExit("cfg4 strong-scaling leg: status words %r" % (status,))
+            raise RuntimeError("cfg4 strong-scaling leg: status words %r" % (status,))
         if rank != 0:
             return None
         # checks on rank 0, over rows of EVERY rank's slab: trace identity on 4096 rows of the whole mesh, oracle on the
@@ -578,7 +578,7 @@ def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arra
             "max_trace_identity_err_4096_rows": trace_err,
         }
         if not (parity <= 1e-10 and trace_err <= 1e-10):
-            raise SystemExit("parity failure in the cfg4 strong-scaling leg: %r" % (entry,))
+            raise RuntimeError("parity failure in the cfg4 strong-scaling leg: %r" % (entry,))
         return entry
     finally:
         for p in pointers:
@@ -790,13 +790,6 @@ def main():
         per_rank = {"compute_ms": [round(float(p[0]), 3) for p in parts],
                     "allgather_ms": [round(float(p[1]), 3) for p in parts],
                     "note": "one step, not overlapped: eigenval on the rank's slab, then the RCCL all-gather alone"}
-    # --- N > 1, after the clock: BASELINE config 4, the one STRONG-scaling config -- the 100^3 mesh of the staged model in
-    # `world` contiguous slabs, every rank's slab evaluated into its rows of the full result with the RCCL all-gather of
-    # finished row blocks pipelined behind the k chunks (tbk_eigenval_device_gather), the gather INSIDE the timing ---------
-    strong = None
-    if comm is not None and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr \
-            and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1":  # (N = 1 with TBK_BENCH_FORCE_COMM=1: a one-rank communicator)
-        strong = strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays)
     host_api = None
     if world == 1 and rank == 0 and not args.construct_only and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
         # SURVEY 8(d) "Evidence": wall-clock through the drop-in surface -- host k in, host eigenvalues out (H2D of k,
@@ -883,10 +876,6 @@ def main():
             other["cfg4"] = run_other_config(lib, device, "cfg4", model=model, arrays=arrays)
             for name in ("cfg1", "cfg3", "cfg5"):
                 other[name] = run_other_config(lib, device, name, cpu_all=cpu_all_other.get(name))
-            if strong is not None:
-                other["cfg4_one_rank_communicator"] = strong
-        elif strong is not None:
-            other = {"cfg4": strong}
         result = {
             "metric": "k-points/sec (H(k)+eig) at N_orb=%d, N_R=%d" % (n_orb, n_r) if not args.construct_only
                       else "k-points/sec (H(k) construction only) at N_orb=%d, N_R=%d" % (n_orb, n_r),
@@ -924,7 +913,45 @@ def main():
             "max_abs_err_vs_oracle": parity,
             "max_trace_identity_err_4096_rows": trace_err,
         }
+    # --- after everything else: BASELINE config 4, the one STRONG-scaling config -- the 100^3 mesh of the staged model in
+    # `world` contiguous slabs, every rank's slab evaluated into its rows of the full result with the RCCL all-gather of
+    # finished row blocks pipelined behind the k chunks (tbk_eigenval_device_gather), the gather INSIDE the timing.  Every
+    # rank takes part (N = 1 only with TBK_BENCH_FORCE_COMM=1: a one-rank communicator).  The main line above is complete
+    # at this point: if the leg fails or does not come back (a rank lost in a collective), the line is printed WITHOUT it
+    # -- with the error under configs.cfg4 -- instead of being lost with the process.
+    strong_failed = False
+    if comm is not None and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr \
+            and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1":
+        import threading  # pylint: disable=import-outside-toplevel
+
+        key = "cfg4" if world > 1 else "cfg4_one_rank_communicator"
+
+        def attach(entry):
+            if result is not None:
+                if result.get("configs") is None:
+                    result["configs"] = {}
+                result["configs"][key] = entry
+
+        def give_up():
+            attach({"error": "the strong-scaling leg did not finish within %s s" % limit, "scaling": "strong", "n_gpus": world})
+            if result is not None:
+                print(json.dumps(result), flush=True)
+            os._exit(0 if result is not None else 3)  # pylint: disable=protected-access
+
+        limit = float(os.environ.get("TBK_BENCH_STRONG_TIMEOUT", "240"))
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            attach(strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays))
+        except Exception as exc:  # pylint: disable=broad-except
+            strong_failed = True
+            attach({"error": "%s: %s" % (type(exc).__name__, exc), "scaling": "strong", "n_gpus": world})
+        watchdog.cancel()
+    if rank == 0 and result is not None:
         print(json.dumps(result), flush=True)
+    if strong_failed:
+        sys.exit(4)
 
     if comm is not None:
         lib.tbk_comm_destroy(comm)
