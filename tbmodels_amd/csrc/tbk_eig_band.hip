@@ -874,8 +874,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 // ONE meeting per step: every wave leaves its 16 partial sums (alternating halves of its row of the
                 // partial-sum area), and every thread adds the waves' partials itself, in wave order
                 double* part = sPart + (c & 1) * 16;
+                // (reflector c needs 1 + 2 (7 - c) of the sixteen sums: whole groups of four beyond them are not reduced --
+                // 20 instead of 32 four-value reductions per panel)
 #pragma unroll
-                for (int k4 = 0; k4 < 16; k4 += 4) wave_partial4(k4, pv[k4], pv[k4 + 1], pv[k4 + 2], pv[k4 + 3], part, lane, wave);
+                for (int k4 = 0; k4 < 16; k4 += 4)
+                    if (k4 < 1 + 2 * (PB - 1 - c)) wave_partial4(k4, pv[k4], pv[k4 + 1], pv[k4 + 2], pv[k4 + 3], part, lane, wave);
                 TBK_CLK(13);  // QR: wave sums
                 lds_fence();
                 __syncthreads();
@@ -1177,8 +1180,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 size_t tbk_band_scratch_per_matrix(int n) { return (size_t)((n + TS - 1) / TS) * (256 + TS * PB) * sizeof(d2); }
 
 static int chase_pitch(int n) {
+    // TBK_CHASE_PITCH=r (measurements): pitch = r mod 16.  /tmp-style bank model of the four-sweeps-per-wave layout: 148 LDS
+    // cycles per tick at 9, 138 at 3 or 11 -- reads of two sweeps that share a 16-lane group collide at every pitch
+    static const int want = getenv("TBK_CHASE_PITCH") ? (atoi(getenv("TBK_CHASE_PITCH")) & 15) | 1 : 9;
     int np = n + PB;
-    while (np % 16 != 9) ++np;
+    while (np % 16 != want) ++np;
     return np;
 }
 
