@@ -920,8 +920,8 @@ def main():
     # at this point: if the leg fails or does not come back (a rank lost in a collective), the line is printed WITHOUT it
     # -- with the error under configs.cfg4 -- instead of being lost with the process.
     strong_failed = False
-    if comm is not None and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr \
-            and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1":
+    if comm is not None and args.config == "cfg2" and not args.construct_only and not args.nr \
+            and ((os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1" and not args.nk) or os.environ.get("TBK_BENCH_STRONG") == "1"):
         import threading  # pylint: disable=import-outside-toplevel
 
         key = "cfg4" if world > 1 else "cfg4_one_rank_communicator"

@@ -194,7 +194,9 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     TBK_TRY(TBK_ROCBLAS(rocblas_set_stream(m->blas, m->stream)));
     TBK_TRY(TBK_CHECK(m->ws_flag.reserve(2 * sizeof(int))));
     TBK_TRY(TBK_HIP(hipMemsetAsync(m->ws_flag.ptr, 0, 2 * sizeof(int), m->stream)));
-    m->h_stage_bytes = size_t(320) << 10;  // one H(k) of up to 128 orbitals, or a few hundred eigenvalue rows
+    // one H(k) (up to 1024 orbitals: 16 MiB) with its k-point and positions, or a few hundred eigenvalue rows
+    m->h_stage_bytes = std::max<size_t>(size_t(320) << 10,
+                                        n_orb <= 1024 ? (size_t)n_orb * n_orb * 16 + (size_t)n_orb * dim * 8 + (size_t(64) << 10) : 0);
     static const int stage_mode = getenv("TBK_STAGE_MODE") ? atoi(getenv("TBK_STAGE_MODE")) : 1;  // 0 off, 1 non-coherent, 2 coherent
     if (stage_mode == 0 || hipHostMalloc(&m->h_stage, m->h_stage_bytes, stage_mode == 1 ? hipHostMallocNonCoherent : hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
