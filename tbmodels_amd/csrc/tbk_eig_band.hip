@@ -498,7 +498,7 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 // with V beside it only ONE workgroup fits a CU -- nothing then overlaps its serial phases: the 8-wave / one-row
 // instantiation <512, 1, true> measured 31.7 us per 512 x 512 matrix against 29.7 and is no longer built).
 template <int NT, int ROWS, bool VN_LDS>
-__global__ void __launch_bounds__(NT, 512 / NT)  // two waves per SIMD: 2 x 256 or 1 x 512 threads per CU
+__global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
                    size_t band_stride, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
     constexpr int NW = NT / 64;
@@ -1257,14 +1257,21 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
-    static std::atomic<bool> raised[5][TBK_MAX_DEVICES] = {};
+    static std::atomic<bool> raised[6][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
     do {                                                                                                                        \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NTV, ROWSV, VNL>), 160 * 1024, raised[SLOT])); \
         hipLaunchKernelGGL((band_reduce_kernel<NTV, ROWSV, VNL>), dim3((unsigned)nk), dim3(NTV), lds, s, d_H, n, d_VW, d_VN,      \
                            static_cast<d2*>(d_band), tbk_band_bytes_per_matrix(n) / sizeof(d2), np, 2, d_D, d_E);               \
     } while (0)
-    if (wide && vn_lds)
+    // TBK_BAND_NARROW=1 (measurement, round 4): TWO waves per matrix and two rows per thread up to 256 orbitals -- four matrices
+    // per CU instead of two, the per-wave overhead of the serial phases (reductions, scalar chains) paid half as often per
+    // matrix; 38 KiB of LDS, second stage in its own launch
+    static const bool narrow_env = getenv("TBK_BAND_NARROW") && atoi(getenv("TBK_BAND_NARROW")) != 0;
+    if (narrow_env && !wide && n <= 256 && d_de_fused == nullptr) {
+        lds = (size_t)npad * PB * 16 + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+        TBK_REDUCE(128, 2, false, 5);
+    } else if (wide && vn_lds)
         TBK_REDUCE(512, 1, true, 3);
     else if (wide)
         TBK_REDUCE(512, 1, false, 4);
