@@ -1,4 +1,4 @@
-// tbk_eig_band.hip -- two-stage Householder tridiagonalisation for 64 < n_orb <= 512, one workgroup per matrix:
+// tbk_eig_band.hip -- two-stage Householder tridiagonalisation for 64 < n_orb <= 1024, one workgroup per matrix:
 //
 //   stage 1  band_reduce_kernel   dense -> band of half-width 8.  Panels of 8 rows; per panel ONE pass over the
 //                                 16 x 16 tiles of the stored (upper) triangle of the trailing matrix, on the matrix
@@ -6,7 +6,8 @@
 //                                 and the product with the next panel's V in the same visit of a tile.
 //   stage 2  chase4_body          band -> tridiagonal by Householder bulge chasing in LDS, four sweeps per wave,
 //                                 sweeps pipelined two steps apart; the tail of the stage-1 kernel up to 256
-//                                 orbitals (the band never leaves the LDS), band_chase4_kernel above.
+//                                 orbitals (the band never leaves the LDS), band_chase4_kernel up to 512,
+//                                 band_chase4g_kernel (the 16 working diagonals in global memory) up to 1024.
 //
 // Reference step: scipy.linalg.eigvalsh per k-point (/root/reference/src/tbmodels/_tb_model.py:1147-1150).
 // The one-stage reduction of tbk_eig_stream.hip reads the trailing triangle once per Householder step
@@ -1180,7 +1181,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 size_t tbk_band_scratch_per_matrix(int n) { return (size_t)((n + TS - 1) / TS) * (256 + TS * PB) * sizeof(d2); }
 
 static int chase_pitch(int n) {
-    // TBK_CHASE_PITCH=r (measurements): pitch = r mod 16.  /tmp-style bank model of the four-sweeps-per-wave layout: 148 LDS
+    // TBK_CHASE_PITCH=r (measurements): pitch = r mod 16.  Bank model of the four-sweeps-per-wave layout (DESIGN_LOG R4.2): 148 LDS
     // cycles per tick at 9, 138 at 3 or 11 -- reads of two sweeps that share a 16-lane group collide at every pitch
     static const int want = getenv("TBK_CHASE_PITCH") ? (atoi(getenv("TBK_CHASE_PITCH")) & 15) | 1 : 9;
     int np = n + PB;

@@ -263,13 +263,13 @@ hipError_t launch_lds(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
     const int n_slices = std::max(1, (((m->ncol + 63) & ~63) + slice_elems - 1) / slice_elems);
     const dim3 grid((unsigned)(8 * (int64_t)tiles_per_xcd * n_slices)), block(LDS_THREADS);
     if (sched) {
-        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, true>), (int)(80 * 1024), raised[1]);
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, true>), (int)(160 * 1024), raised[1]);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((hk_csr_lds_kernel<MODE, CONV, KT, true>), grid, block, lds, m->stream, d_A, m->d_sptr, m->d_srec_r,
                            m->d_srec_v, m->d_colmap, d_k, d_pos, m->dim, m->ncol, m->n_orb, m->n_r, nk, nk_pad, d_H, tiles_per_xcd,
                            slice_elems);
     } else {
-        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, false>), (int)(80 * 1024), raised[0]);
+        hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, false>), (int)(160 * 1024), raised[0]);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((hk_csr_lds_kernel<MODE, CONV, KT, false>), grid, block, lds, m->stream, d_A, m->d_cptr, m->d_rec_r,
                            m->d_rec_v, m->d_colmap, d_k, d_pos, m->dim, m->ncol, m->n_orb, m->n_r, nk, nk_pad, d_H, tiles_per_xcd,
@@ -291,6 +291,9 @@ hipError_t launch_lds_mode(tbk_model* m, const double* d_A, int64_t nk, int64_t 
 // phase tile of KT k-points x all lattice vectors in <= 80 KiB of LDS (two workgroups per CU): 8, 4, 2, 1, or 0 = no fit
 int tbk_csr_tile_kpoints(int64_t n_r) {
     const int64_t budget = 80 * 1024 / (int64_t)sizeof(double);
+    // TBK_CSR_KT16=1 (measurement, round 4): tiles of 16 k-points -- twice the FMAs per record decode, ONE workgroup per CU
+    static const bool kt16 = getenv("TBK_CSR_KT16") && atoi(getenv("TBK_CSR_KT16")) != 0;
+    if (kt16 && n_r > 0 && n_r * 34 <= 2 * budget - 1024) return 16;
     if (n_r <= 0 || n_r * 4 > budget) return 0;
     if (n_r * 18 <= budget) return 8;
     if (n_r * 10 <= budget) return 4;
@@ -409,7 +412,9 @@ int tbk_launch_hk_csr(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
     const int kt = tbk_csr_tile_kpoints(m->n_r);
     if (kt > 0) {
         StageTimer t(m, TBK_T_HK);
-        if (kt == 8)
+        if (kt == 16)
+            TBK_HIP((launch_lds_mode<16>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));
+        else if (kt == 8)
             TBK_HIP((launch_lds_mode<8>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));
         else if (kt == 4)
             TBK_HIP((launch_lds_mode<4>(m, d_A, nk, nk_pad, mode, convention, d_k, d_pos, d_H)));

@@ -243,15 +243,19 @@ def test_repeated_runs_are_bit_identical(n_orb, n_r, n_k, reps):
         assert np.array_equal(again, first)
 
 
-@pytest.mark.parametrize("n_orb,n_k,reps", [(256, 4096, 60), (150, 4096, 40), (130, 2048, 30), (400, 1024, 24), (512, 1024, 16)])
+@pytest.mark.parametrize("n_orb,n_k,reps", [(256, 4096, 60), (150, 4096, 40), (130, 2048, 30), (400, 1024, 24), (512, 1024, 16),
+                                            (640, 160, 8), (1024, 24, 5), (300, 64, 30), (512, 7, 20)])
 def test_two_stage_reduction_is_race_free(n_orb, n_k, reps):
     """The two-stage reduction (csrc/tbk_eig_band.hip) has a dozen phases per panel that meet at workgroup barriers and
     share LDS; a missing meeting shows up as a WRONG matrix once in ~10^5 (round 2: the last QR step's partial sums
     were overwritten by a wave that had run ahead -- 2 rows in 500 000, off by 1e-2).  Many repetitions of one call:
     every row must come out bit-identical every time, and right.  (130 and 150 orbitals take the one-stage cascade since
     round 3 -- streaming kernel, eight-wave register kernel, 64-row and packed kernels, each handing its trailing block
-    to the next through the head of the matrix' storage: the same kind of meeting points.)"""
-    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 16, syn.MODEL_SEED + n_orb)
+    to the next through the head of the matrix' storage: the same kind of meeting points.  Round 4: 640 and 1024 orbitals take
+    the eight-wave / two-rows-per-thread kernel and the second stage whose diagonals live in global memory -- its ticks meet
+    through s_waitcnt vmcnt(0) + barrier instead of LDS ordering --, calls of <= 128 matrices the eight-wave / one-row
+    kernels.)"""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 16 if n_orb <= 512 else 4, syn.MODEL_SEED + n_orb)
     k = syn.random_kpoints(n_k, seed=n_orb)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     first = model.eigenval_array(k).copy()

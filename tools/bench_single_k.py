@@ -11,11 +11,14 @@ import tbmodels_amd  # noqa: E402
 from tbmodels_amd import synthetic as syn  # noqa: E402
 from tbmodels_amd import _lib  # noqa: E402
 
-sizes = [int(x) for x in sys.argv[1:]] or [96, 128, 200, 256, 384, 512, 768, 1024]
+rocsolver = "--rocsolver" in sys.argv  # the library path (rocsolver_zheevd) instead of the own kernels, for comparison
+sizes = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [96, 128, 200, 256, 384, 512, 768, 1024]
 for n in sizes:
     r_vec, hop, pos = syn.dense_model_arrays(n, 16, syn.MODEL_SEED + n)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     k = syn.random_kpoints(64)
+    if rocsolver:
+        model.set_option(_lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_ROCSOLVER)
     for nk in (1, 7, 64):
         arg = k[0] if nk == 1 else k[:nk]
         reps = 20 if n <= 512 else 6
