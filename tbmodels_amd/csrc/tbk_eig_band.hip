@@ -490,6 +490,14 @@ __device__ __forceinline__ size_t vw_index(int row, int c) {
     return ((size_t)(row >> 4) * 4 + (c >> 2)) * 64 + (size_t)(c & 3) * 16 + (row & 15);
 }
 
+// workgroups that share the tile pass of ONE matrix in the launch chain: enough that a wave owns one block (two at 1024
+// orbitals), at most eight
+__host__ __device__ inline int tbk_band_split_members(int n, int nw) {
+    const int nbk = (n + TS - 1) / TS;
+    const int want = (nbk + nw - 1) / nw;
+    return want < 1 ? 1 : (want > 8 ? 8 : want);
+}
+
 struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l holds [l % 16][l / 16 + 4 s], s = 0..3
     double re[4], im[4];
 };
@@ -498,10 +506,23 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 // next panel's V in LDS beside X (up to 256 orbitals) or in global memory (above: X alone is 64 KiB at 512 orbitals, and
 // with V beside it only ONE workgroup fits a CU -- nothing then overlaps its serial phases: the 8-wave / one-row
 // instantiation <512, 1, true> measured 31.7 us per 512 x 512 matrix against 29.7 and is no longer built).
-template <int NT, int ROWS, bool VN_LDS>
+//
+// PHASE (round 4): 0 = the whole first stage of a matrix in one workgroup (what every call of more than a few matrices
+// takes).  For calls of a FEW matrices the first stage is a chain of launches instead -- one matrix' tile pass is bounded
+// by the matrix pipe of the ONE CU its workgroup sits on (0.3 ms of a 1.5 ms reduction at 256 orbitals, 2.3 of 7.9 ms at
+// 512; DESIGN_LOG.md R4.7), and the tiles of a pass are independent:
+//   PHASE 1, panel p, one workgroup per matrix: the W phase of panel p - 1 (from the sum of the members' partial products),
+//            then look-ahead, panel QR and T of panel p; V, T go to global memory;
+//   PHASE 2, panel p, `members` workgroups per matrix (blockIdx.x = member, blockIdx.y = matrix): the tile pass of panel p,
+//            the own blocks dealt out over the waves of ALL members; every member leaves its partial X in global memory.
+//            Behind the last panel the same launch applies the last pending update (no products).
+// Stream order is the only synchronisation between them (no spinning on flags: nothing can hang).
+template <int NT, int ROWS, bool VN_LDS, int PHASE = 0>
 __global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
-                   size_t band_stride, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
+                   size_t band_stride, int np, int stagger, double* __restrict__ D, double* __restrict__ E, int p_fixed = 0,
+                   d2* __restrict__ split_all = nullptr) {
+    static_assert(PHASE == 0 || !VN_LDS, "the launch chain keeps the next panel's V in global memory");
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double br_smem[];
     const int tid = threadIdx.x;
@@ -522,14 +543,24 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     d2* sT = sS + 64;                                      // [8][8] T of the current panel
     d2* sTau = sT + 64;                                    // [8]
 
-    const size_t mat = blockIdx.x;
+    // the launch chain: `members` workgroups share a matrix in PHASE 2; its waves and theirs are numbered through
+    const int members = PHASE == 2 ? (int)gridDim.x : 1;
+    const int member = PHASE == 2 ? (int)blockIdx.x : 0;
+    const int nw_all = NW * members;          // waves that share the tile pass of a matrix
+    const int wave_all = member * NW + wave;  // this wave among them
+    const size_t mat = PHASE == 2 ? blockIdx.y : blockIdx.x;
     double* H = Hall + mat * (size_t)n * n * 2;
     d2* VW = VWall + mat * (size_t)nbk * 256;
     d2* sVn = VN_LDS ? sVnL : VNall + mat * (size_t)npad * PB;  // the next panel's V, [npad][8], wherever it lives
+    // between the launches of the chain, per matrix: T of the panel (64) and the members' partial X ([member][npad][8])
+    const size_t split_stride = 64 + (size_t)tbk_band_split_members(n, NW) * npad * PB;
+    d2* gT = PHASE != 0 ? split_all + mat * split_stride : nullptr;
+    d2* gX = PHASE != 0 ? gT + 64 : nullptr;
 
     // the pending-update buffer starts out empty
-    for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
-    bool have_update = false;
+    if (PHASE == 0 || (PHASE == 1 && p_fixed == 0))
+        for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
+    bool have_update = PHASE != 0 && p_fixed > 0;
 #ifdef TBK_PHASE_CLOCK
     unsigned long long clk_acc_[16];
 #pragma unroll
@@ -549,7 +580,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         const int na = nbk - I0;
         const int lrow = lane & 15, lq = lane >> 4;
         double* tr = sTr + wave * (16 * 17);
-        const int n_q = (na + NW - 1) / NW;
+        const int n_q = (na + nw_all - 1) / nw_all;
         const int n_t = na / 2;
         const int n_visits = n_q * (n_t + 1);
 
@@ -565,7 +596,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             // a record that is not `active` loads some valid tile and is ignored
             const int vq = min(v, n_visits - 1);
             const int q = vq / (n_t + 1), t = vq - q * (n_t + 1);
-            const int a_raw = wave + NW * q;
+            const int a_raw = wave_all + nw_all * q;
             const int a = min(a_raw, na - 1);
             o.active = v < n_visits && a_raw < na && !((na & 1) == 0 && t == n_t && t > 0 && a_raw >= n_t);
             int a2 = a + t;
@@ -746,9 +777,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #endif
             TBK_CLK(11);
             if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
-                if (wave + NW * q < na) {
+                if (wave_all + nw_all * q < na) {
                     double* xs = reinterpret_cast<double*>(sX);
-                    const int I = I0 + wave + NW * q;
+                    const int I = I0 + wave_all + nw_all * q;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double rot = dpp_mov<0x128>(own2[r]);
@@ -776,13 +807,34 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 
     // thread t <-> global rows / columns t + rr NT, rr < ROWS, in the thread-per-row phases
     auto row_of = [&](int rr) { return tid + rr * NT; };
-    int p = 0;
+    if (PHASE == 2) {
+        // the tile pass of panel p_fixed on this member's share of the own blocks; its partial X goes to global memory.
+        // (Behind the last panel: the last pending update, no products.)
+        const int s = PB * (p_fixed + 1);
+        if (n - s >= 2) {
+            for (int i = tid; i < npad * PB; i += NT) sX[i] = (d2){0.0, 0.0};
+            wg_sync();
+            big_pass(s, have_update, true);
+            d2* mine = gX + (size_t)member * npad * PB;
+            for (int i = tid; i < npad * PB; i += NT) mine[i] = sX[i];
+        } else {
+            big_pass(PB * p_fixed, true, false);
+        }
+        return;
+    }
+    // PHASE 1 enters the loop in the MIDDLE of iteration p_fixed - 1 (its W phase) and leaves in front of the pass of p_fixed
+    bool resume_w = PHASE == 1 && p_fixed > 0;
+    int p = PHASE == 1 ? max(p_fixed - 1, 0) : 0;
     for (;; ++p) {
         const int g0 = PB * p;       // first row of the panel
         const int s = g0 + PB;       // start of the trailing matrix behind it
         const int m = n - s;
         if (m < 2) break;
+        bool qr_row[ROWS];           // rows of the trailing matrix behind the panel
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) qr_row[rr] = row_of(rr) >= s && row_of(rr) < n;
         TBK_CLK(6);
+        if (!resume_w) {  // (look-ahead .. tile pass: not indented)
         // ---- look-ahead: block row p (8 rows, columns >= 8 p) brought up to date with the pending (V, W) ----
         // the 8 pending rows [V | W][g0 + r][0 .. 15]: lane t of every row of 16 lanes holds entry t, and the FMAs below
         // take it from there (row_newbcast) -- through LDS they were 128 broadcast reads per thread and panel, and two
@@ -835,10 +887,8 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         TBK_CLK(0);
         // ---- Householder QR of the panel on rows i >= s: y = conj(x) (model: panel_qr) ----
         d2 y[ROWS][PB], vn[ROWS][PB];
-        bool qr_row[ROWS];
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
-            qr_row[rr] = row_of(rr) >= s && row_of(rr) < n;
 #pragma unroll
             for (int c = 0; c < PB; ++c) {
                 y[rr][c] = qr_row[rr] ? conjd(x[rr][c]) : (d2){0.0, 0.0};
@@ -1019,8 +1069,28 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
         wg_sync();
         TBK_CLK(3);
+        if (PHASE == 1) {  // the pass of this panel is the next launch; T waits for the W phase in global memory
+            if (tid < 64) gT[tid] = sT[tid];
+            return;
+        }
         big_pass(s, have_update, true);
         TBK_CLK(4);
+        } else {
+            // PHASE 1, first trip: X = the sum of the members' partial products (in member order), T of that panel
+            const int mem_n = tbk_band_split_members(n, NW);
+            for (int i = tid; i < npad * PB; i += NT) {
+                d2 acc = (d2){0.0, 0.0};
+                for (int g = 0; g < mem_n; ++g) {
+                    const d2 v = gX[(size_t)g * npad * PB + i];
+                    acc[0] += v[0];
+                    acc[1] += v[1];
+                }
+                sX[i] = acc;
+            }
+            if (tid < 64) sT[tid] = gT[tid];
+            wg_sync();
+            resume_w = false;
+        }
         // ---- W = X T - V S / 2,  S = T^H (V^H X) T  (model: stage1_band) ----
         d2 xr[ROWS][PB], vr[ROWS][PB];  // this thread's rows of A V and of V, read back (nothing lives in registers over the pass)
 #pragma unroll
@@ -1146,6 +1216,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         TBK_CLK(5);
     }
     // the last pending update (no look-ahead consumed any of its rows)
+    if constexpr (PHASE == 0) {  // (in the launch chain the last pending update and the band's way out are launches of their own)
     if (have_update) big_pass(PB * p, true, false);
     // the band leaves in compact form -- band[i][dd] = H[i][i + dd], dd = 0..8 -- so that the matrix buffer is free for
     // the next chunk's H(k) while the second stage still works on this one
@@ -1169,6 +1240,18 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     if (blockIdx.x == 0 && threadIdx.x == NT - 64)
         for (int k = 0; k < 16; ++k) tbk_band_clock[k] = clk_acc_[k];
 #endif
+    }  // PHASE == 0
+}
+
+// The band's way out of the matrix for the launch chain: band[i][dd] = H[i][i + dd], dd = 0..8 (what the tail of the one-launch
+// kernel does).
+__global__ void __launch_bounds__(256) band_extract_kernel(const double* __restrict__ Hall, int n, d2* __restrict__ band_all, size_t band_stride) {
+    const double* H = Hall + (size_t)blockIdx.x * n * n * 2;
+    d2* band = band_all + (size_t)blockIdx.x * band_stride;
+    for (int idx = threadIdx.x; idx < n * (PB + 1); idx += 256) {
+        const int i = idx / (PB + 1), dd = idx - i * (PB + 1);
+        band[idx] = (i + dd < n) ? *reinterpret_cast<const d2*>(H + ((size_t)i * n + i + dd) * 2) : (d2){0.0, 0.0};
+    }
 }
 
 }  // namespace
@@ -1229,6 +1312,50 @@ size_t tbk_band_bytes_per_matrix(int n) {
     return ((size_t)n * (PB + 1) + (chase_global(n) ? (size_t)16 * chase_pitch(n) : 0)) * sizeof(d2);
 }
 
+// Calls of a few matrices (Z2Pack-style lines and single k-points, _tb_model.py:1103-1108; band-structure paths of a few dozen
+// points): the first stage as a chain of launches (PHASE 1 / 2 of band_reduce_kernel), so that every tile pass runs on
+// `members` CUs per matrix instead of one.  By the size of the CALL (TBK_OPT_K_CHUNK must not change a result: the partial
+// sums of the members differ from one workgroup's in the last bit).  TBK_BAND_SPLIT=0: off (measurements).
+bool tbk_band_split(const tbk_model* m, int64_t nk) {
+    static const bool on = !(getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 0);
+    static const int64_t forced_limit = getenv("TBK_BAND_SPLIT_MAX") ? atoll(getenv("TBK_BAND_SPLIT_MAX")) : 0;
+    const int n = m->n_orb;
+    if (!on || n <= 128 || n > BAND_MAXN) return false;
+    // as long as every member workgroup of every matrix finds a CU of its own: 256 / members matrices (64 up to 512 orbitals,
+    // 32 at 1024).  Measured (one k-point per call, reduction stage): 256 orbitals 2.11 -> 2.04 ms, 384: 4.62 -> 3.80, 512: 8.31 ->
+    // 6.01, 1024: 49.0 -> 24.4
+    const int64_t limit = forced_limit > 0 ? forced_limit : 256 / tbk_band_split_members(n, n <= 256 ? 4 : 8);
+    return std::max<int64_t>(m->call_nk, nk) <= limit;
+}
+
+template <int NT, int ROWS>
+static int launch_split(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t nk, d2* d_VW, d2* d_VN, d2* d_band, size_t lds) {
+    constexpr int NW = NT / 64;
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const int members = tbk_band_split_members(n, NW);
+    const size_t split_stride = 64 + (size_t)members * npad * PB;
+    TBK_CHECK(m->ws_split.reserve((size_t)nk * split_stride * sizeof(d2)));
+    d2* d_split = m->ws_split.as<d2>();
+    static std::atomic<bool> raised1[TBK_MAX_DEVICES] = {}, raised2[TBK_MAX_DEVICES] = {};
+    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NT, ROWS, false, 1>), 160 * 1024, raised1));
+    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_reduce_kernel<NT, ROWS, false, 2>), 160 * 1024, raised2));
+    const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
+    const int np = chase_pitch(n);
+    int p_end = 0;  // first panel without a trailing matrix behind it: n - 8 (p + 1) < 2
+    while (n - PB * (p_end + 1) >= 2) ++p_end;
+    for (int p = 0; p <= p_end; ++p) {
+        // PHASE 1 of panel p (p_end: only the W phase of the last panel); PHASE 2: its pass (p_end: the last pending update)
+        hipLaunchKernelGGL((band_reduce_kernel<NT, ROWS, false, 1>), dim3((unsigned)nk), dim3(NT), lds, s, d_H, n, d_VW, d_VN, d_band, stride,
+                           np, 2, (double*)nullptr, (double*)nullptr, p, d_split);
+        if (p == p_end && p_end == 0) break;  // (n < 10: nothing was ever pending)
+        hipLaunchKernelGGL((band_reduce_kernel<NT, ROWS, false, 2>), dim3((unsigned)members, (unsigned)nk), dim3(NT), lds, s, d_H, n, d_VW,
+                           d_VN, d_band, stride, np, 2, (double*)nullptr, (double*)nullptr, p, d_split);
+    }
+    hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)nk), dim3(256), 0, s, d_H, n, d_band, stride);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
 // Stage one: the upper triangle of every d_H matrix is overwritten; d_vw: scratch of tbk_band_scratch_per_matrix(n)
 // bytes per matrix; d_band receives the band, tbk_band_bytes_per_matrix(n) bytes per matrix.
 int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band, double* d_de_fused) {
@@ -1258,6 +1385,13 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
+    if (d_de_fused == nullptr && tbk_band_split(m, nk)) {
+        // the launch chain: one row per thread where the rows allow it (the serial phases are thread-per-row)
+        auto lds_for = [&](int waves) { return (size_t)npad * PB * 16 + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16; };
+        if (n <= 256) return launch_split<256, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(4));
+        if (n <= 512) return launch_split<512, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8));
+        return launch_split<512, 2>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8));
+    }
     static std::atomic<bool> raised[6][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
     do {                                                                                                                        \

@@ -215,6 +215,7 @@ struct tbk_model {
     DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
     DevBuf ws_band;   // two-stage reduction: pending [V | W] panel of every matrix of a chunk
     DevBuf ws_bandmat[2];  // ... and the band matrices between its stages (one per chunk in flight)
+    DevBuf ws_split;  // calls of a few matrices: T and the members' partial X between the launches of the first stage
     // Set for the duration of one eigenvalue call by tbk_eigenval_device_gather (tbk_comm.hip): the chunk pipeline calls it
     // whenever the eigenvalues of rows [c0, c0 + nkc) of the call have been enqueued, with an event recorded behind
     // them -- the all-gather of finished rows leaves on the communicator's stream while later chunks compute.
@@ -296,6 +297,8 @@ bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this mo
 int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band,
                            double* d_de_fused = nullptr);
 bool tbk_band_fused(int n);  // both stages in one kernel (<= 256 orbitals) or two launches, the second one overlappable
+// calls of a few matrices: the first stage as a chain of launches, every tile pass on several CUs (never fused with stage two)
+bool tbk_band_split(const tbk_model* m, int64_t nk);
 int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de);
 
 // tbk_eig_small.hip

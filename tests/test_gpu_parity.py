@@ -650,6 +650,39 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
         assert lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(poisoned), 2, _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
 
 
+@pytest.mark.parametrize("n_orb", [200, 300, 520])
+def test_launch_chain_of_small_calls_agrees_with_the_one_launch_kernel(n_orb):
+    """Calls of a few matrices take the first stage of the two-stage reduction as a chain of launches (every tile pass on
+    several CUs, csrc/tbk_eig_band.hip PHASE 1 / 2); TBK_BAND_SPLIT=0 (read once per process) keeps the one-launch kernels:
+    the same eigenvalues to rounding, both within 1e-10 of the oracle; the chain is deterministic."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 5, syn.MODEL_SEED + 400 + n_orb)
+    k = syn.random_kpoints(9, seed=n_orb)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    here = model.eigenval_array(k)
+    assert np.array_equal(here, model.eigenval_array(k))
+    one = model.eigenval(k[0])
+    assert np.abs(one - here[0]).max() < 1e-12
+    _close(here, np.array(oracle.eigenval(r_vec, hop, k)))
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import tbmodels_amd; from tbmodels_amd import synthetic as syn\n"
+        "r, h, p = syn.dense_model_arrays(%d, 5, syn.MODEL_SEED + 400 + %d)\n"
+        "m = tbmodels_amd.Model.from_packed(r, h, pos=p)\n"
+        "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(9, seed=%d)))\n" % (root, n_orb, n_orb, n_orb)
+    )
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "e.npy")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, TBK_BAND_SPLIT="0"), timeout=300)
+        other = np.load(out)
+    assert np.abs(other - here).max() < 1e-11
+
+
 def test_two_stage_and_one_stage_reductions_agree():
     """TBK_BAND=0 (read once per process) selects the one-stage streaming reduction of tbk_eig_stream.hip: same
     eigenvalues to rounding as the default two-stage path, on a multi-chunk call."""

@@ -15,6 +15,7 @@ StageTimer::StageTimer(tbk_model* m_, int, hipStream_t s) : m(m_), on(false), st
 StageTimer::~StageTimer() {}
 
 int main(int argc, char** argv) {
+    setenv("TBK_BAND_SPLIT", "0", 1);  // (this driver has no workspace allocator: the one-launch kernels only)
     const int n = argc > 1 ? atoi(argv[1]) : 256;
     const int nk = argc > 2 ? atoi(argv[2]) : 4096;
     std::vector<double> h((size_t)n * n * 2);
