@@ -1324,7 +1324,8 @@ bool tbk_band_split(const tbk_model* m, int64_t nk) {
     // as long as every member workgroup of every matrix finds a CU of its own: 256 / members matrices (64 up to 512 orbitals,
     // 32 at 1024).  Measured (one k-point per call, reduction stage): 256 orbitals 2.11 -> 2.04 ms, 384: 4.62 -> 3.80, 512: 8.31 ->
     // 6.01, 1024: 49.0 -> 24.4
-    const int64_t limit = forced_limit > 0 ? forced_limit : 256 / tbk_band_split_members(n, n <= 256 ? 4 : 8);
+    // (up to 256 orbitals the serial launches dominate and 64 matrices in one launch are as fast: 2.49 vs 2.40 ms -- 8 there)
+    const int64_t limit = forced_limit > 0 ? forced_limit : (n <= 256 ? 8 : 256 / tbk_band_split_members(n, 8));
     return std::max<int64_t>(m->call_nk, nk) <= limit;
 }
 
