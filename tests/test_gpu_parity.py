@@ -662,7 +662,7 @@ def test_launch_chain_of_small_calls_agrees_with_the_one_launch_kernel(n_orb):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r_vec, hop, pos = syn.dense_model_arrays(n_orb, 5, syn.MODEL_SEED + 400 + n_orb)
-    k = syn.random_kpoints(9, seed=n_orb)
+    k = syn.random_kpoints(7, seed=n_orb)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     here = model.eigenval_array(k)
     assert np.array_equal(here, model.eigenval_array(k))
@@ -674,7 +674,7 @@ def test_launch_chain_of_small_calls_agrees_with_the_one_launch_kernel(n_orb):
         "import tbmodels_amd; from tbmodels_amd import synthetic as syn\n"
         "r, h, p = syn.dense_model_arrays(%d, 5, syn.MODEL_SEED + 400 + %d)\n"
         "m = tbmodels_amd.Model.from_packed(r, h, pos=p)\n"
-        "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(9, seed=%d)))\n" % (root, n_orb, n_orb, n_orb)
+        "np.save(sys.argv[1], m.eigenval_array(syn.random_kpoints(7, seed=%d)))\n" % (root, n_orb, n_orb, n_orb)
     )
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "e.npy")
