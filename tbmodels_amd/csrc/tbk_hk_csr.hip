@@ -125,9 +125,12 @@ hk_csr_lds_kernel(const double* __restrict__ A, const int64_t* __restrict__ cptr
     // slice of `slice_elems` packed elements -- its ~64 resident workgroups then read the same ~1.4 MB of records, which
     // stay in that XCD's 4 MB L2.  With every workgroup sweeping ALL elements for its tile the 22 MB record stream was
     // re-read from beyond L2 by each of them (L2 hit rate 42 %, waves waiting 70 % of their time).
+    // (tiles_per_xcd == 0: a handful of k tiles -- one-k calls: fewer tiles than XCDs would leave the others idle; workgroup b
+    // takes tile b % n_tiles, slice b / n_tiles, and the slices are single rounds so that the element sweep spreads over the chip)
+    const int n_tiles_flat = (int)((nk + KT - 1) / KT);
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int64_t tile = (int64_t)xcd * tiles_per_xcd + seq % tiles_per_xcd;
-    const int slice = seq / tiles_per_xcd;
+    const int64_t tile = tiles_per_xcd > 0 ? (int64_t)xcd * tiles_per_xcd + seq % tiles_per_xcd : (int64_t)(blockIdx.x % n_tiles_flat);
+    const int slice = tiles_per_xcd > 0 ? seq / tiles_per_xcd : (int)(blockIdx.x / n_tiles_flat);
     const int64_t k0 = tile * KT;
     if (k0 >= nk) return;
     for (int64_t idx = threadIdx.x; idx < n_r * KT; idx += LDS_THREADS) {
@@ -258,10 +261,11 @@ hipError_t launch_lds(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pa
     // slices of 4 x 1024 packed elements (measured: 1 -> 18.5, 2 -> 17.0, 3 -> 16.6, 4 -> 16.1, 6 -> 18.3, 8 -> 19.8 ms per 50 000 k-points at cfg3) (TBK_CSR_SLICE_ROUNDS: measurements); one slice = the whole triangle for small models
     static const int slice_rounds = getenv("TBK_CSR_SLICE_ROUNDS") ? std::max(1, atoi(getenv("TBK_CSR_SLICE_ROUNDS"))) : 4;
     const int64_t n_tiles = (nk + KT - 1) / KT;
-    const int tiles_per_xcd = (int)((n_tiles + 7) / 8);
-    const int slice_elems = slice_rounds * LDS_THREADS;
+    const bool flat = n_tiles < 8;  // one-k calls and short lines: see the kernel
+    const int tiles_per_xcd = flat ? 0 : (int)((n_tiles + 7) / 8);
+    const int slice_elems = (flat ? 1 : slice_rounds) * LDS_THREADS;
     const int n_slices = std::max(1, (((m->ncol + 63) & ~63) + slice_elems - 1) / slice_elems);
-    const dim3 grid((unsigned)(8 * (int64_t)tiles_per_xcd * n_slices)), block(LDS_THREADS);
+    const dim3 grid((unsigned)(flat ? n_tiles * n_slices : 8 * (int64_t)tiles_per_xcd * n_slices)), block(LDS_THREADS);
     if (sched) {
         hipError_t e = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_csr_lds_kernel<MODE, CONV, KT, true>), (int)(160 * 1024), raised[1]);
         if (e != hipSuccess) return e;
