@@ -56,6 +56,8 @@ __device__ unsigned long long tbk_band_clock[32];
 //   TBK_ABLATE_OPERANDS  every visit reads the partner's [V | W] / Vn operand blocks of ONE fixed block (always cached)
 //   TBK_ABLATE_BARRIER   no workgroup barrier per step of the pass
 //   TBK_ABLATE_STORES    the updated tiles are never stored (an upper bound for ANY scheme that defers the update)
+//   TBK_ABLATE_STORES_ALT  ... stored on every second panel only: what "the rank-16 update every second panel" saves in
+//                        stores, before any of its costs (a K = 32 update, the corrections of the products)
 constexpr int PB = 8;    // panel height = band half-width
 constexpr int TS = 16;   // MFMA tile edge
 
@@ -693,6 +695,8 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         const int gr = Ir * TS + lq + 4 * r;
 #ifdef TBK_ABLATE_STORES
                         if (gr < n && gc < n && tre[r] == 1.2345e300) {
+#elif defined(TBK_ABLATE_STORES_ALT)
+                        if (gr < n && gc < n && ((s / PB) & 1) == 0) {  // stores on every SECOND panel only
 #else
                         if (gr < n && gc < n) {
 #endif

@@ -6,9 +6,9 @@
 #   GPU box:     bash tools/band_ablate.sh run > gpurun_out/ablate.txt
 cd "$(dirname "$0")/.."
 mkdir -p tools/exp
-VARIANTS=("" "-DTBK_ABLATE_OPERANDS" "-DTBK_ABLATE_BARRIER" "-DTBK_ABLATE_STORES" "-DTBK_ABLATE_OPERANDS -DTBK_ABLATE_BARRIER"
+VARIANTS=("" "-DTBK_ABLATE_OPERANDS" "-DTBK_ABLATE_BARRIER" "-DTBK_ABLATE_STORES" "-DTBK_ABLATE_STORES_ALT" "-DTBK_ABLATE_OPERANDS -DTBK_ABLATE_BARRIER"
           "-DTBK_ABLATE_OPERANDS -DTBK_ABLATE_BARRIER -DTBK_ABLATE_STORES")
-NAMES=(base operands barrier stores operands_barrier all_three)
+NAMES=(base operands barrier stores stores_alt operands_barrier all_three)
 if [ "$1" = build ]; then
   for i in "${!VARIANTS[@]}"; do
     hipcc -O3 -std=c++17 --offload-arch=gfx950 ${VARIANTS[$i]} -Iinclude -Itbmodels_amd/csrc tools/band_phase_clock.hip \

@@ -18,8 +18,8 @@ import os
 import shutil
 import sys
 
-KERNELS = ("hk_dense", "hk_csr", "herm_tridiag4", "herm_tridiag_packed", "herm_tridiag_stream", "band_reduce", "band_chase",
-           "phase_rows", "tridiag_ql", "tridiag_bisect", "fold_rows")
+KERNELS = ("hk_dense", "hk_csr", "herm_tridiag4", "herm_tridiag8", "herm_tridiag_packed", "herm_tridiag_stream", "band_reduce",
+           "band_chase", "band_extract", "phase_rows", "tridiag_ql", "tridiag_bisect", "fold_rows", "gather_place")
 CONFIG_NOTE = {
     "cfg2": "cfg2: dense N_orb=64, N_R=4096, 100 000 random k-points (the bench line)",
     "cfg3": "cfg3: CSR N_orb=256, N_R=512, 50 000 random k-points",
