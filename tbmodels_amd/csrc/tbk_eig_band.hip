@@ -1325,11 +1325,11 @@ bool tbk_band_split(const tbk_model* m, int64_t nk) {
     static const int64_t forced_limit = getenv("TBK_BAND_SPLIT_MAX") ? atoll(getenv("TBK_BAND_SPLIT_MAX")) : 0;
     const int n = m->n_orb;
     if (!on || n <= 128 || n > BAND_MAXN) return false;
-    // as long as every member workgroup of every matrix finds a CU of its own: 256 / members matrices (64 up to 512 orbitals,
-    // 32 at 1024).  Measured (one k-point per call, reduction stage): 256 orbitals 2.11 -> 2.04 ms, 384: 4.62 -> 3.80, 512: 8.31 ->
+    // as long as every member workgroup of every matrix finds a CU of its own: n_cu / members matrices (on 256 CUs: 64 up to
+    // 512 orbitals, 32 at 1024).  Measured (one k-point per call, reduction stage): 256 orbitals 2.11 -> 2.04 ms, 384: 4.62 -> 3.80, 512: 8.31 ->
     // 6.01, 1024: 49.0 -> 24.4
     // (up to 256 orbitals the serial launches dominate and 64 matrices in one launch are as fast: 2.49 vs 2.40 ms -- 8 there)
-    const int64_t limit = forced_limit > 0 ? forced_limit : (n <= 256 ? 8 : 256 / tbk_band_split_members(n, 8));
+    const int64_t limit = forced_limit > 0 ? forced_limit : (n <= 256 ? 8 : std::max(1, m->n_cu) / tbk_band_split_members(n, 8));
     return std::max<int64_t>(m->call_nk, nk) <= limit;
 }
 
