@@ -247,6 +247,14 @@ def test_chunk_pipelined_gather_equals_the_in_stream_gather(small_model):
         assert rc == 0 and status[0] == 0 and np.array_equal(out[:5000], plain) and not out[5000:].any()
         out, status, rc = _gather_call(lib, comm, handle, rand[:0], 300, 128, 0)
         assert rc == 0 and status[0] == 0 and not out.any()
+        # a path without chunk events (rocSOLVER): every block leaves behind the main stream at the end of the call
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_ROCSOLVER))
+        try:
+            plain = model.eigenval_array(rand[:3000])
+            out, status, rc = _gather_call(lib, comm, handle, rand[:3000], 3000, 700, 0)
+            assert rc == 0 and status[0] == 0 and np.array_equal(out, plain)
+        finally:
+            _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_AUTO))
         # a NaN k-point: the status word says so, the flags are consumed (tbk_eigenval_check is clean afterwards)
         bad = rand[:3000].copy()
         bad[1234, 2] = np.nan
