@@ -475,17 +475,17 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
     return entry
 
 
-def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays, steps=3, warmup=1):
+def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays, steps=3, warmup=1, mesh=100):
     """cfg4 at N ranks (every rank calls this): rank r evaluates rows slab_bounds(10^6, N, r) of the 100^3 mesh.  One step =
     tbk_eigenval_device_gather (slab eigenvalues + pipelined all-gather into the [N][per][n] result on every rank) +
     a wait for the communicator's stream; barrier on both sides of the timed steps, MAX over ranks.  Returns rank 0's
     entry for ``configs.cfg4`` (None elsewhere)."""
     from tbmodels_amd.sharding import slab_bounds  # pylint: disable=import-outside-toplevel
 
-    total = 100 ** 3
+    total = mesh ** 3  # (mesh: the CPU test-suite walks this function with a small mesh and a stand-in library)
     lo, hi = slab_bounds(total, world, rank)
     per = -(-total // world)
-    k = np.ascontiguousarray(synthetic.grid_slab(100, lo, hi))
+    k = np.ascontiguousarray(synthetic.grid_slab(mesh, lo, hi))
     pointers = []
 
     def dmalloc(nbytes):
@@ -555,7 +555,7 @@ def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arra
         # first rows of the first and the last slab
         eig = np.empty((world * per, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig), d_all, eig.nbytes))
-        k_all = synthetic.grid_slab(100, 0, total)
+        k_all = synthetic.grid_slab(mesh, 0, total)
         trace_err = trace_identity_error(arrays, k_all, eig[:total])
         last_lo = slab_bounds(total, world, world - 1)[0]
         rows = np.r_[0:8, last_lo:last_lo + 8]
@@ -564,8 +564,9 @@ def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arra
         n_ranks = ctypes.c_int(0)
         _lib.check(lib.tbk_comm_ranks(comm, ctypes.byref(n_ranks), None))
         entry = {
-            "workload": "cfg4: dense N_orb=%d N_R=%d, 100^3 uniform mesh in %d contiguous slabs (one per GPU), eigenval + RCCL "
-                        "all-gather of the eigenvalues to every rank (pipelined behind the k chunks)" % (n_orb, len(arrays["R"]), world),
+            "workload": "cfg4: dense N_orb=%d N_R=%d, %d^3 uniform mesh in %d contiguous slabs (one per GPU), eigenval + RCCL "
+                        "all-gather of the eigenvalues to every rank (pipelined behind the k chunks)"
+                        % (n_orb, len(arrays["R"]), mesh, world),
             "value": round(total * steps / elapsed, 1), "unit": "k-points/s", "scaling": "strong", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "rccl_ranks": n_ranks.value, "kpoints_per_rank": per,

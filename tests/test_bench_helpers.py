@@ -51,3 +51,118 @@ def test_hk_roofline_entries_price_the_documented_work():
     b_k = 16.0 * 256 * 257 / 2 + 24
     assert sparse["bound"] == "hbm" and sparse["algorithmic_bytes_per_kpoint"] == b_k
     assert abs(sparse["achieved"] - b_k * 1e5 / 30.4e-3 / 1e9) < 0.5 and abs(sparse["frac"] - sparse["achieved"] / 8000.0) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py's strong-scaling leg (cfg4 at N ranks) with N = 2 on the CPU: a stand-in for libtbk that keeps "device" buffers in
+# NumPy arrays, evaluates slabs with the oracle and does the all-gather through the process group -- what is checked is the
+# leg's own logic (slabs, result layout [rank][per][n], per-rank timings, parity rows of the first and the last slab, the
+# trace identity over the whole mesh), which no one-GPU box can run at N > 1.
+# ------------------------------------------------------------------------------------------------
+class _StandInLib:
+    def __init__(self, group, world, rank, arrays):
+        import ctypes
+
+        self.ctypes = ctypes
+        self.group, self.world, self.rank, self.arrays = group, world, rank, arrays
+        self.buffers = {}
+        self.next_id = 1
+
+    def _buf(self, pointer):
+        value = pointer.value if hasattr(pointer, "value") else pointer
+        return self.buffers[int(value)]
+
+    def tbk_device_malloc(self, device, nbytes, out):
+        handle = self.next_id
+        self.next_id += 1
+        self.buffers[handle] = np.zeros(int(nbytes) // 8 + 1)
+        out._obj.value = handle
+        return 0
+
+    def tbk_device_free(self, device, pointer):
+        self.buffers.pop(int(pointer.value), None)
+        return 0
+
+    def _host(self, pointer, count):
+        return np.ctypeslib.as_array(self.ctypes.cast(pointer, self.ctypes.POINTER(self.ctypes.c_double)), shape=(count,))
+
+    def tbk_memcpy_h2d(self, device, dst, src, nbytes):
+        self._buf(dst)[: nbytes // 8] = self._host(src, nbytes // 8)
+        return 0
+
+    def tbk_memcpy_d2h(self, device, dst, src, nbytes):
+        self._host(dst, nbytes // 8)[:] = self._buf(src)[: nbytes // 8]
+        return 0
+
+    def tbk_model_set_option(self, *args):
+        return 0
+
+    def tbk_synchronize(self, *args):
+        return 0
+
+    def tbk_comm_synchronize(self, *args):
+        return 0
+
+    def tbk_comm_ranks(self, comm, count, rank):
+        count._obj.value = self.world
+        return 0
+
+    def _eig(self, d_k, nk):
+        from oracle import tbk_oracle as oracle
+
+        k = self._buf(d_k)[: nk * 3].reshape(nk, 3)
+        return np.array(oracle.eigenval(self.arrays["R"], self.arrays["hop"], k)).reshape(nk, -1)
+
+    def tbk_eigenval_device_hint(self, model, d_k, h_k, nk, d_out):
+        eig = self._eig(d_k, nk)
+        self._buf(d_out)[: eig.size] = eig.reshape(-1)
+        return 0
+
+    def tbk_eigenval_device_gather(self, comm, model, d_k, h_k, nk, per, host_status, d_all, d_status):
+        n = self.arrays["n_orb"]
+        slab = np.zeros((per, n))
+        if nk:
+            slab[:nk] = self._eig(d_k, nk)
+        pieces = self.group.all_gather_array(slab)
+        self._buf(d_all)[: self.world * per * n] = np.concatenate(pieces).reshape(-1)
+        self._buf(d_status)[: self.world] = 0.0
+        return 0
+
+
+def _strong_leg_worker(rank, world, out_dir):
+    import ctypes
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from tbmodels_amd import synthetic as syn
+    from tbmodels_amd.rendezvous import FileGroup
+
+    group = FileGroup(rank, world, os.path.join(out_dir, "rdzv"), token="leg")
+    r_vec, hop, pos = syn.dense_model_arrays(5, 12, syn.MODEL_SEED + 77)
+    arrays = dict(kind="dense", n_orb=5, R=r_vec, hop=hop, pos=pos)
+    lib = _StandInLib(group, world, rank, arrays)
+    entry = bench.strong_scaling_leg(lib, 0, ctypes.c_void_p(1), ctypes.c_void_p(2), group, world, rank, 5, arrays, steps=1,
+                                     warmup=1, mesh=7)  # 343 points: slabs of 172 and 171
+    with open(os.path.join(out_dir, "leg%d.json" % rank), "w") as handle:
+        json.dump(entry, handle)
+    group.close()
+
+
+def test_strong_scaling_leg_logic_with_two_ranks(tmp_path):
+    import json
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_strong_leg_worker, args=(rank, 2, str(tmp_path))) for rank in range(2)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(timeout=300)
+        assert proc.exitcode == 0, "worker exited with %r" % proc.exitcode
+    entry = json.load(open(tmp_path / "leg0.json"))
+    assert json.load(open(tmp_path / "leg1.json")) is None  # only rank 0 reports
+    assert entry["scaling"] == "strong" and entry["n_gpus"] == 2 and entry["rccl_ranks"] == 2 and entry["kpoints_per_rank"] == 172
+    assert entry["max_abs_err_vs_oracle"] <= 1e-12 and entry["max_trace_identity_err_4096_rows"] <= 1e-10
+    assert len(entry["per_rank"]["compute_ms"]) == 2 and len(entry["per_rank"]["exposed_gather_ms"]) == 2
+    assert entry["value"] > 0 and "7^3 uniform mesh in 2 contiguous slabs" in entry["workload"]
