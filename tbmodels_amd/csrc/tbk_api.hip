@@ -372,7 +372,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1], &m->ws_H2, &m->ws_split};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1], &m->ws_H2, &m->ws_split, &m->ws_posraw};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);
     delete m;
@@ -476,7 +476,10 @@ extern "C" int tbk_hamilton_device(tbk_model* m, const double* d_k, int64_t nk, 
         const bool own_rows = tbk_hk_inline_phases(m, nkc);  // a few k-points: the H(k) kernel makes its phase rows
         if (!own_rows) TBK_CHECK(fill_rows(m, kc, nkc, nk_pad, d_A));
         const double* d_orb = nullptr;
-        if (convention == 1) {
+        // (one-k host call on the matrix-vector path: the H(k) kernel forms the phases of its one k-point itself from the
+        // raw positions -- no orbital_phase_kernel launch)
+        const bool inline_orb = m->h_k_inline != nullptr && m->d_pos_inline != nullptr && nk == 1 && own_rows;
+        if (convention == 1 && !inline_orb) {
             TBK_CHECK(m->ws_orb.reserve((size_t)nkc * m->n_orb * 2 * sizeof(double)));
             TBK_CHECK(tbk_launch_orbital_phases(m, kc, d_pos, nkc, m->ws_orb.as<double>()));
             d_orb = m->ws_orb.as<double>();
@@ -1069,16 +1072,37 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
             char* st = static_cast<char*>(m->h_stage);
             TBK_CHECK(m->ws_k.reserve(k_bytes));
             TBK_CHECK(m->ws_out.reserve(h_bytes));
-            std::memcpy(st, k, k_bytes);
-            TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
+            // ONE k-point of a dense model (the Z2Pack call shape): k goes into the kernel arguments and the positions of
+            // convention 1 stay on the device from call to call -- two uploads and one launch less per call
+            const bool inline_k = nk == 1 && !m->sparse && !m->kdotp && tbk_hk_inline_phases(m, 1);
             const double* d_pos = nullptr;
-            if (convention == 1) {
-                TBK_CHECK(m->ws_pos.reserve(p_bytes));
-                std::memcpy(st + k_bytes, pos, p_bytes);
-                TBK_HIP(hipMemcpyAsync(m->ws_pos.ptr, st + k_bytes, p_bytes, hipMemcpyHostToDevice, m->stream));
-                d_pos = m->ws_pos.as<double>();
+            if (inline_k) {
+                if (convention == 1) {
+                    const size_t n_pos = (size_t)m->n_orb * m->dim;
+                    if (m->pos_cache.size() != n_pos || std::memcmp(m->pos_cache.data(), pos, p_bytes) != 0) {
+                        TBK_CHECK(m->ws_posraw.reserve(p_bytes));
+                        std::memcpy(st + k_bytes, pos, p_bytes);
+                        TBK_HIP(hipMemcpyAsync(m->ws_posraw.ptr, st + k_bytes, p_bytes, hipMemcpyHostToDevice, m->stream));
+                        m->pos_cache.assign(pos, pos + n_pos);
+                    }
+                    m->d_pos_inline = m->ws_posraw.as<double>();
+                    d_pos = m->d_pos_inline;  // (non-NULL for the argument checks; the kernels read pos_raw)
+                }
+                m->h_k_inline = k;
+            } else {
+                std::memcpy(st, k, k_bytes);
+                TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
+                if (convention == 1) {
+                    TBK_CHECK(m->ws_pos.reserve(p_bytes));
+                    std::memcpy(st + k_bytes, pos, p_bytes);
+                    TBK_HIP(hipMemcpyAsync(m->ws_pos.ptr, st + k_bytes, p_bytes, hipMemcpyHostToDevice, m->stream));
+                    d_pos = m->ws_pos.as<double>();
+                }
             }
-            TBK_CHECK(tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, m->ws_out.as<double>()));
+            const int rc_inline = tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, m->ws_out.as<double>());
+            m->h_k_inline = nullptr;
+            m->d_pos_inline = nullptr;
+            TBK_CHECK(rc_inline);
             TBK_HIP(hipMemcpyAsync(st + k_bytes + p_bytes, m->ws_out.ptr, h_bytes, hipMemcpyDeviceToHost, m->stream));
             TBK_CHECK(wait_main_stream(m));
             std::memcpy(H_out, st + k_bytes + p_bytes, h_bytes);
@@ -1133,9 +1157,17 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
         // small call: [k | E | flags] through the pinned buffer, everything enqueued, one synchronisation
         char* st = static_cast<char*>(m->h_stage);
         int* flag = reinterpret_cast<int*>(st + k_bytes + e_bytes);
-        std::memcpy(st, k, k_bytes);
-        TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
-        TBK_CHECK(eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>()));
+        // (one k-point of a dense model on the matrix-vector path: k travels in the kernel arguments, see tbk_hamilton)
+        const bool inline_k = nk == 1 && !m->sparse && !m->kdotp && tbk_hk_inline_phases(m, 1);
+        if (inline_k) {
+            m->h_k_inline = k;
+        } else {
+            std::memcpy(st, k, k_bytes);
+            TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
+        }
+        const int rc_inline = eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>());
+        m->h_k_inline = nullptr;
+        TBK_CHECK(rc_inline);
         TBK_HIP(hipMemcpyAsync(st + k_bytes, m->ws_out.ptr, e_bytes, hipMemcpyDeviceToHost, m->stream));
         TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
         TBK_CHECK(wait_main_stream(m));

@@ -84,7 +84,15 @@ struct HkArgs {
     int p_tiles;  // > 0: a tail launch of that many units
     int sub_splits;
     double* P2;
+    // one-k host calls (round 4; Z2Pack evaluates ONE k-point per call, _tb_model.py:1103-1108): the k-point travels in the
+    // kernel arguments instead of through an upload the kernels would have to wait for, and the convention-1 phases of the one
+    // k-point are formed where they are used from the raw orbital positions (no orbital_phase_kernel launch in front)
+    double k_val[TBK_MAX_DIM];
+    int k_inline;
+    const double* pos_raw;  // [n_orb][dim], with k_inline and convention 1
 };
+
+__device__ __forceinline__ double hk_kcomp(const HkArgs& a, int64_t kq, int d) { return a.k_inline ? a.k_val[d] : a.kpts[kq * a.dim + d]; }
 
 // One finished element of the packed tile -> H[k][i][j] (and H[k][j][i] conjugated in FULL mode), with the
 // convention-1 orbital phases if asked (_tb_model.py:1124-1128; the table e[k][p] = exp(2 pi i k.pos_p) is
@@ -92,8 +100,22 @@ struct HkArgs {
 template <int MODE, int CONV>
 __device__ __forceinline__ void store_element(const HkArgs& a, int64_t kq, int oi, int oj, double re, double im) {
     if (CONV == 1 && oi != oj) {  // (on the diagonal conj(e_i) e_i = 1: left alone, so that Im H[i][i] stays exactly 0)
-        const d2 ei = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oi) * 2);
-        const d2 ej = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oj) * 2);
+        d2 ei, ej;
+        if (a.k_inline) {  // the one k-point of a host call: e_p = exp(2 pi i k.pos_p), the arithmetic of orbital_phase_kernel
+            double di = 0.0, dj = 0.0;
+            for (int d = 0; d < a.dim; ++d) {
+                di = fma(a.k_val[d], a.pos_raw[oi * a.dim + d], di);
+                dj = fma(a.k_val[d], a.pos_raw[oj * a.dim + d], dj);
+            }
+            double sn, cs;
+            sincospi(2.0 * di, &sn, &cs);
+            ei = (d2){cs, sn};
+            sincospi(2.0 * dj, &sn, &cs);
+            ej = (d2){cs, sn};
+        } else {
+            ei = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oi) * 2);
+            ej = *reinterpret_cast<const d2*>(a.pos + ((size_t)kq * a.n_orb + oj) * 2);
+        }
         const double cs = ei[0] * ej[0] + ei[1] * ej[1], sn = ei[0] * ej[1] - ei[1] * ej[0];
         const double t = re * cs - im * sn;
         im = re * sn + im * cs;
@@ -340,7 +362,7 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_p
             double v = 0.0;
             if (q < nk_here && r < a.n_r) {
                 double dot = 0.0;
-                for (int d = 0; d < a.dim; ++d) dot = fma(a.kpts[(kbase + q) * a.dim + d], (double)a.R[r * a.dim + d], dot);
+                for (int d = 0; d < a.dim; ++d) dot = fma(hk_kcomp(a, kbase + q, d), (double)a.R[r * a.dim + d], dot);
                 double sn, cs;
                 sincospi(2.0 * dot, &sn, &cs);
                 v = (kk & 1) ? sn : cs;
@@ -653,11 +675,20 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.sub_splits = 1;
     a.P2 = nullptr;
     a.unit_grid = 1;
+    a.k_inline = 0;
+    a.pos_raw = nullptr;
+    for (int d = 0; d < TBK_MAX_DIM; ++d) a.k_val[d] = 0.0;
     if (tbk_hk_gemv_path(m, nk)) {
         int slices, rows_per_slice;
         gemv_plan(m, nk, &slices, &rows_per_slice);
         const size_t per_split = (size_t)nk * a.ncol_pad * 2 * sizeof(double);
-        TBK_ARG(d_A != nullptr || (tbk_hk_inline_phases(m, nk) && d_k != nullptr), "phase rows missing");
+        if (m->h_k_inline != nullptr && nk == 1 && d_A == nullptr && tbk_hk_inline_phases(m, 1)) {
+            a.k_inline = 1;  // (tbk_hamilton / tbk_eigenval on host buffers, one k-point: no upload of k)
+            for (int d = 0; d < m->dim; ++d) a.k_val[d] = m->h_k_inline[d];
+            a.pos_raw = m->d_pos_inline;  // convention 1: the raw positions (tbk_hamilton keeps them on the device)
+        }
+        TBK_ARG(d_A != nullptr || (tbk_hk_inline_phases(m, nk) && (d_k != nullptr || a.k_inline)), "phase rows missing");
+        TBK_ARG(convention != 1 || mode == HK_TRI || d_pos != nullptr || (a.k_inline && a.pos_raw != nullptr), "convention 1 needs the orbital phases");
         TBK_CHECK(m->ws_part.reserve(per_split * slices));
         a.P = m->ws_part.as<double>();
         a.splits = slices;

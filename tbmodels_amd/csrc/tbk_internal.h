@@ -215,6 +215,12 @@ struct tbk_model {
     DevBuf ws_kline;  // one mesh line without both folded components (second-level fold)
     DevBuf ws_band;   // two-stage reduction: pending [V | W] panel of every matrix of a chunk
     DevBuf ws_bandmat[2];  // ... and the band matrices between its stages (one per chunk in flight)
+    // one-k host calls (tbk_hamilton / tbk_eigenval, nk == 1, dense): the k-point goes into the kernel arguments (no upload),
+    // the convention-1 positions stay on the device between calls (uploaded again only when their bytes change)
+    const double* h_k_inline = nullptr;    // the caller's k-point for the duration of the call, else NULL
+    const double* d_pos_inline = nullptr;  // raw positions [n_orb][dim] on the device for the call in progress, else NULL
+    std::vector<double> pos_cache;         // host copy of what ws_posraw holds
+    DevBuf ws_posraw;
     DevBuf ws_split;  // calls of a few matrices: T and the members' partial X between the launches of the first stage
     // Set for the duration of one eigenvalue call by tbk_eigenval_device_gather (tbk_comm.hip): the chunk pipeline calls it
     // whenever the eigenvalues of rows [c0, c0 + nkc) of the call have been enqueued, with an event recorded behind

@@ -97,6 +97,30 @@ def test_synthetic_cases(synthetic, tag, sparse):
     _close(np.array(model.eigenval(k)), synthetic[tag + "_eig"])
 
 
+@pytest.mark.parametrize("n_orb,n_r", [(8, 30), (64, 200), (100, 12)])
+def test_one_k_calls_take_k_in_the_kernel_arguments_and_keep_the_positions_on_the_device(n_orb, n_r):
+    """ONE k-point per call is the Z2Pack call shape (_tb_model.py:1103-1108): the k-point goes into the kernel arguments, the
+    convention-1 phases of that k-point are formed inside the H(k) kernel from the raw positions, and those stay on the device
+    between calls -- until their bytes change.  Every call must equal the oracle and the batched call on the same k-points."""
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 500 + n_orb)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    k = syn.random_kpoints(6, seed=n_orb) * 3.0 - 1.0  # (outside [0, 1) too)
+    batch1, batch2 = model.hamilton(k, convention=1), model.hamilton(k, convention=2)
+    for q in range(len(k)):
+        _close(model.hamilton(k[q], convention=1), oracle.hamilton(r_vec, hop, k[q], 1, pos=pos))
+        _close(model.hamilton(k[q], convention=1), batch1[q], 1e-13)
+        _close(model.hamilton(k[q]), batch2[q], 1e-13)
+        _close(model.eigenval(k[q]), oracle.eigenval(r_vec, hop, k[q]))
+    # new positions: the cached copy on the device must go
+    moved = np.ascontiguousarray(pos[::-1] * 0.5 + 0.1)
+    model.pos = moved
+    _close(model.hamilton(k[2], convention=1), oracle.hamilton(r_vec, hop, k[2], 1, pos=moved))
+    model.pos = pos
+    _close(model.hamilton(k[2], convention=1), batch1[2], 1e-13)
+    h = model.hamilton(k[3], convention=1)
+    assert np.array_equal(h, h.conj().T) and not np.diagonal(h).imag.any()  # exactly Hermitian, real diagonal
+
+
 def test_scalar_k_single_point_and_empty(synthetic):
     model = tbmodels_amd.Model.from_packed(synthetic["dim1_R"], synthetic["dim1_hop"], pos=synthetic["dim1_pos"])
     k = float(synthetic["dim1_scalar_k"])
