@@ -582,6 +582,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         const int na = nbk - I0;
         const int lrow = lane & 15, lq = lane >> 4;
         double* tr = sTr + wave * (16 * 17);
+        // this lane's place inside a 16-row block of X / Vn ([row][Re 0..7 | Im 0..7] doubles, row lq + 4 r) and its sign there
+        const int lane_x = lq * 16 + 2 * (lrow & 7) + (lrow >> 3);
+        const double lane_sgn = (lrow < 8) ? -1.0 : 1.0;
         const int n_q = (na + nw_all - 1) / nw_all;
         const int n_t = na / 2;
         const int n_visits = n_q * (n_t + 1);
@@ -625,18 +628,19 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #ifdef TBK_ABLATE_OPERANDS
                     o.pb[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(I0 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
 #else
-                    o.pb[sg] = reinterpret_cast<const double*>(sVn)[(size_t)(o.I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)];
+                    o.pb[sg] = (reinterpret_cast<const double*>(sVn) + (size_t)o.I2 * (TS * 16) + lane_x)[sg * 64];  // (uniform base, immediates)
 #endif
             }
             // clamped addresses; rows / columns beyond n are masked when the tile is used
-            const int gc = o.Jc * TS + lrow;
+            // (32-bit element offsets from the matrix' uniform base: a matrix is at most 16 MiB)
+            const unsigned gc = (unsigned)min(o.Jc * TS + lrow, n - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gr = o.Ir * TS + lq + 4 * r;
+                const unsigned gr = (unsigned)min(o.Ir * TS + lq + 4 * r, n - 1);
+                const d2* at = reinterpret_cast<const d2*>(reinterpret_cast<const char*>(H) + (size_t)((gr * (unsigned)n + gc) * 16u));
                 // (tiles stream through once per pass: non-temporal, so that they do not push the [V | W] blocks, which every
                 // visit re-reads, out of L2)
-                const d2 v2 = TBK_TILE_NT ? __builtin_nontemporal_load(Hat(min(gr, n - 1), min(gc, n - 1)))
-                                          : *Hat(min(gr, n - 1), min(gc, n - 1));
+                const d2 v2 = TBK_TILE_NT ? __builtin_nontemporal_load(at) : *at;
                 o.tre[r] = v2[0];
                 o.tim[r] = v2[1];
             }
@@ -661,34 +665,45 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     own2 = own1;
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg)
-                        own_b[sg] = VN_LDS ? reinterpret_cast<const double*>(sVn)[(size_t)(cur.I * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)]
-                                           : cur.pb[sg];
+                        own_b[sg] = VN_LDS ? (reinterpret_cast<const double*>(sVn) + cur.I * (TS * 16) + lane_x)[sg * 64] : cur.pb[sg];
                 }
                 double par_b[4];
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg)
-                    par_b[sg] = diag ? own_b[sg]
-                                     : (VN_LDS ? reinterpret_cast<const double*>(sVn)[(size_t)(I2 * TS + lq + 4 * sg) * 16 + 2 * (lrow & 7) + (lrow >> 3)]
-                                               : cur.pb[sg]);
+                    par_b[sg] = diag ? own_b[sg] : (VN_LDS ? (reinterpret_cast<const double*>(sVn) + I2 * (TS * 16) + lane_x)[sg * 64] : cur.pb[sg]);
                 d4 tre = cur.tre, tim = cur.tim;
                 const int gc = Jc * TS + lrow;
+                // (everything the vector unit does here is time the matrix pipe does not get: the masks of the tiles on the
+                // matrix' edge and the roles of the two blocks are wave-uniform facts, so they are branches, not 48 selects)
+                const bool interior = (Ir + 1) * TS <= n && (Jc + 1) * TS <= n;
+                if (!interior) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool inside = Ir * TS + lq + 4 * r < n && gc < n;
-                    tre[r] = inside ? tre[r] : 0.0;
-                    tim[r] = inside ? tim[r] : 0.0;
+                    for (int r = 0; r < 4; ++r) {
+                        const bool inside = Ir * TS + lq + 4 * r < n && gc < n;
+                        tre[r] = inside ? tre[r] : 0.0;
+                        tim[r] = inside ? tim[r] : 0.0;
+                    }
                 }
                 if (with_update) {
                     // tile -= [V | W]_row . ([W | V]_col)^H : A = row block, k-step sg; B = conj(col block, k-step (sg + 2) % 4)
+                    if (own_is_row) {
 #pragma unroll
-                    for (int sg = 0; sg < 4; ++sg) {
-                        const int sb = (sg + 2) & 3;
-                        const double ar = own_is_row ? own.re[sg] : cur.par.re[sg], ai = own_is_row ? own.im[sg] : cur.par.im[sg];
-                        const double br = own_is_row ? cur.par.re[sb] : own.re[sb], bi = own_is_row ? cur.par.im[sb] : own.im[sb];
-                        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, tre, 0, 0, 1);  // -ar br
-                        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, tre, 0, 0, 1);  // -ai bi
-                        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, tim, 0, 0, 1);  // -ai br
-                        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, tim, 0, 0, 0);  // +ar bi
+                        for (int sg = 0; sg < 4; ++sg) {
+                            const int sb = (sg + 2) & 3;
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], cur.par.re[sb], tre, 0, 0, 1);  // -ar br
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], cur.par.im[sb], tre, 0, 0, 1);  // -ai bi
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], cur.par.re[sb], tim, 0, 0, 1);  // -ai br
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], cur.par.im[sb], tim, 0, 0, 0);  // +ar bi
+                        }
+                    } else {
+#pragma unroll
+                        for (int sg = 0; sg < 4; ++sg) {
+                            const int sb = (sg + 2) & 3;
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.par.re[sg], own.re[sb], tre, 0, 0, 1);
+                            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.par.im[sg], own.im[sb], tre, 0, 0, 1);
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.par.im[sg], own.re[sb], tim, 0, 0, 1);
+                            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.par.re[sg], own.im[sb], tim, 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -698,12 +713,13 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #elif defined(TBK_ABLATE_STORES_ALT)
                         if (gr < n && gc < n && ((s / PB) & 1) == 0) {  // stores on every SECOND panel only
 #else
-                        if (gr < n && gc < n) {
+                        if (interior || (gr < n && gc < n)) {
 #endif
+                            d2* at = reinterpret_cast<d2*>(reinterpret_cast<char*>(H) + (size_t)(((unsigned)gr * (unsigned)n + (unsigned)gc) * 16u));
                             if (TBK_TILE_NT)
-                                __builtin_nontemporal_store((d2){tre[r], tim[r]}, Hat(gr, gc));
+                                __builtin_nontemporal_store((d2){tre[r], tim[r]}, at);
                             else
-                                *Hat(gr, gc) = (d2){tre[r], tim[r]};
+                                *at = (d2){tre[r], tim[r]};
                         }
                     }
                 }
@@ -762,13 +778,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                             }
                         }
                         // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
-                        double* xs = reinterpret_cast<double*>(sX);
+                        double* xs = reinterpret_cast<double*>(sX) + I2 * (TS * 16) + lane_x;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const double rot = dpp_mov<0x128>(o2[r]);  // the other half of the 16-lane row
-                            const double val = (lrow < 8) ? o1[r] - rot : o1[r] + rot;
-                            const size_t at = (size_t)(I2 * TS + lq + 4 * r) * 16 + 2 * (lrow & 7) + (lrow >> 3);
-                            xs[at] += val;
+                            xs[r * 64] += fma(rot, lane_sgn, o1[r]);   // o1 - rot (Re columns) / o1 + rot (Im columns): exact either way
                         }
                     }
                 }
@@ -782,14 +796,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             TBK_CLK(11);
             if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
                 if (wave_all + nw_all * q < na) {
-                    double* xs = reinterpret_cast<double*>(sX);
                     const int I = I0 + wave_all + nw_all * q;
+                    double* xs = reinterpret_cast<double*>(sX) + I * (TS * 16) + lane_x;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double rot = dpp_mov<0x128>(own2[r]);
-                        const double val = (lrow < 8) ? own1[r] - rot : own1[r] + rot;
-                        const size_t at = (size_t)(I * TS + lq + 4 * r) * 16 + 2 * (lrow & 7) + (lrow >> 3);
-                        xs[at] += val;
+                        xs[r * 64] += fma(rot, lane_sgn, own1[r]);
                     }
                 }
                 lds_fence();
