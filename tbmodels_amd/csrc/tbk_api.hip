@@ -612,8 +612,14 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     // Folded H(k) (a mesh: ~30 small launches per chunk, 1.05 of the 5.5 ms a 32768-point chunk of cfg4 takes) is
     // built BESIDE the reduction of the previous chunk, into a second H buffer; chunk c then waits for the reduction
     // of chunk c - 2.  (Not for the direct contraction, which fills the chip and shares the FP64 pipe: see above.)
-    const bool h_overlap = builder != nullptr && tbk_eig_small_supported(m->n_orb) && n_chunks > 2 &&
-                           (getenv("TBK_H_OVERLAP") == nullptr || atoi(getenv("TBK_H_OVERLAP")) != 0);
+    // Round 4: also the direct H(k) of the two-stage sizes (from 189 orbitals) -- that reduction is a chain of short phases
+    // which leaves the matrix pipe idle four fifths of the time, and the sparse H(k) is an HBM-write kernel
+    // (TBK_H_OVERLAP_BIG=0: one after the other, the round-3 order).
+    static const bool overlap_on = getenv("TBK_H_OVERLAP") == nullptr || atoi(getenv("TBK_H_OVERLAP")) != 0;
+    static const bool overlap_big = getenv("TBK_H_OVERLAP_BIG") != nullptr && atoi(getenv("TBK_H_OVERLAP_BIG")) != 0;
+    const bool h_overlap = n_chunks > 2 && overlap_on &&
+                           ((builder != nullptr && tbk_eig_small_supported(m->n_orb)) ||
+                            (overlap_big && builder == nullptr && !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m)));
     double* d_Hbuf[2] = {d_H, d_H};
     if (h_overlap) {
         TBK_CHECK(m->ws_H2.reserve((size_t)max_chunk * nn2 * sizeof(double)));
