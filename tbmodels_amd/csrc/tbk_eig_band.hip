@@ -149,6 +149,18 @@ __device__ __forceinline__ void wg_sync() {
     __syncthreads();
 }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a counter in LDS, written / polled without the vmcnt(0) a volatile access would bring along (the tile loads and stores in
+// flight have nothing to do with it); LDS operations of a wave are performed in order
+__device__ __forceinline__ void lds_post(int* p, int value) {
+    const unsigned at = (unsigned)(size_t)(__attribute__((address_space(3))) int*)p;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(at), "v"(value) : "memory");
+}
+__device__ __forceinline__ int lds_poll(const int* p) {
+    const unsigned at = (unsigned)(size_t)(__attribute__((address_space(3))) const int*)p;
+    int value;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(value) : "v"(at) : "memory");
+    return __builtin_amdgcn_readfirstlane(value);
+}
 
 // 1 / x and (sqrt(x), 1 / sqrt(x)) from the hardware estimates plus Newton steps: a dozen instructions less per call
 // than IEEE division / sqrt, on the serial path of every Householder step.  x > 0 and well inside the double range
@@ -519,6 +531,9 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 //            the own blocks dealt out over the waves of ALL members; every member leaves its partial X in global memory.
 //            Behind the last panel the same launch applies the last pending update (no products).
 // Stream order is the only synchronisation between them (no spinning on flags: nothing can hang).
+#ifndef TBK_PASS_CHAIN
+#define TBK_PASS_CHAIN 1  // 0: a workgroup barrier per step of the tile pass (rounds 2 - 4a)
+#endif
 template <int NT, int ROWS, bool VN_LDS, int PHASE = 0>
 __global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
@@ -544,6 +559,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     d2* sS = sRow + 16;                                    // [64]  S = T^H M T
     d2* sT = sS + 64;                                      // [8][8] T of the current panel
     d2* sTau = sT + 64;                                    // [8]
+    int* sProg = reinterpret_cast<int*>(sTau + 8);         // [8]  visits finished, per wave (the chain of the tile pass)
 
     // the launch chain: `members` workgroups share a matrix in PHASE 2; its waves and theirs are numbered through
     const int members = PHASE == 2 ? (int)gridDim.x : 1;
@@ -559,6 +575,8 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     d2* gT = PHASE != 0 ? split_all + mat * split_stride : nullptr;
     d2* gX = PHASE != 0 ? gT + 64 : nullptr;
 
+    if (tid < 8) sProg[tid] = 0;  // (the first barrier of whatever follows is in front of the first pass)
+    int prog_base = 0;            // visits of the passes so far: the chain's counters only ever grow
     // the pending-update buffer starts out empty
     if (PHASE == 0 || (PHASE == 1 && p_fixed == 0))
         for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
@@ -588,6 +606,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         const int n_q = (na + nw_all - 1) / nw_all;
         const int n_t = na / 2;
         const int n_visits = n_q * (n_t + 1);
+        // Partner products are added into sX in a fixed order (results do not depend on timing).  The order used to be kept by a
+        // workgroup barrier per step; it is the same when wave w only waits for wave w + 1 to have finished the PREVIOUS step
+        // -- block a + t was the partner of wave w + 1 one step earlier, and of nobody else since -- which holds whenever the
+        // cyclic walk cannot wrap onto a block of the same round (na >= 2 NW: tools/check_pass_chain.py enumerates the
+        // schedules).  The waves then drift apart by what their loads cost them and meet at the end of a round only.
+        const bool chain = TBK_PASS_CHAIN && with_hemm && na >= 2 * NW;
 
         struct Visit {
             bool active, diag, own_is_row;
@@ -779,6 +803,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         }
                         // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
                         double* xs = reinterpret_cast<double*>(sX) + I2 * (TS * 16) + lane_x;
+                        if (chain && wave + 1 < NW) {  // wave + 1 is done with this block (its partner one step ago)
+                            const int need = prog_base + v;
+                            while (lds_poll(sProg + wave + 1) < need) __builtin_amdgcn_s_sleep(1);
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const double rot = dpp_mov<0x128>(o2[r]);  // the other half of the 16-lane row
@@ -790,8 +818,13 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             TBK_CLK(10);
             // the step's meeting point: LDS only (this wave's tile stores drain in the background)
 #ifndef TBK_ABLATE_BARRIER
-            lds_fence();
-            __syncthreads();
+            if (chain && t != n_t) {
+                // (a wave's LDS operations are performed in order: the counter lands behind the sums it announces)
+                lds_post(sProg + wave, prog_base + v + 1);  // (all lanes, one address, one value)
+            } else {
+                lds_fence();
+                __syncthreads();
+            }
 #endif
             TBK_CLK(11);
             if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
@@ -818,6 +851,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 visit(vb, v + 1);
             }
         }
+        prog_base += n_visits;
         wg_sync();  // tile stores complete before anybody re-reads the matrix
     };
 
@@ -1391,7 +1425,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     static const bool wide_env = !(getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 0);
     const bool wide = wide_env && n <= 512 && std::max<int64_t>(m->call_nk, nk) <= 128;
     const int nw = (n > 512 || wide) ? 8 : 4;
-    size_t lds = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+    size_t lds = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
     // d_de_fused: the workgroup runs the second stage too (same LDS) and writes (d, e) itself; d_band is not used
     const int np = chase_pitch(n);
     double* d_D = d_de_fused;
@@ -1404,7 +1438,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
     if (d_de_fused == nullptr && tbk_band_split(m, nk)) {
         // the launch chain: one row per thread where the rows allow it (the serial phases are thread-per-row)
-        auto lds_for = [&](int waves) { return (size_t)npad * PB * 16 + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16; };
+        auto lds_for = [&](int waves) { return (size_t)npad * PB * 16 + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16; };
         if (n <= 256) return launch_split<256, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(4));
         if (n <= 512) return launch_split<512, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8));
         return launch_split<512, 2>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8));
@@ -1421,7 +1455,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // matrix; 38 KiB of LDS, second stage in its own launch
     static const bool narrow_env = getenv("TBK_BAND_NARROW") && atoi(getenv("TBK_BAND_NARROW")) != 0;
     if (narrow_env && !wide && n <= 256 && d_de_fused == nullptr) {
-        lds = (size_t)npad * PB * 16 + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8) * 16;
+        lds = (size_t)npad * PB * 16 + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
         TBK_REDUCE(128, 2, false, 5);
     } else if (wide && vn_lds)
         TBK_REDUCE(512, 1, true, 3);
