@@ -358,12 +358,20 @@ def hk_roofline_entry(arrays, n_orb, n_r, dim, stage_ms, stage_n, k_total, confi
     out_bytes = 16.0 * (n_orb * (n_orb + 1) / 2 if not construct_only else n_orb * n_orb)
     b_k = out_bytes + 8 * dim
     achieved = b_k * k_per_launch / secs / 1e9 if hk_ms_avg > 0 else 0.0
-    return {
+    entry = {
         "kernel": "hk_csr_lds_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
         "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
         "algorithmic_bytes_per_kpoint": b_k,
         "avg_launch_ms": round(hk_ms_avg, 4), "launches": stage_n["hk"], "kpoints_per_launch": k_per_launch,
     }
+    if "val" in arrays:
+        # the other side of the same kernel: one complex multiply-add (8 flops) per stored hopping entry and k-point on the
+        # FP64 vector pipe -- at the bench model's fill the record walk, not the 16 B per element it writes, is what binds it
+        records = float(len(arrays["val"]))
+        valu = 8.0 * records * k_per_launch / secs / 1e12 if hk_ms_avg > 0 else 0.0
+        entry["valu"] = {"records_per_kpoint": records, "flops_per_kpoint": 8.0 * records, "achieved": round(valu, 3),
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(valu / FP64_MFMA_PEAK_TFLOPS, 4)}
+    return entry
 
 
 def single_k_latency(lib, model, k_slab, n_orb, calls=128, warm=8):

@@ -62,3 +62,22 @@ def test_chase_pipeline_two_steps_apart_is_conflict_free():
         assert np.allclose(d, d_seq, atol=1e-12) and np.allclose(e, e_seq, atol=1e-12)  # the same algorithm, reordered
     with pytest.raises(AssertionError, match="share cells"):
         model.stage2_pipelined(band, 1)
+
+
+def test_pass_chain_keeps_the_addition_order_of_the_partner_products():
+    """csrc/tbk_eig_band.hip replaces the per-step barrier of the tile pass by "wave w waits for wave w + 1" wherever
+    `na >= 2 NW`; tools/check_pass_chain.py restates the visit schedule: no block may get two writers the rule leaves unordered."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_pass_chain", os.path.join(ROOT, "tools", "check_pass_chain.py"))
+    chain = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chain)
+    unordered_somewhere = False
+    for na in range(1, 41):
+        for n_waves in (2, 4, 8):
+            for members in (1, 2, 4):
+                bad = chain.violations(na, n_waves, members)
+                if chain.chain_allowed(na, n_waves):
+                    assert not bad, (na, n_waves, members, bad[:2])
+                unordered_somewhere |= bool(bad)
+    assert unordered_somewhere  # (the check can fail: eight waves on 5 - 11 blocks are unordered, and keep the barrier)
