@@ -297,14 +297,14 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
         // element (i, j) of the band lives at (i - j) np + j: per lane and column c the part that does not depend on
         // the block position r0
         int dstat[4], bstat[4];
-        bool d_conj[4], d_diag[4], d_low[4];
+        bool d_low[4];
+        double d_imf[4];  // what the stored imaginary part is multiplied by: -1 above the diagonal (conjugate), 0 on it, 1 below
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int b = 4 * h + c;
             dstat[c] = abs(a - b) * np + min(a, b);
             bstat[c] = (PB + a - b) * np + b;
-            d_conj[c] = a < b;
-            d_diag[c] = a == b;
+            d_imf[c] = a < b ? -1.0 : (a == b ? 0.0 : 1.0);
             d_low[c] = a >= b;
         }
         const int xstat = (PB + a) * np;  // first column of the block below, row a
@@ -382,10 +382,7 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
                 }
                 const d2 bk0a = sL[xstat + r0];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (d_conj[c]) dv[c][1] = -dv[c][1];
-                    if (d_diag[c]) dv[c][1] = 0.0;
-                }
+                for (int c = 0; c < 4; ++c) dv[c][1] *= d_imf[c];
                 // row sums: y = D v and u = Bk v (four local terms, then the other half of the row)
                 d2 ya = (d2){0.0, 0.0}, ua = ya;
 #pragma unroll
@@ -399,37 +396,33 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
                 ua[1] += dpp_mov<0x128>(ua[1]);
                 const d2 tu = cmul(tau, ua);
                 const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};  // first column of Bk' (v[0] = 1 when tau != 0)
-                // y and x are needed by column too: through the slot's scratch (one wave: its LDS traffic is ordered)
+                // D' = H^H D H = D - v w^H - w v^H  with  w = tau y - (|tau|^2 rho / 2) v,  rho = v^H y  (real: D is Hermitian)
+                const double rho = sum_a8(va[0] * ya[0] + va[1] * ya[1]);
+                const double f = -0.5 * (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+                d2 wa = cmul(tau, ya);
+                wa[0] = fma(f, va[0], wa[0]);
+                wa[1] = fma(f, va[1], wa[1]);
+                // w and x are needed by column too: through the slot's scratch (one wave: its LDS traffic is ordered)
                 asm volatile("" ::: "memory");
                 if (h == 0) {
-                    scr[a] = ya;
+                    scr[a] = wa;
                     scr[8 + a] = xa;
                 }
                 asm volatile("" ::: "memory");
-                d2 yb[4], xb[4];
+                d2 wb[4], xb[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    yb[c] = scr[4 * h + c];
+                    wb[c] = scr[4 * h + c];
                     xb[c] = scr[8 + 4 * h + c];
                 }
                 const d2 alpha = scr[8];
                 asm volatile("" ::: "memory");
-                const double rho = sum_a8(va[0] * ya[0] + va[1] * ya[1]);
-                // D' = D - conj(tau) v_a conj(y_b) - tau y_a conj(v_b) + |tau|^2 rho v_a conj(v_b)
-                {
-                    const d2 ctau = conjd(tau);
-                    const d2 cva = cmul(ctau, va);   // conj(tau) v_a
-                    const d2 tya = cmul(tau, ya);    // tau y_a
-                    const double f = (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
-                    const d2 fva = (d2){f * va[0], f * va[1]};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        d2 dn = dv[c];
-                        cfnmac(dn, cva, yb[c]);
-                        cfnmac(dn, tya, vb[c]);
-                        cfmac(dn, fva, vb[c]);
-                        if (active && d_low[c] && r0 + a < n) sL[dstat[c] + r0] = dn;
-                    }
+                for (int c = 0; c < 4; ++c) {
+                    d2 dn = dv[c];
+                    cfnmac(dn, va, wb[c]);
+                    cfnmac(dn, wa, vb[c]);
+                    if (active && d_low[c] && r0 + a < n) sL[dstat[c] + r0] = dn;
                 }
                 // Bk' = Bk - tau u conj(v_b); next reflector from its first column; Bk'' = Bk' - conj(tau2) v2_a z_b
                 d2 bn[4];
@@ -450,11 +443,13 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
                     if (4 * h + c == 0) bn[c] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
                     if (active && r0 + PB + a < n && r0 + 4 * h + c < n) sL[bstat[c] + r0] = bn[c];
                 }
-                if (active) {
-                    va = n_va;
-                    tau = n_tau;
+                // (unconditionally: a slot that is not active holds nothing -- its next sweep starts from the column itself --
+                // and a conditional copy is twelve register moves per tick)
+                va = n_va;
+                tau = n_tau;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                if (active) {
                     if (++k == k_len) {
                         k = -1;
                         sw += NSLOT;
