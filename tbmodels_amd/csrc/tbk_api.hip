@@ -178,7 +178,15 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
         if (rc != TBK_OK) return fail(rc);      \
     } while (0)
 
-    TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)));
+    {
+        // TBK_MAIN_PRIORITY=1 (measurements): the main stream -- the H(k) kernels -- at the highest priority
+        static const bool main_hi = getenv("TBK_MAIN_PRIORITY") != nullptr && atoi(getenv("TBK_MAIN_PRIORITY")) != 0;
+        int lo = 0, hi = 0;
+        if (main_hi && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+            TBK_TRY(TBK_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi)));
+        else
+            TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)));
+    }
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_eig, hipStreamNonBlocking)));
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_ql, hipStreamNonBlocking)));
     for (int b = 0; b < 2; ++b) {
@@ -621,6 +629,14 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
                            ((builder != nullptr && tbk_eig_small_supported(m->n_orb)) ||
                             (overlap_big && builder == nullptr && !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m)));
     double* d_Hbuf[2] = {d_H, d_H};
+    struct LdsFloor {  // (reset on every way out)
+        tbk_model* m;
+        ~LdsFloor() { m->hk_lds_floor = 0; }
+    } lds_floor_guard{m};
+    if (h_overlap && builder == nullptr) {
+        static const int floor_kib = getenv("TBK_H_OVERLAP_LDS") ? atoi(getenv("TBK_H_OVERLAP_LDS")) : 84;
+        m->hk_lds_floor = (size_t)floor_kib * 1024;
+    }
     if (h_overlap) {
         TBK_CHECK(m->ws_H2.reserve((size_t)max_chunk * nn2 * sizeof(double)));
         d_Hbuf[1] = m->ws_H2.as<double>();

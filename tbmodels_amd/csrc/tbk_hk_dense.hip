@@ -539,11 +539,14 @@ static int tail_split_rounds() {
 template <int MODE, int CONV>
 int launch(tbk_model* m, const HkArgs& a0, int grid) {
     hipStream_t s = m->stream;
-    const size_t lds = 2 * STAGE_DOUBLES * sizeof(double);  // 73,728 B: above the 64 KiB default cap
+    // 73,728 B: above the 64 KiB default cap.  m->hk_lds_floor (the pipeline of the two-stage sizes, when H(k) of the next chunk
+    // runs beside a reduction): ask for more than half a CU's LDS, so that ONE contraction workgroup shares a CU with one
+    // reduction workgroup instead of two of a kind
+    const size_t lds = std::max<size_t>(2 * STAGE_DOUBLES * sizeof(double), m->hk_lds_floor);
     static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
     static std::atomic<bool> raised_split[TBK_MAX_DEVICES] = {};
-    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), (int)lds, raised));
-    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), (int)lds, raised_split));
+    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, false>), 160 * 1024, raised));
+    TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_dense_kernel<MODE, CONV, true>), 160 * 1024, raised_split));
     HkArgs a = a0;
     a.unit_grid = grid;
     const int slots = 2 * m->n_cu;  // __launch_bounds__(256, 2) and 72 KiB of LDS: two workgroups per CU

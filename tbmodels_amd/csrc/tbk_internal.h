@@ -226,6 +226,7 @@ struct tbk_model {
     // whenever the eigenvalues of rows [c0, c0 + nkc) of the call have been enqueued, with an event recorded behind
     // them -- the all-gather of finished rows leaves on the communicator's stream while later chunks compute.
     std::function<int(int64_t c0, int64_t nkc, hipEvent_t done)> chunk_done;
+    size_t hk_lds_floor = 0;  // dynamic LDS the dense contraction asks for at least (0: what it needs)
     std::vector<EventPair> events;
     double t_ms[TBK_T_COUNT] = {0, 0, 0, 0};
     int64_t t_n[TBK_T_COUNT] = {0, 0, 0, 0};
