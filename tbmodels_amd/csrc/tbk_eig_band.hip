@@ -529,6 +529,9 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 #ifndef TBK_PASS_CHAIN
 #define TBK_PASS_CHAIN 1  // 0: a workgroup barrier per step of the tile pass (rounds 2 - 4a)
 #endif
+#ifndef TBK_PASS_SPLIT
+#define TBK_PASS_SPLIT 1  // 0: the left-over blocks of a pass' last round on one wave each, the others idle
+#endif
 template <int NT, int ROWS, bool VN_LDS, int PHASE = 0>
 __global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
@@ -600,7 +603,21 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         const double lane_sgn = (lrow < 8) ? -1.0 : 1.0;
         const int n_q = (na + nw_all - 1) / nw_all;
         const int n_t = na / 2;
-        const int n_visits = n_q * (n_t + 1);
+        // The last round of own blocks holds r_last = na - nw_all (n_q - 1) of them: fewer than waves unless na is a multiple.
+        // When at least two waves are left per block (g_last), the walk of each such block is SPLIT over g_last helper waves
+        // -- helper j takes the steps t = j L + 1 .. (j + 1) L after a slot in which everybody fetches the block's operands
+        // (helper 0: the diagonal tile) -- so the round lasts L + 1 slots instead of n_t + 1 (240 -> 226 slots over the passes
+        // of a 256-orbital matrix).  Every helper keeps its own partial accumulators and flushes them in turn.  L >= r_last
+        // keeps the partner blocks of one slot distinct (block offsets i + j L + tau, i < r_last).
+        const int q_last = n_q - 1;
+        const int r_last = na - nw_all * q_last;
+        const int g_last = nw_all / r_last;
+        const int l_try = (n_t + g_last - 1) / g_last;
+        const bool split = TBK_PASS_SPLIT && g_last >= 2 && n_t >= 1 && l_try >= r_last;
+        const int l_split = split ? l_try : 0;
+        const int v_last0 = q_last * (n_t + 1);
+        const int n_visits = v_last0 + (split ? l_split + 1 : n_t + 1);
+        const int h_i = wave_all % r_last, h_j = wave_all / r_last;  // this wave in a split round: block and helper index
         // Partner products are added into sX in a fixed order (results do not depend on timing).  The order used to be kept by a
         // workgroup barrier per step; it is the same when wave w only waits for wave w + 1 to have finished the PREVIOUS step
         // -- block a + t was the partner of wave w + 1 one step earlier, and of nobody else since -- which holds whenever the
@@ -610,6 +627,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 
         struct Visit {
             bool active, diag, own_is_row;
+            bool fetch;      // this visit's "partner" loads are the own block's operands (diagonal tile / first slot of a helper)
+            bool own_valid;  // this wave holds (partial) accumulators of an own block in this round
+            bool last;       // last slot of a round: the accumulators go to sX behind it
+            bool in_split;   // slot of a split last round (barrier per slot, helpers flush in turn)
             int I, I2, Ir, Jc;
             d4 tre, tim;
             Frag par;
@@ -619,10 +640,31 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             // the loads (the compiler's wait-count tracking gives up at a merge: it then waits for everything in flight);
             // a record that is not `active` loads some valid tile and is ignored
             const int vq = min(v, n_visits - 1);
-            const int q = vq / (n_t + 1), t = vq - q * (n_t + 1);
-            const int a_raw = wave_all + nw_all * q;
+            int t, a_raw;
+            bool tile, own_ok;
+            o.in_split = split && vq >= v_last0;
+            if (!o.in_split) {
+                const int q = vq / (n_t + 1);
+                t = vq - q * (n_t + 1);
+                a_raw = wave_all + nw_all * q;
+                own_ok = a_raw < na;
+                tile = own_ok;
+                o.fetch = own_ok && t == 0;
+                o.last = t == n_t;
+            } else {
+                const int tau = vq - v_last0;
+                a_raw = nw_all * q_last + h_i;
+                own_ok = h_j < g_last;
+                t = tau == 0 ? 0 : h_j * l_split + tau;
+                tile = own_ok && (tau == 0 ? h_j == 0 : t <= n_t);
+                o.fetch = own_ok && tau == 0;
+                o.last = tau == l_split;
+                t = min(t, n_t);  // (an idle slot of the last helper: some valid block)
+            }
             const int a = min(a_raw, na - 1);
-            o.active = v < n_visits && a_raw < na && !((na & 1) == 0 && t == n_t && t > 0 && a_raw >= n_t);
+            o.own_valid = own_ok;
+            o.fetch = o.fetch && v < n_visits;
+            o.active = v < n_visits && tile && !((na & 1) == 0 && t == n_t && t > 0 && a_raw >= n_t);
             int a2 = a + t;
             if (a2 >= na) a2 -= na;
             o.I = I0 + a;
@@ -673,19 +715,19 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         for (int sg = 0; sg < 4; ++sg) own.re[sg] = own.im[sg] = own_b[sg] = 0.0;
         // one visit: everything between the arrival of its operands and the step's meeting point
         auto visit = [&](const Visit& cur, int v) {
-            const int q = v / (n_t + 1), t = v - q * (n_t + 1);
+            const bool chain_here = chain && !cur.in_split;
             TBK_CLK(7);
+            if (cur.fetch) {  // first slot of an own block: its operands are this visit's "partner" loads
+                own = cur.par;
+                own1 = (d4){0.0, 0.0, 0.0, 0.0};
+                own2 = own1;
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg)
+                    own_b[sg] = VN_LDS ? (reinterpret_cast<const double*>(sVn) + cur.I * (TS * 16) + lane_x)[sg * 64] : cur.pb[sg];
+            }
             if (cur.active) {
                 const bool diag = cur.diag, own_is_row = cur.own_is_row;
                 const int I2 = cur.I2, Ir = cur.Ir, Jc = cur.Jc;
-                if (diag) {  // first visit of an own block: its operands are this visit's "partner" loads
-                    own = cur.par;
-                    own1 = (d4){0.0, 0.0, 0.0, 0.0};
-                    own2 = own1;
-#pragma unroll
-                    for (int sg = 0; sg < 4; ++sg)
-                        own_b[sg] = VN_LDS ? (reinterpret_cast<const double*>(sVn) + cur.I * (TS * 16) + lane_x)[sg * 64] : cur.pb[sg];
-                }
                 double par_b[4];
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg)
@@ -798,7 +840,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         }
                         // partner block: lane (row lq + 4 r, c = lrow) adds Re X[row][c] (c < 8) or Im X[row][c - 8]
                         double* xs = reinterpret_cast<double*>(sX) + I2 * (TS * 16) + lane_x;
-                        if (chain && wave + 1 < NW) {  // wave + 1 is done with this block (its partner one step ago)
+                        if (chain_here && wave + 1 < NW) {  // wave + 1 is done with this block (its partner one step ago)
                             const int need = prog_base + v;
                             while (lds_poll(sProg + wave + 1) < need) __builtin_amdgcn_s_sleep(1);
                         }
@@ -813,7 +855,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             TBK_CLK(10);
             // the step's meeting point: LDS only (this wave's tile stores drain in the background)
 #ifndef TBK_ABLATE_BARRIER
-            if (chain && t != n_t) {
+            if (chain_here && !cur.last) {
                 // (a wave's LDS operations are performed in order: the counter lands behind the sums it announces)
                 lds_post(sProg + wave, prog_base + v + 1);  // (all lanes, one address, one value)
             } else {
@@ -822,18 +864,21 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
 #endif
             TBK_CLK(11);
-            if (with_hemm && t == n_t) {  // last step of this own block: its accumulators go to sX
-                if (wave_all + nw_all * q < na) {
-                    const int I = I0 + wave_all + nw_all * q;
-                    double* xs = reinterpret_cast<double*>(sX) + I * (TS * 16) + lane_x;
+            if (with_hemm && cur.last) {  // last slot of a round: the own blocks' accumulators go to sX
+                // (a split round: the helpers of a block one after the other, in helper order)
+                const int turns = cur.in_split ? g_last : 1;
+                for (int turn = 0; turn < turns; ++turn) {
+                    if (cur.own_valid && (!cur.in_split || h_j == turn)) {
+                        double* xs = reinterpret_cast<double*>(sX) + cur.I * (TS * 16) + lane_x;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double rot = dpp_mov<0x128>(own2[r]);
-                        xs[r * 64] += fma(rot, lane_sgn, own1[r]);
+                        for (int r = 0; r < 4; ++r) {
+                            const double rot = dpp_mov<0x128>(own2[r]);
+                            xs[r * 64] += fma(rot, lane_sgn, own1[r]);
+                        }
                     }
+                    lds_fence();
+                    __syncthreads();
                 }
-                lds_fence();
-                __syncthreads();
             }
         };
         // two visit records in turn (no register copies: a copy of a record waits for its loads where it stands)

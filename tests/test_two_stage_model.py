@@ -76,6 +76,8 @@ def test_pass_chain_keeps_the_addition_order_of_the_partner_products():
     for na in range(1, 41):
         for n_waves in (2, 4, 8):
             for members in (1, 2, 4):
+                # (with the split last round: every tile of the triangle exactly once, operands fetched before use)
+                assert not chain.coverage_errors(na, n_waves * members), (na, n_waves, members)
                 bad = chain.violations(na, n_waves, members)
                 if chain.chain_allowed(na, n_waves):
                     assert not bad, (na, n_waves, members, bad[:2])
