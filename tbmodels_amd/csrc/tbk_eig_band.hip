@@ -526,6 +526,9 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 //            the own blocks dealt out over the waves of ALL members; every member leaves its partial X in global memory.
 //            Behind the last panel the same launch applies the last pending update (no products).
 // Stream order is the only synchronisation between them (no spinning on flags: nothing can hang).
+#ifndef TBK_BAND_WAVES_PER_SIMD
+#define TBK_BAND_WAVES_PER_SIMD 2  // register budget of the four-wave kernels (3: 168 registers -- measured: spills)
+#endif
 #ifndef TBK_PASS_CHAIN
 #define TBK_PASS_CHAIN 1  // 0: a workgroup barrier per step of the tile pass (rounds 2 - 4a)
 #endif
@@ -533,7 +536,7 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 #define TBK_PASS_SPLIT 1  // 0: the left-over blocks of a pass' last round on one wave each, the others idle
 #endif
 template <int NT, int ROWS, bool VN_LDS, int PHASE = 0>
-__global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
+__global__ void __launch_bounds__(NT, NT <= 256 ? TBK_BAND_WAVES_PER_SIMD : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
                    size_t band_stride, int np, int stagger, double* __restrict__ D, double* __restrict__ E, int p_fixed = 0,
                    d2* __restrict__ split_all = nullptr) {
