@@ -529,6 +529,9 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 #ifndef TBK_BAND_WAVES_PER_SIMD
 #define TBK_BAND_WAVES_PER_SIMD 2  // register budget of the four-wave kernels (3: 168 registers -- measured: spills)
 #endif
+#ifdef TBK_ABLATE_BARRIER
+#define TBK_PASS_CHAIN 0  // (the ablation removes the meeting point altogether: nobody would announce a finished visit)
+#endif
 #ifndef TBK_PASS_CHAIN
 #define TBK_PASS_CHAIN 1  // 0: a workgroup barrier per step of the tile pass (rounds 2 - 4a)
 #endif
