@@ -139,7 +139,7 @@ int tbk_synchronize(tbk_model* m);
  * symmetric tridiagonal form with the same eigenvalues: d[nk][n_orb] diagonals, e[nk][n_orb] off-diagonals (e[.][n-1] = 0).
  * n_orb <= 1024.  method: TBK_REDUCE_AUTO = what tbk_eigenval takes for this size (register-resident reduction up to 64
  * orbitals, one-stage reduction up to 188 -- in registers up to 128, streaming above -- two-stage reduction -- dense ->
- * band of half-width 8 on the matrix pipe, band -> tridiagonal by bulge chasing -- from 189 to 1024); _ONE_STAGE / _TWO_STAGE force one of them (one-stage:
+ * band of half-width 8 on the matrix pipe, band -> tridiagonal by bulge chasing -- from 185 to 1024); _ONE_STAGE / _TWO_STAGE force one of them (one-stage:
  * n_orb <= 512 only; two-stage: 64 < n_orb <= 1024 only).  H_reduced (may be NULL) receives the work copy of the matrices as the reduction left it:
  * after the two-stage reduction its upper triangle holds the band form of stage one.
  * Host buffers; synchronous.  For tests and for callers that bring their own matrices. */

@@ -620,7 +620,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     // Folded H(k) (a mesh: ~30 small launches per chunk, 1.05 of the 5.5 ms a 32768-point chunk of cfg4 takes) is
     // built BESIDE the reduction of the previous chunk, into a second H buffer; chunk c then waits for the reduction
     // of chunk c - 2.  (Not for the direct contraction, which fills the chip and shares the FP64 pipe: see above.)
-    // Round 4: also the direct H(k) of the two-stage sizes (from 189 orbitals) -- that reduction is a chain of short phases
+    // Round 4: also the direct H(k) of the two-stage sizes (from 185 orbitals) -- that reduction is a chain of short phases
     // which leaves the matrix pipe idle four fifths of the time, and the sparse H(k) is an HBM-write kernel
     // (TBK_H_OVERLAP_BIG=0: one after the other, the round-3 order).
     static const bool overlap_on = getenv("TBK_H_OVERLAP") == nullptr || atoi(getenv("TBK_H_OVERLAP")) != 0;

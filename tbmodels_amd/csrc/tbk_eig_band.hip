@@ -1397,8 +1397,10 @@ bool tbk_eig_band_preferred(int n) {
     // (round 3: the one-stage kernel hands its last 128 steps to the register-resident kernels -- eight waves per matrix
     // from 128 to 64, tbk_eig_small.hip -- which moved the crossover up: 1.34 vs 2.37 us per matrix at 130 orbitals, 1.96 vs
     // 2.57 at 144, 2.56 vs 3.02 at 160; reduction stage of 4096 matrices 12.2 vs 12.7 ms at 176, 13.4 vs 13.9 at 184,
-    // 14.9 vs 14.4 at 192)
-    static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 189;  // measurements only
+    // 14.9 vs 14.4 at 192.  Round 4, after the trims of both stages, whole eigenval per k-point, one-stage vs two-stage:
+    // 2.85 vs 3.16 us at 168, 3.36 vs 3.34 at 176, 3.70 vs 3.70 at 184, 3.88 vs 3.78 at 188 -- 177 .. 192 orbitals pad to
+    // the same twelve blocks of 16, so the two-stage path takes over where the one-stage time reaches that: from 185)
+    static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 185;  // measurements only
     return n >= from && n <= BAND_MAXN;
 }
 

@@ -636,7 +636,7 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     il = np.tril_indices(n, -1)
     poisoned[:, il[0], il[1]] = np.nan
     d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(poisoned)
-    # the two-stage kernels at every size they handle (eigenval itself takes them from 189 orbitals on); the
+    # the two-stage kernels at every size they handle (eigenval itself takes them from 185 orbitals on); the
     # production choice and the forced one-stage path are compared below
     method = _lib.TBK_REDUCE_TWO_STAGE if n > 64 else _lib.TBK_REDUCE_AUTO
     _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(poisoned), method, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
@@ -716,7 +716,7 @@ def test_two_stage_and_one_stage_reductions_agree():
     import tempfile
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r_vec, hop, pos = syn.dense_model_arrays(200, 6, syn.MODEL_SEED + 321)  # (above the crossover at 189 orbitals)
+    r_vec, hop, pos = syn.dense_model_arrays(200, 6, syn.MODEL_SEED + 321)  # (above the crossover at 185 orbitals)
     k = syn.random_kpoints(2600, seed=5)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
     from tbmodels_amd import _lib
@@ -766,7 +766,7 @@ def test_register_cascade_agrees_with_the_streaming_kernel(n_orb, switch):
             out = os.path.join(tmp, "e%s.npy" % value)
             env = dict(os.environ)
             env.pop(switch, None)
-            if n_orb > 188:
+            if n_orb > 184:
                 env["TBK_BAND"] = "0"
             if value is not None:
                 env[switch] = value
