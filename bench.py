@@ -139,9 +139,9 @@ def _cpu_chunk(bounds):
     from oracle import tbk_oracle as oracle  # checker / baseline only
 
     lo, hi = bounds
-    if hi > lo:
-        oracle.eigenval(_CPU_SHARED["R"], _CPU_SHARED["hop"], _CPU_SHARED["k"][lo:hi])
-    return hi - lo
+    if hi > lo:  # the rows go back to the parent: they are the parity check of the GPU result on the same k-points
+        return np.array(oracle.eigenval(_CPU_SHARED["R"], _CPU_SHARED["hop"], _CPU_SHARED["k"][lo:hi]))
+    return np.empty((0, _CPU_SHARED["hop"].shape[-1]))
 
 
 def _cpu_worker_init():
@@ -177,7 +177,8 @@ def usable_cores():
 
 def cpu_baseline_all_cores(arrays, kpts, per_proc):
     """The same oracle in one process per host core, each on its own contiguous k chunk (what a
-    user of the reference does with its pickle support).  Forks, so it runs BEFORE this process touches the GPU."""
+    user of the reference does with its pickle support).  Forks, so it runs BEFORE this process touches the GPU.
+    Returns (entry, eigenvalues of rows [0, total) of `kpts`): the rows are the oracle sample the GPU result is held to."""
     import multiprocessing as mp  # pylint: disable=import-outside-toplevel
 
     procs = usable_cores()
@@ -191,14 +192,15 @@ def cpu_baseline_all_cores(arrays, kpts, per_proc):
     with mp.get_context("fork").Pool(procs, initializer=_cpu_worker_init) as pool:
         pool.map(_cpu_chunk, [(0, 0)] * procs, chunksize=1)  # every worker up and imported before the clock starts
         t0 = time.perf_counter()
-        done = sum(pool.map(_cpu_chunk, list(zip(edges[:-1], edges[1:])), chunksize=1))
+        rows = np.concatenate(pool.map(_cpu_chunk, list(zip(edges[:-1], edges[1:])), chunksize=1))
         dt = time.perf_counter() - t0
+    done = len(rows)
     _CPU_SHARED.clear()
     return {
         "value": round(done / dt, 2), "unit": "k-points/s", "cores": procs, "kind": "port", "host_cpus": os.cpu_count(),
         "sample": "%d k-points of this workload in %d processes (one contiguous chunk each), same oracle, %.1f s"
                   % (done, procs, dt),
-    }
+    }, rows
 
 
 def launch_ranks(n_ranks):
@@ -399,7 +401,27 @@ def config_kpoints(name, nk, dim):
     return np.ascontiguousarray(np.random.default_rng(synthetic.K_SEED).random((nk, dim)))
 
 
-def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup=1, cpu_all=None):
+def standalone_reduction(lib, device, n_orb, matrices, reps=3):
+    """The reduction stage alone on the chip (tbk_reduce_standalone: device-made random Hermitian matrices, HIP events around
+    the reduction only): us per matrix and fraction of the FP64 peak for the whole reduction and, at the two-stage sizes, for
+    each stage -- beside the in-pipeline stage time, during which the next chunk's H(k) shares the FP64 pipe."""
+    us = (ctypes.c_double * 3)()
+    _lib.check(lib.tbk_reduce_standalone(device, n_orb, matrices, reps, us))
+    flops = 16.0 / 3.0 * n_orb ** 3
+    entry = {"matrices_per_launch": matrices, "reps": reps, "us_per_matrix": round(us[0], 4),
+             "achieved": round(flops / (us[0] * 1e-6) / 1e12, 3), "unit": "TFLOP/s",
+             "frac": round(flops / (us[0] * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+             "note": "tbk_reduce_standalone: nothing else on the chip; (16/3) n^3 flops per matrix over the HIP-event time"}
+    if us[1] > 0.0:
+        entry["stage1_us_per_matrix"] = round(us[1], 4)
+        entry["stage2_us_per_matrix"] = round(us[2], 4)
+        entry["stage1_frac"] = round(flops / (us[1] * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
+        entry["stages_note"] = ("each stage in a launch of its own (up to 256 orbitals the product fuses them into one kernel: "
+                                "us_per_matrix is that kernel)")
+    return entry
+
+
+def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup=1, cpu_all=None, cpu_all_rows=None):
     """
     One of the other BASELINE configs at its FULL size on this GPU, after the main clock and outside ``ms_per_step``:
     `steps` timed passes of tbk_eigenval_device_hint over the config's k list (resident in HBM), the stage times, the
@@ -458,13 +480,21 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
               {"cfg1": 1000, "cfg3": 48, "cfg4": 256, "cfg5": 4}).get(name, 8)
     cpu_rate, cpu_dt, cpu_eig = cpu_baseline(arrays, k, sample)
     parity = float(np.abs(cpu_eig - eig[:len(cpu_eig)]).max())
+    oracle_rows = sample
+    if cpu_all_rows is not None and len(cpu_all_rows):
+        # the rows the all-core baseline computed anyway (before the GPU was touched): the same k-points, every one compared
+        parity = max(parity, float(np.abs(cpu_all_rows - eig[:len(cpu_all_rows)]).max()))
+        oracle_rows = max(sample, len(cpu_all_rows))
+    eig_roofline = eig_roofline_entry(n_orb, nk * steps, stage_ms["eig"], steps) if stage_ms["eig"] > 0 else None
+    if eig_roofline is not None and n_orb > 64 and os.environ.get("TBK_BENCH_SKIP_STANDALONE") != "1":
+        eig_roofline["standalone"] = standalone_reduction(lib, device, n_orb, 4096 if n_orb <= 256 else 2048)
     entry = {
         "workload": "%s: %s N_orb=%d N_R=%d, %d %s k-points, eigenval (H(k)+eig), 1 GPU"
                     % (name, arrays["kind"], n_orb, n_r, nk, "grid" if name in ("cfg1", "cfg4") else "random"),
         "value": round(nk * steps / elapsed, 1), "unit": "k-points/s", "steps": steps, "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3),
         "stage_ms_per_step": {key: round(v / steps, 3) for key, v in stage_ms.items()},
-        "eig_roofline": eig_roofline_entry(n_orb, nk * steps, stage_ms["eig"], steps) if stage_ms["eig"] > 0 else None,
+        "eig_roofline": eig_roofline,
         "roofline": hk_roofline_entry(arrays, n_orb, n_r, dim, stage_ms, stage_n, nk * steps, name),
         "cpu_baseline": {
             "value": round(cpu_rate, 3), "unit": "k-points/s", "cores": 1, "kind": "port",
@@ -474,7 +504,9 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         },
         "cpu_baseline_all_cores": cpu_all,
         "single_k_us": single,
-        "max_abs_err_vs_oracle": parity, "oracle_sample": sample,
+        "max_abs_err_vs_oracle": parity,
+        "oracle_sample": "%d rows (the first %d k-points of the workload%s)"
+                         % (oracle_rows, oracle_rows, ": the rows of cpu_baseline_all_cores" if oracle_rows > sample else ""),
         "max_trace_identity_err_4096_rows": trace_err,
         "model_build_and_staging_s": round(build_s, 2),
     }
@@ -594,6 +626,47 @@ def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arra
             lib.tbk_device_free(device, p)
 
 
+def guarded_strong_leg(result, world, limit, leg):
+    """Runs `leg()` (the cfg4 strong-scaling leg; every rank calls this) under a watchdog and files its outcome in `result`
+    (rank 0's main record, None elsewhere): the entry under configs and a TOP-LEVEL "strong_scaling": "ok" | "failed" |
+    "timeout".  A leg that raises (a failed collective, its own parity check) returns True -- the caller prints the line and
+    exits non-zero.  A leg that does not come back within `limit` seconds (a rank lost in a collective) ends THIS process
+    from the watchdog thread: the line is printed with "timeout", then os._exit(3) -- the process exits, it is never
+    re-executed or restarted (it has touched the GPU)."""
+    import threading  # pylint: disable=import-outside-toplevel
+
+    key = "cfg4" if world > 1 else "cfg4_one_rank_communicator"
+
+    def attach(entry, verdict):
+        if result is not None:
+            if result.get("configs") is None:
+                result["configs"] = {}
+            result["configs"][key] = entry
+            result["strong_scaling"] = verdict
+
+    def give_up():
+        attach({"error": "the strong-scaling leg did not finish within %s s" % limit, "scaling": "strong", "n_gpus": world}, "timeout")
+        if result is not None:
+            print(json.dumps(result), flush=True)
+        sys.stderr.write("[bench] the cfg4 strong-scaling leg timed out after %s s\n" % limit)
+        sys.stderr.flush()
+        os._exit(3)  # pylint: disable=protected-access
+
+    # (rank 0 -- the one with the record -- gives up first: a launcher that sees another rank fail may stop rank 0 before it
+    # has printed the line)
+    watchdog = threading.Timer(limit if result is not None else limit + 30.0, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+    failed = False
+    try:
+        attach(leg(), "ok")
+    except Exception as exc:  # pylint: disable=broad-except
+        failed = True
+        attach({"error": "%s: %s" % (type(exc).__name__, exc), "scaling": "strong", "n_gpus": world}, "failed")
+    watchdog.cancel()
+    return failed
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -635,12 +708,13 @@ def main():
     k_slab = np.ascontiguousarray(k_slab)
 
     cpu_all = None
+    cpu_all_rows = None
     cpu_all_other = {}
     per_proc_all = {"cfg1": 64, "cfg2": 256, "cfg3": 24, "cfg4": 256, "cfg5": 2}  # ~5-10 s each
     run_others = (world == 1 and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr
                   and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1")
     if rank == 0 and world == 1 and args.cpu_sample != 0 and not args.construct_only:
-        cpu_all = cpu_baseline_all_cores(arrays, k_slab, per_proc_all[args.config])
+        cpu_all, cpu_all_rows = cpu_baseline_all_cores(arrays, k_slab, per_proc_all[args.config])
         if run_others and os.environ.get("TBK_BENCH_CPU_LIGHT") != "1":
             # all-core row of the sparse config too; it forks, so it runs here, before the GPU is touched
             arrays3 = build_model_arrays("cfg3")
@@ -823,6 +897,41 @@ def main():
             "value_with_list_return": round(nk_gpu / (dt_call + dt_list), 1),
         }
         _lib.check(lib.tbk_get_timing(model, None, None, 1))  # drop the stage events of these two extra calls
+    construct = None
+    if world == 1 and rank == 0 and not args.construct_only and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
+        # SURVEY 8(d) "Metric": k-points/s for H(k) construction alone, the result resident in HBM (tbk_hamilton_device, the
+        # FULL matrix of Model.hamilton); and hard part 5: the batch hamilton() wall-clock through HOST buffers, PCIe-bound
+        nk_c = min(nk_gpu, max(1, int(12e9 // (n_orb * n_orb * 16))))  # at most 12 GB of H
+        d_hc = dmalloc(nk_c * n_orb * n_orb * 16)
+        try:
+            _lib.check(lib.tbk_hamilton_device(model, d_k, nk_c, 2, None, d_hc))
+            _lib.check(lib.tbk_synchronize(model))
+            c_steps = 3
+            t1 = time.perf_counter()
+            for _ in range(c_steps):
+                _lib.check(lib.tbk_hamilton_device(model, d_k, nk_c, 2, None, d_hc))
+            _lib.check(lib.tbk_synchronize(model))
+            dt_c = (time.perf_counter() - t1) / c_steps
+        finally:
+            lib.tbk_device_free(device, d_hc)
+        construct = {"value": round(nk_c / dt_c, 1), "unit": "k-points/s", "ms_per_step": round(dt_c * 1e3, 3), "steps": c_steps,
+                     "kpoints": nk_c, "includes": "tbk_hamilton_device: phase rows + contraction + scatter to the full "
+                     "H[k][i][j] (both triangles), k and H resident in HBM"}
+        nk_h = min(nk_gpu, max(1, int(1.4e9 // (n_orb * n_orb * 16))))  # ~1.3 GB of H: 20 000 k-points at 64 orbitals
+        h_host = np.zeros((nk_h, n_orb, n_orb), dtype=np.complex128)   # written once: a warm buffer (pages exist)
+        _lib.check(lib.tbk_hamilton(model, _lib.ptr(k_slab), nk_h, 2, None, _lib.ptr(h_host)))
+        t1 = time.perf_counter()
+        _lib.check(lib.tbk_hamilton(model, _lib.ptr(k_slab), nk_h, 2, None, _lib.ptr(h_host)))
+        dt_h = time.perf_counter() - t1
+        h_trace = float(np.abs(np.trace(h_host[:64], axis1=1, axis2=2).imag).max())
+        if host_api is not None:
+            host_api["hamilton"] = {"value": round(nk_h / dt_h, 1), "unit": "k-points/s", "kpoints": nk_h,
+                                    "GB/s": round(h_host.nbytes / dt_h / 1e9, 2), "ms_per_call": round(dt_h * 1e3, 3),
+                                    "includes": "tbk_hamilton on host buffers: H2D of k, kernels, chunked D2H of H into a "
+                                                "warm (already written) host array",
+                                    "max_abs_imag_trace_64_rows": h_trace}
+        del h_host
+        _lib.check(lib.tbk_get_timing(model, None, None, 1))
     peak_measured = None
     if rank == 0 and arrays["kind"] == "dense" and os.environ.get("TBK_BENCH_SKIP_PEAK") != "1":
         tf = ctypes.c_double(0.0)
@@ -835,12 +944,16 @@ def main():
     #      slab, so every k chunk of the pipeline is covered (host work independent of the GPU path)
     eig_head = np.empty((min(nk_gpu, 64), n_orb))
     trace_err = None
+    parity_all = None
     if not args.construct_only and rank == 0:
         d_e = d_e_pair[(step_no[0] - 1) & 1]  # the buffer of the last step
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_head), d_e, eig_head.nbytes))
         eig_all = np.empty((nk_gpu, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_all), d_e, eig_all.nbytes))
         trace_err = trace_identity_error(arrays, k_slab, eig_all)
+        if cpu_all_rows is not None and len(cpu_all_rows):
+            # every row the all-core CPU baseline computed (the first rows of this slab) against the GPU's eigenvalues
+            parity_all = float(np.abs(cpu_all_rows - eig_all[:len(cpu_all_rows)]).max())
         del eig_all
 
     result = None
@@ -856,6 +969,9 @@ def main():
         eig_roofline = None
         if not args.construct_only and stage_ms.get("eig", 0.0) > 0.0:
             eig_roofline = eig_roofline_entry(n_orb, nk_gpu * args.steps, stage_ms["eig"], args.steps)
+            if world == 1 and os.environ.get("TBK_BENCH_SKIP_STANDALONE") != "1" and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
+                eig_roofline["standalone"] = standalone_reduction(
+                    lib, device, n_orb, 32768 if n_orb <= 64 else 8192 if n_orb <= 128 else 4096 if n_orb <= 256 else 2048)
 
         sample = args.cpu_sample
         if sample < 0:
@@ -863,12 +979,17 @@ def main():
             sample = {"cfg1": 1000, "cfg2": 640, "cfg3": 48, "cfg4": 640, "cfg5": 4}[args.config]
         cpu = None
         parity = None
+        oracle_rows = 0
         if world > 1:
             sample = min(sample, 64)  # N > 1: the oracle only as the checker; the baseline is reported at N = 1
         if sample > 0 and not args.construct_only:
             cpu_rate, cpu_dt, cpu_eig = cpu_baseline(arrays, k_slab, sample)
             n_cmp = min(len(cpu_eig), len(eig_head))
             parity = float(np.abs(cpu_eig[:n_cmp] - eig_head[:n_cmp]).max())
+            oracle_rows = n_cmp
+            if parity_all is not None:
+                parity = max(parity, parity_all)
+                oracle_rows = max(n_cmp, len(cpu_all_rows))
         if sample > 0 and not args.construct_only and world == 1:
             cpu = {
                 "value": round(cpu_rate, 2), "unit": "k-points/s", "cores": 1, "kind": "port",
@@ -884,7 +1005,8 @@ def main():
             _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_AUTO))
             other["cfg4"] = run_other_config(lib, device, "cfg4", model=model, arrays=arrays)
             for name in ("cfg1", "cfg3", "cfg5"):
-                other[name] = run_other_config(lib, device, name, cpu_all=cpu_all_other.get(name))
+                entry_all, rows_all = cpu_all_other.get(name, (None, None))
+                other[name] = run_other_config(lib, device, name, cpu_all=entry_all, cpu_all_rows=rows_all)
         result = {
             "metric": "k-points/sec (H(k)+eig) at N_orb=%d, N_R=%d" % (n_orb, n_r) if not args.construct_only
                       else "k-points/sec (H(k) construction only) at N_orb=%d, N_R=%d" % (n_orb, n_r),
@@ -920,7 +1042,11 @@ def main():
             "configs": other,
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "max_abs_err_vs_oracle": parity,
+            "oracle_sample": "%d rows (the first %d k-points of the slab%s)"
+                             % (oracle_rows, oracle_rows, ": the rows of cpu_baseline_all_cores" if parity_all is not None else ""),
             "max_trace_identity_err_4096_rows": trace_err,
+            "construct_only": construct,
+            "strong_scaling": None,
         }
     # --- after everything else: BASELINE config 4, the one STRONG-scaling config -- the 100^3 mesh of the staged model in
     # `world` contiguous slabs, every rank's slab evaluated into its rows of the full result with the RCCL all-gather of
@@ -931,37 +1057,13 @@ def main():
     strong_failed = False
     if comm is not None and args.config == "cfg2" and not args.construct_only and not args.nr \
             and ((os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1" and not args.nk) or os.environ.get("TBK_BENCH_STRONG") == "1"):
-        import threading  # pylint: disable=import-outside-toplevel
-
-        key = "cfg4" if world > 1 else "cfg4_one_rank_communicator"
-
-        def attach(entry):
-            if result is not None:
-                if result.get("configs") is None:
-                    result["configs"] = {}
-                result["configs"][key] = entry
-
-        def give_up():
-            attach({"error": "the strong-scaling leg did not finish within %s s" % limit, "scaling": "strong", "n_gpus": world})
-            if result is not None:
-                print(json.dumps(result), flush=True)
-            # every rank leaves with status 0: the main line is valid, and a launcher that sees a failing rank may discard it
-            os._exit(0)  # pylint: disable=protected-access
-
-        limit = float(os.environ.get("TBK_BENCH_STRONG_TIMEOUT", "240"))
-        watchdog = threading.Timer(limit, give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            attach(strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays))
-        except Exception as exc:  # pylint: disable=broad-except
-            strong_failed = True
-            attach({"error": "%s: %s" % (type(exc).__name__, exc), "scaling": "strong", "n_gpus": world})
-        watchdog.cancel()
+        strong_failed = guarded_strong_leg(
+            result, world, float(os.environ.get("TBK_BENCH_STRONG_TIMEOUT", "240")),
+            lambda: strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays,
+                                       mesh=int(os.environ.get("TBK_BENCH_STRONG_MESH", "100"))))
     if rank == 0 and result is not None:
         print(json.dumps(result), flush=True)
-    if strong_failed:  # (the main line stands and says so under configs; the status tells the launcher something went wrong
-        # only when the failure is this rank's own parity check -- a peer lost in a collective ends through the watchdog)
+    if strong_failed:  # the main line stands and says "strong_scaling": "failed"; the exit status below reports it too
         sys.stderr.write("[bench] the cfg4 strong-scaling leg failed on rank %d: see configs in the JSON line\n" % rank)
 
     if comm is not None:
@@ -973,6 +1075,8 @@ def main():
         for key in ("max_abs_err_vs_oracle", "max_trace_identity_err_4096_rows"):
             if result.get(key) is not None and not result[key] <= 1e-10:
                 raise SystemExit("parity failure: %s = %g" % (key, result[key]))
+    if strong_failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

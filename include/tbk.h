@@ -63,7 +63,12 @@ typedef enum tbk_status {
  * Tridiagonal stage of the two hand-written paths: lane-per-matrix QL for large batches of n_orb <= 64,
  * bisection on Sturm counts otherwise (n_orb > 64, calls of <= max(4096, 768 n_orb) k-points, and the last
  * chunk of a call).  Both are backward stable; they agree to rounding, so eigenvalues are reproducible run to
- * run but depend on the batch size at the 1e-13 level. */
+ * run but depend on the batch size at the 1e-13 level.  The same holds for the reduction above 128 orbitals: calls of
+ * a few matrices take wider kernels / a chain of launches (tbk_eig_band.hip: tbk_band_split, `wide`) whose partial sums
+ * differ from the one-workgroup kernels' in the last bit.  Bitwise reproducibility is therefore a property of a CALL SHAPE:
+ * the same k list on the same number of devices / ranks (tbk_eigenval_multi and ShardedEigenval cut it into
+ * ceil(nk / n) slabs, and every slab chooses its kernels by ITS size) gives the same bits every time; the same list on a
+ * different device count agrees to rounding only. */
 enum { TBK_EIG_AUTO = 0, TBK_EIG_WAVE = 1, TBK_EIG_ROCSOLVER = 2 };
 enum {
     TBK_OPT_EIGENSOLVER = 1, /* one of TBK_EIG_*                                           */
@@ -147,6 +152,13 @@ enum { TBK_REDUCE_AUTO = 0, TBK_REDUCE_ONE_STAGE = 1, TBK_REDUCE_TWO_STAGE = 2 }
 int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const double* H, int method, double* d, double* e,
                            double* H_reduced);
 
+/* The reduction stage alone on the chip, timed with HIP events on random Hermitian matrices made on the device (nothing
+ * crosses PCIe): us_per_matrix[0] = the reduction as tbk_eigenval runs it for this size and call size (both stages of the
+ * two-stage path), [1] = its first stage (dense -> band) alone, [2] = its second stage (band -> tridiagonal) alone -- [1],
+ * [2] are 0 below the two-stage sizes.  Mean over `reps` repetitions after one warm-up.  Measurement only (bench.py
+ * `eig_roofline.standalone`): the in-pipeline stage time shares the FP64 pipe with the next chunk's H(k). */
+int tbk_reduce_standalone(int device, int n_orb, int64_t nk, int reps, double* us_per_matrix);
+
 /* ---- k.p models (kdotp.py:51-100): H(k) = sum_p prod_d k_d^powers[p][d] * coeffs[p] ------- */
 int tbk_kdotp_create(int device, int dim, int n_orb, int64_t n_p, const int32_t* powers,
                      const double* coeffs, tbk_kdotp** out);
@@ -203,6 +215,12 @@ int tbk_comm_synchronize(tbk_comm* c);
  * creation; synchronous.  A rank whose staging / allocation failed reports it HERE, and nobody enters the data
  * collectives (a rank raising alone in front of a collective leaves its peers hanging in it). */
 int tbk_comm_agree(tbk_comm* c, int status, double* verdict);
+/* The landing area of tbk_eigenval_device_gather for slabs of `per` rows of n_orb eigenvalues (grow-only, sized from per,
+ * n_orb and the world size alone).  Call it in the step whose outcome tbk_comm_agree exchanges: an allocation failure on one
+ * rank then reaches every rank's verdict BEFORE anybody enters the data collectives.  (The gather allocates by itself when
+ * this was skipped; a failure there travels in that rank's status word, behind the same sequence of collectives.) */
+int tbk_comm_prepare_gather(tbk_comm* c, int n_orb, int64_t per);
+
 /* One sharded eigenvalue call with the gather pipelined behind the k chunks (replaces the per-process body of a
  * multiprocessing farm over Model.eigenval, _tb_model.py:1134-1150; k-points are independent, :1111-1123).
  * Every rank calls it with the SAME `per` (slab length in k-points = ceil(NK / world)) and its own nk <= per k-points

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tbk_eigenval_check": (_c_int, [_vp]),
     "tbk_synchronize": (_c_int, [_vp]),
     "tbk_tridiagonal_reduce": (_c_int, [_c_int, _c_int, _c_i64, _vp, _c_int, _vp, _vp, _vp]),
+    "tbk_reduce_standalone": (_c_int, [_c_int, _c_int, _c_i64, _c_int, ctypes.POINTER(ctypes.c_double)]),
     "tbk_kdotp_create": (_c_int, [_c_int, _c_int, _c_int, _c_i64, _vp, _vp, _pp]),
     "tbk_kdotp_destroy": (None, [_vp]),
     "tbk_kdotp_hamilton": (_c_int, [_vp, _vp, _c_i64, _vp]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     "tbk_comm_wait_slot": (_c_int, [_vp, _vp, _c_int]),
     "tbk_comm_synchronize": (_c_int, [_vp]),
     "tbk_comm_agree": (_c_int, [_vp, _c_int, _vp]),
+    "tbk_comm_prepare_gather": (_c_int, [_vp, _c_int, _c_i64]),
     "tbk_eigenval_device_gather": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
     "tbk_mfma_f64_peak": (_c_int, [_c_int, ctypes.POINTER(ctypes.c_double)]),
 }

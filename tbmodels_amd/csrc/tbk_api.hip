@@ -620,9 +620,10 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     // Folded H(k) (a mesh: ~30 small launches per chunk, 1.05 of the 5.5 ms a 32768-point chunk of cfg4 takes) is
     // built BESIDE the reduction of the previous chunk, into a second H buffer; chunk c then waits for the reduction
     // of chunk c - 2.  (Not for the direct contraction, which fills the chip and shares the FP64 pipe: see above.)
-    // Round 4: also the direct H(k) of the two-stage sizes (from 185 orbitals) -- that reduction is a chain of short phases
-    // which leaves the matrix pipe idle four fifths of the time, and the sparse H(k) is an HBM-write kernel
-    // (TBK_H_OVERLAP_BIG=0: one after the other, the round-3 order).
+    // Round 4, MEASURED AND LEFT OFF (DESIGN_LOG.md R4.15): the same for the direct H(k) of the two-stage sizes (from 185
+    // orbitals) -- that reduction is a chain of short phases which leaves the matrix pipe idle four fifths of the time, and
+    // the sparse H(k) is an HBM-write kernel.  Default: one after the other (the round-3 order); TBK_H_OVERLAP_BIG=1 turns
+    // the overlap (and the 84 KiB hk_lds_floor below) on for measurements.
     static const bool overlap_on = getenv("TBK_H_OVERLAP") == nullptr || atoi(getenv("TBK_H_OVERLAP")) != 0;
     static const bool overlap_big = getenv("TBK_H_OVERLAP_BIG") != nullptr && atoi(getenv("TBK_H_OVERLAP_BIG")) != 0;
     const bool h_overlap = n_chunks > 2 && overlap_on &&
@@ -947,6 +948,12 @@ static int eigenval_folded(tbk_model* m, const double* d_k, const double* h_k, i
     return TBK_OK;
 }
 
+// the call takes the library's own reduction kernels (the chunk pipeline), not rocSOLVER
+static bool eigenval_own_solvers(const tbk_model* m) {
+    return m->eigensolver != TBK_EIG_ROCSOLVER &&
+           (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb)));
+}
+
 static int eigenval_device_solve(tbk_model* m, const double* d_k, const double* h_k, int64_t nk, double* d_E) {
     TBK_ARG(m != nullptr, "model is NULL");
     TBK_LOCK(m);
@@ -960,8 +967,7 @@ static int eigenval_device_solve(tbk_model* m, const double* d_k, const double* 
         tbk_set_error("TBK_EIG_WAVE handles n_orb <= 64 only (n_orb = %d)", m->n_orb);
         return TBK_ERR_ARGUMENT;
     }
-    if (m->eigensolver != TBK_EIG_ROCSOLVER &&
-        (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb)))) {
+    if (eigenval_own_solvers(m)) {
         bool done = false;
         TBK_CHECK(eigenval_folded(m, d_k, h_k, nk, d_E, &done));
         if (done) return TBK_OK;
@@ -1004,8 +1010,7 @@ static int eigenval_device_impl(tbk_model* m, const double* d_k, const double* h
     TBK_CHECK(eigenval_device_solve(m, d_k, h_k, nk, d_E));
     // the wave solvers raise the flag themselves (QL and bisection see every non-finite (d, e) and answer NaN);
     // rocSOLVER's eigenvalues get the pass over the output
-    const bool own_solvers = m != nullptr && m->eigensolver != TBK_EIG_ROCSOLVER &&
-                             (tbk_eig_small_supported(m->n_orb) || (m->eigensolver == TBK_EIG_AUTO && tbk_eig_stream_supported(m->n_orb)));
+    const bool own_solvers = m != nullptr && eigenval_own_solvers(m);
     if (nk > 0 && m != nullptr && !own_solvers) {
         const int64_t total = nk * m->n_orb;
         const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8 * 1024);
@@ -1179,8 +1184,10 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
         // small call: [k | E | flags] through the pinned buffer, everything enqueued, one synchronisation
         char* st = static_cast<char*>(m->h_stage);
         int* flag = reinterpret_cast<int*>(st + k_bytes + e_bytes);
-        // (one k-point of a dense model on the matrix-vector path: k travels in the kernel arguments, see tbk_hamilton)
-        const bool inline_k = nk == 1 && !m->sparse && !m->kdotp && tbk_hk_inline_phases(m, 1);
+        // (one k-point of a dense model on the matrix-vector path: k travels in the kernel arguments, see tbk_hamilton --
+        // only the chunk pipeline reads it from there: the rocSOLVER branch fills its phase rows from ws_k, which a call
+        // that skipped the upload would leave stale)
+        const bool inline_k = nk == 1 && !m->sparse && !m->kdotp && eigenval_own_solvers(m) && tbk_hk_inline_phases(m, 1);
         if (inline_k) {
             m->h_k_inline = k;
         } else {
@@ -1236,6 +1243,88 @@ extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const d
         TBK_HIP(hipStreamSynchronize(m->stream));
         return TBK_OK;
     }();
+    tbk_model_destroy(m);
+    return rc;
+}
+
+// The reduction stage ALONE on the chip, timed with HIP events: what `eig_roofline.standalone` of bench.py quotes beside the
+// in-pipeline figure (there the H(k) of the next chunk shares the FP64 pipe).  Random Hermitian matrices are made on the
+// device; every repetition works on a fresh copy (the reduction consumes its input), only the reduction is inside the events.
+__global__ void __launch_bounds__(256) random_hermitian_kernel(double* __restrict__ H, int n, int64_t nk) {
+    const int64_t total = nk * (int64_t)n * n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t mat = t / ((int64_t)n * n);
+        const int r = (int)((t / n) % n), c = (int)(t % n);
+        const int i = r < c ? r : c, j = r < c ? c : r;  // the element of the upper triangle this one mirrors
+        uint64_t x = (uint64_t)mat * 0x9E3779B97F4A7C15ull + (uint64_t)i * 0xBF58476D1CE4E5B9ull + (uint64_t)j * 0x94D049BB133111EBull + 1;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        const double re = (double)(int64_t)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        x ^= x >> 29; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 32;
+        const double im = (double)(int64_t)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        H[2 * t] = re;
+        H[2 * t + 1] = i == j ? 0.0 : (r < c ? im : -im);
+    }
+}
+
+extern "C" int tbk_reduce_standalone(int device, int n_orb, int64_t nk, int reps, double* us_per_matrix) {
+    TBK_ARG(us_per_matrix != nullptr, "us_per_matrix is NULL");
+    TBK_ARG(nk >= 1 && reps >= 1, "nk / reps < 1");
+    TBK_ARG(n_orb >= 1 && n_orb <= 1024, "n_orb must be in [1, 1024]");
+    for (int q = 0; q < 3; ++q) us_per_matrix[q] = 0.0;
+    tbk_model* m = nullptr;
+    TBK_CHECK(create_common(device, 1, n_orb, 0, nullptr, 2, &m));
+    const size_t n = (size_t)n_orb, mat_bytes = n * n * 2 * sizeof(double);
+    DevBuf pristine;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = [&]() -> int {
+        TBK_LOCK(m);
+        m->call_nk = nk;
+        TBK_CHECK(pristine.reserve((size_t)nk * mat_bytes));
+        TBK_CHECK(m->ws_H.reserve((size_t)nk * mat_bytes));
+        TBK_CHECK(m->ws_E.reserve((size_t)nk * n * 2 * sizeof(double)));
+        TBK_HIP(hipEventCreate(&ev[0]));
+        TBK_HIP(hipEventCreate(&ev[1]));
+        hipLaunchKernelGGL(random_hermitian_kernel, dim3(4096), dim3(256), 0, m->stream, pristine.as<double>(), n_orb, nk);
+        TBK_HIP(hipGetLastError());
+        const bool band = !tbk_eig_small_supported(n_orb) && tbk_eig_two_stage(m);
+        if (band) {
+            TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n_orb)));
+            TBK_CHECK(m->ws_bandmat[0].reserve((size_t)nk * tbk_band_bytes_per_matrix(n_orb)));
+        }
+        // what: 0 = the reduction as the pipeline runs it, 1 = first stage alone, 2 = second stage alone (two-stage sizes only)
+        for (int what = 0; what < (band ? 3 : 1); ++what) {
+            float best = 0.0f, sum = 0.0f;
+            for (int r = 0; r <= reps; ++r) {  // (repetition 0 warms up)
+                if (what != 2)
+                    TBK_HIP(hipMemcpyAsync(m->ws_H.ptr, pristine.ptr, (size_t)nk * mat_bytes, hipMemcpyDeviceToDevice, m->stream));
+                TBK_HIP(hipEventRecord(ev[0], m->stream));
+                if (what == 0) {
+                    if (tbk_eig_small_supported(n_orb))
+                        TBK_CHECK(tbk_launch_tridiag(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>()));
+                    else
+                        TBK_CHECK(tbk_launch_tridiag_stream(m, m->stream, m->ws_H.as<double>(), nk, m->ws_E.as<double>(), TBK_REDUCE_AUTO));
+                } else if (what == 1) {
+                    TBK_CHECK(tbk_launch_band_reduce(m, m->stream, m->ws_H.as<double>(), nk, m->ws_band.ptr, m->ws_bandmat[0].ptr));
+                } else {
+                    TBK_CHECK(tbk_launch_band_chase(m, m->stream, m->ws_bandmat[0].ptr, nk, m->ws_E.as<double>()));
+                }
+                TBK_HIP(hipEventRecord(ev[1], m->stream));
+                TBK_HIP(hipEventSynchronize(ev[1]));
+                float ms = 0.0f;
+                TBK_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                if (r > 0) {
+                    sum += ms;
+                    best = (r == 1 || ms < best) ? ms : best;
+                }
+            }
+            (void)best;
+            us_per_matrix[what] = (double)sum / reps * 1e3 / (double)nk;
+        }
+        return TBK_OK;
+    }();
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    pristine.release();
     tbk_model_destroy(m);
     return rc;
 }

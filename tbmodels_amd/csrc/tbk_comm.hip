@@ -227,32 +227,75 @@ extern "C" int tbk_comm_agree(tbk_comm* c, int status, double* verdict) {
     return TBK_OK;
 }
 
-extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const double* d_k, const double* h_k, int64_t nk, int64_t per,
-                                          int host_status, double* d_all, double* d_status_all) {
-    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
-    TBK_ARG(per >= 0 && nk >= 0 && nk <= per, "need 0 <= nk <= per");
-    TBK_ARG(d_all != nullptr || per == 0, "result is NULL");
-    TBK_ARG(d_status_all != nullptr, "status array is NULL");
-    TBK_ARG(m->device == c->device, "model and communicator live on different devices");
-    TBK_LOCK(m);  // the hook below belongs to this call alone
+// The landing area of the pipelined gather ([world][block rows][n_orb] doubles) for slabs of `per` rows of `n_orb` values:
+// grow-only, sized from (per, n_orb, world) alone.  Callers run this INSIDE the step whose failures are exchanged by
+// tbk_comm_agree, so that an allocation failure on one rank reaches every rank's verdict before anybody enters the data
+// collectives; tbk_eigenval_device_gather itself only allocates when this was skipped.
+extern "C" int tbk_comm_prepare_gather(tbk_comm* c, int n_orb, int64_t per) {
+    TBK_ARG(c != nullptr, "comm is NULL");
+    TBK_ARG(n_orb >= 1 && per >= 0, "need n_orb >= 1, per >= 0");
     TBK_HIP(hipSetDevice(c->device));
-    const int64_t n = m->n_orb;
-    const int64_t slab = per * n;                       // doubles per rank
-    const int64_t B = tbk_gather_block_rows(per, (int)n);
-    const int64_t n_blocks = per > 0 ? (per + B - 1) / B : 0;
-    double* mine = d_all + (size_t)c->rank * slab;
-    const bool compute = host_status == 0 && nk > 0;
-    // rows this rank does not compute are zero (short or empty slab, or a rank that arrives with a failure)
-    const int64_t first_idle = compute ? nk : 0;
-    if (per > first_idle)
-        TBK_HIP(hipMemsetAsync(mine + (size_t)first_idle * n, 0, (size_t)(per - first_idle) * n * sizeof(double), m->stream));
-    const size_t want = (size_t)c->world * (size_t)B * n * sizeof(double);
-    if (want > c->stage_bytes) {  // (grow-only; the first call of a shape pays the allocation)
+    const int64_t B = tbk_gather_block_rows(per, n_orb);
+    const size_t want = (size_t)c->world * (size_t)B * (size_t)n_orb * sizeof(double);
+    if (want > c->stage_bytes) {
+        // (a gather of an earlier call may still read the old area: it is released behind the communicator's stream)
+        TBK_HIP(hipStreamSynchronize(c->stream));
         if (c->d_stage) TBK_HIP(hipFree(c->d_stage));
         c->d_stage = nullptr;
         c->stage_bytes = 0;
         TBK_HIP(hipMalloc((void**)&c->d_stage, want));
         c->stage_bytes = want;
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const double* d_k, const double* h_k, int64_t nk, int64_t per,
+                                          int host_status, double* d_all, double* d_status_all) {
+    // Without these nothing can be enqueued at all (the peers' agreement step has vouched for them):
+    TBK_ARG(c != nullptr && m != nullptr, "comm / model is NULL");
+    TBK_ARG(per >= 0, "per < 0");
+    TBK_ARG(d_all != nullptr || per == 0, "result is NULL");
+    TBK_ARG(d_status_all != nullptr, "status array is NULL");
+    TBK_ARG(m->device == c->device, "model and communicator live on different devices");
+    TBK_LOCK(m);  // the hook below belongs to this call alone
+    TBK_HIP(hipSetDevice(c->device));
+    // From here on a failure of THIS rank must not end the call: the peers are entering n_blocks all-gathers and the status
+    // gather, and a rank that returned early would leave them waiting.  It becomes this rank's status word instead -- the
+    // call walks the same sequence of collectives (its rows are then meaningless) and every rank raises alike.
+    int local = TBK_OK;
+    const auto soft = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && local == TBK_OK) {
+            tbk_set_error("%s failed: %s (tbk_eigenval_device_gather)", what, hipGetErrorString(e));
+            local = (e == hipErrorOutOfMemory) ? TBK_ERR_MEMORY : TBK_ERR_DEVICE;
+        }
+    };
+    if (nk < 0 || nk > per) {
+        tbk_set_error("invalid argument: need 0 <= nk <= per");
+        local = TBK_ERR_ARGUMENT;
+        nk = 0;
+    }
+    if (host_status != 0) local = host_status;
+    const int64_t n = m->n_orb;
+    const int64_t slab = per * n;                       // doubles per rank
+    const int64_t B = tbk_gather_block_rows(per, (int)n);
+    const int64_t n_blocks = per > 0 ? (per + B - 1) / B : 0;
+    double* mine = d_all + (size_t)c->rank * slab;
+    const bool compute = local == TBK_OK && nk > 0;
+    // rows this rank does not compute are zero (short or empty slab, or a rank that arrives with a failure)
+    const int64_t first_idle = compute ? nk : 0;
+    if (per > first_idle)
+        soft(hipMemsetAsync(mine + (size_t)first_idle * n, 0, (size_t)(per - first_idle) * n * sizeof(double), m->stream), "hipMemsetAsync");
+    double* landing = c->d_stage;
+    if ((size_t)c->world * (size_t)B * n * sizeof(double) > c->stage_bytes) {
+        // (tbk_comm_prepare_gather was skipped or asked for another shape)
+        const int rc_prepare = tbk_comm_prepare_gather(c, (int)n, per);
+        landing = c->d_stage;
+        if (rc_prepare != TBK_OK) {
+            if (local == TBK_OK) local = rc_prepare;
+            // no landing area: the result itself takes the pieces ([world][per][n] holds [world][B][n]); the status word says
+            // that nothing of this rank's copy is to be used
+            landing = d_all;
+        }
     }
     int64_t next_block = 0;
     const bool ranged = m->timing;
@@ -261,19 +304,21 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
             const int64_t b0 = next_block * B, rows = std::min(per, b0 + B) - b0;
             const int64_t count = rows * n;
             if (ranged) tbk_range_push("tbk:allgather_eigenvalues(block)");
-            const ncclResult_t r = ncclAllGather(mine + (size_t)b0 * n, c->d_stage, (size_t)count, ncclDouble, c->comm, c->stream);
+            const ncclResult_t r = ncclAllGather(mine + (size_t)b0 * n, landing, (size_t)count, ncclDouble, c->comm, c->stream);
             if (ranged) tbk_range_pop();
             TBK_NCCL(r);
-            if (((count | slab | (b0 * n)) & 1) == 0) {  // 16-byte copies when every piece starts on an even double
+            if (landing == d_all) {
+                // (this rank has no landing area and reports a failure: its rows are not placed)
+            } else if (((count | slab | (b0 * n)) & 1) == 0) {  // 16-byte copies when every piece starts on an even double
                 const int64_t pairs = count / 2;
                 const unsigned gx = (unsigned)std::min<int64_t>((pairs + 255) / 256, 512);
                 hipLaunchKernelGGL(gather_place_kernel, dim3(gx, (unsigned)c->world), dim3(256), 0, c->stream,
-                                   reinterpret_cast<const double2*>(c->d_stage), reinterpret_cast<double2*>(d_all), pairs, slab / 2,
+                                   reinterpret_cast<const double2*>(landing), reinterpret_cast<double2*>(d_all), pairs, slab / 2,
                                    b0 * n / 2);
                 TBK_HIP(hipGetLastError());
             } else {
                 for (int r2 = 0; r2 < c->world; ++r2)
-                    TBK_HIP(hipMemcpyAsync(d_all + (size_t)r2 * slab + (size_t)b0 * n, c->d_stage + (size_t)r2 * count,
+                    TBK_HIP(hipMemcpyAsync(d_all + (size_t)r2 * slab + (size_t)b0 * n, landing + (size_t)r2 * count,
                                            (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             }
             ++next_block;
@@ -292,10 +337,10 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
     }
     // whatever is left -- the zero rows of a short slab, paths without chunk events (rocSOLVER), a call that failed on
     // the way: the peers are waiting in the same sequence of collectives -- goes behind the main stream
-    TBK_HIP(hipEventRecord(c->tail, m->stream));
-    TBK_HIP(hipStreamWaitEvent(c->stream, c->tail, 0));
+    soft(hipEventRecord(c->tail, m->stream), "hipEventRecord");
+    soft(hipStreamWaitEvent(c->stream, c->tail, 0), "hipStreamWaitEvent");
     const int rc2 = send_blocks(per);
-    const int status = host_status != 0 ? host_status : (rc != TBK_OK ? rc : rc2);
+    const int status = local != TBK_OK ? local : (rc != TBK_OK ? rc : rc2);
     hipLaunchKernelGGL(status_word_kernel, dim3(1), dim3(1), 0, c->stream, m->ws_flag.as<int>(), status, c->d_status);
     TBK_HIP(hipGetLastError());
     TBK_NCCL(ncclAllGather(c->d_status, c->d_status + 1, 1, ncclDouble, c->comm, c->stream));
@@ -303,5 +348,6 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
     // the next call on the model's streams must not overwrite rows a gather is still reading
     TBK_HIP(hipEventRecord(c->done[0], c->stream));
     TBK_HIP(hipStreamWaitEvent(m->stream, c->done[0], 0));
+    if (local != TBK_OK && host_status == 0) return local;
     return rc != TBK_OK ? rc : rc2;
 }

@@ -159,6 +159,7 @@ class ShardedEigenval:
             handle = self.model._staged()  # pylint: disable=protected-access
             d_all = self._buffer("all", self.world * per * n_orb * 8)
             d_status = self._buffer("status", self.world * 8)
+            _lib.check(lib.tbk_comm_prepare_gather(comm, n_orb, per))  # the gather's landing area: its allocation can fail too
             if stop > start:
                 k_slab = np.ascontiguousarray(k[start:stop])
                 d_k = self._buffer("k", k_slab.nbytes)

@@ -24,7 +24,12 @@ def test_all_cores_baseline_runs_the_oracle_in_forked_workers():
     r_vec, hop, pos = syn.dense_model_arrays(6, 9, syn.MODEL_SEED + 5)
     arrays = dict(kind="dense", n_orb=6, R=r_vec, hop=hop, pos=pos)
     k = syn.random_kpoints(500)
-    result = bench.cpu_baseline_all_cores(arrays, k, per_proc=20)
+    from oracle import tbk_oracle as oracle
+
+    result, rows = bench.cpu_baseline_all_cores(arrays, k, per_proc=20)
+    # the rows the workers computed come back: they are the oracle sample the GPU result is compared with, row for row
+    total = min(len(k), 20 * result["cores"])
+    assert rows.shape == (total, 6) and np.array_equal(rows, np.array(oracle.eigenval(r_vec, hop, k[:total])))
     assert result["kind"] == "port" and result["cores"] == bench.usable_cores()
     assert result["value"] > 0 and result["unit"] == "k-points/s"
     assert ("%d k-points" % min(len(k), 20 * result["cores"])) in result["sample"]
@@ -118,6 +123,9 @@ class _StandInLib:
         self._buf(d_out)[: eig.size] = eig.reshape(-1)
         return 0
 
+    fail_rank = -1  # this rank's solver "fails" inside the gather: like the library, it still walks every collective and
+    # its verdict reaches every rank through the status words (the LAST collective)
+
     def tbk_eigenval_device_gather(self, comm, model, d_k, h_k, nk, per, host_status, d_all, d_status):
         n = self.arrays["n_orb"]
         slab = np.zeros((per, n))
@@ -125,11 +133,12 @@ class _StandInLib:
             slab[:nk] = self._eig(d_k, nk)
         pieces = self.group.all_gather_array(slab)
         self._buf(d_all)[: self.world * per * n] = np.concatenate(pieces).reshape(-1)
-        self._buf(d_status)[: self.world] = 0.0
+        mine = np.array([3.0 if self.rank == self.fail_rank else 0.0])
+        self._buf(d_status)[: self.world] = np.concatenate(self.group.all_gather_array(mine))
         return 0
 
 
-def _strong_leg_worker(rank, world, out_dir):
+def _strong_leg_worker(rank, world, out_dir, fail_rank=-1):
     import ctypes
     import json
 
@@ -142,8 +151,12 @@ def _strong_leg_worker(rank, world, out_dir):
     r_vec, hop, pos = syn.dense_model_arrays(5, 12, syn.MODEL_SEED + 77)
     arrays = dict(kind="dense", n_orb=5, R=r_vec, hop=hop, pos=pos)
     lib = _StandInLib(group, world, rank, arrays)
-    entry = bench.strong_scaling_leg(lib, 0, ctypes.c_void_p(1), ctypes.c_void_p(2), group, world, rank, 5, arrays, steps=1,
-                                     warmup=1, mesh=7)  # 343 points: slabs of 172 and 171
+    lib.fail_rank = fail_rank
+    try:
+        entry = bench.strong_scaling_leg(lib, 0, ctypes.c_void_p(1), ctypes.c_void_p(2), group, world, rank, 5, arrays, steps=1,
+                                         warmup=1, mesh=7)  # 343 points: slabs of 172 and 171 (world 2), 43 x 7 + 42 (world 8)
+    except RuntimeError as exc:
+        entry = {"raised": str(exc)}
     with open(os.path.join(out_dir, "leg%d.json" % rank), "w") as handle:
         json.dump(entry, handle)
     group.close()
@@ -151,18 +164,97 @@ def _strong_leg_worker(rank, world, out_dir):
 
 def test_strong_scaling_leg_logic_with_two_ranks(tmp_path):
     import json
-    import multiprocessing as mp
 
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_strong_leg_worker, args=(rank, 2, str(tmp_path))) for rank in range(2)]
-    for proc in procs:
-        proc.start()
-    for proc in procs:
-        proc.join(timeout=300)
-        assert proc.exitcode == 0, "worker exited with %r" % proc.exitcode
+    _run_leg_workers(tmp_path, 2)
     entry = json.load(open(tmp_path / "leg0.json"))
     assert json.load(open(tmp_path / "leg1.json")) is None  # only rank 0 reports
     assert entry["scaling"] == "strong" and entry["n_gpus"] == 2 and entry["rccl_ranks"] == 2 and entry["kpoints_per_rank"] == 172
     assert entry["max_abs_err_vs_oracle"] <= 1e-12 and entry["max_trace_identity_err_4096_rows"] <= 1e-10
     assert len(entry["per_rank"]["compute_ms"]) == 2 and len(entry["per_rank"]["exposed_gather_ms"]) == 2
     assert entry["value"] > 0 and "7^3 uniform mesh in 2 contiguous slabs" in entry["workload"]
+
+
+def _run_leg_workers(tmp_path, world, fail_rank=-1):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_strong_leg_worker, args=(rank, world, str(tmp_path), fail_rank)) for rank in range(world)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(timeout=300)
+        assert proc.exitcode == 0, "worker exited with %r" % proc.exitcode
+
+
+def test_strong_scaling_leg_with_eight_ranks_and_ragged_slabs(tmp_path):
+    """World 8 on the 7^3 mesh: 343 / 8 is no whole number and no multiple of a mesh plane (49) -- slabs of 43 rows cut
+    planes and lines, the last slab is short (42 rows + one padding row in the [rank][per][n] result).  Rows of every
+    slab reach rank 0's trace identity; the oracle rows are those of the first and the last slab."""
+    import json
+
+    _run_leg_workers(tmp_path, 8)
+    entry = json.load(open(tmp_path / "leg0.json"))
+    for rank in range(1, 8):
+        assert json.load(open(tmp_path / ("leg%d.json" % rank))) is None
+    assert entry["n_gpus"] == 8 and entry["rccl_ranks"] == 8 and entry["kpoints_per_rank"] == 43
+    assert entry["max_abs_err_vs_oracle"] <= 1e-12 and entry["max_trace_identity_err_4096_rows"] <= 1e-10
+    assert len(entry["per_rank"]["compute_ms"]) == 8 and "in 8 contiguous slabs" in entry["workload"]
+
+
+def test_strong_scaling_leg_failure_on_one_rank_reaches_every_rank(tmp_path):
+    """Rank 5's solver fails INSIDE the pipelined gather (its status word is non-zero; like libtbk it still walks every
+    collective): every one of the eight ranks raises, nobody hangs, nobody reports a number."""
+    import json
+
+    _run_leg_workers(tmp_path, 8, fail_rank=5)
+    for rank in range(8):
+        entry = json.load(open(tmp_path / ("leg%d.json" % rank)))
+        assert entry is not None and "status words" in entry["raised"], (rank, entry)
+
+
+def _guarded_worker(rank, world, out_dir, mode):
+    """One rank of bench.guarded_strong_leg: `mode` "hang" -- rank 1 never arrives at the leg's first collective, rank 0
+    waits in it for ever; "raise" -- the leg raises on rank 0."""
+    import io
+    import json
+    import time
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    result = {"metric": "m", "value": 1.0, "configs": None, "strong_scaling": None} if rank == 0 else None
+
+    def leg():
+        if mode == "raise":
+            raise RuntimeError("parity failure in the cfg4 strong-scaling leg")
+        if rank == 1:
+            return None
+        time.sleep(3600)  # the collective a lost peer never joins
+        return None
+
+    sys.stdout = open(os.path.join(out_dir, "stdout%d.txt" % rank), "w")
+    failed = bench.guarded_strong_leg(result, world, 1.0, leg)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+    sys.exit(1 if failed else 0)
+
+
+def test_strong_scaling_watchdog_prints_the_line_and_exits_non_zero(tmp_path):
+    """A rank lost in a collective: the watchdog prints rank 0's line (top-level "strong_scaling": "timeout", the error
+    under configs) and ends the process with a NON-ZERO status; a leg that raises gives "failed" and status 1."""
+    import json
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    for mode, want_rc, verdict in (("hang", 3, "timeout"), ("raise", 1, "failed")):
+        out = tmp_path / mode
+        out.mkdir()
+        proc = ctx.Process(target=_guarded_worker, args=(0, 2, str(out), mode))
+        proc.start()
+        proc.join(timeout=120)
+        assert proc.exitcode == want_rc, (mode, proc.exitcode)
+        lines = [line for line in open(out / "stdout0.txt").read().splitlines() if line.strip()]
+        assert len(lines) == 1
+        record = json.loads(lines[0])
+        assert record["strong_scaling"] == verdict and record["value"] == 1.0
+        assert "error" in record["configs"]["cfg4"] and record["configs"]["cfg4"]["n_gpus"] == 2

@@ -264,6 +264,19 @@ def test_chunk_pipelined_gather_equals_the_in_stream_gather(small_model):
         # a rank that arrives with a failure: nothing computed, its status gathered
         out, status, rc = _gather_call(lib, comm, handle, rand[:1000], 1000, 256, 0, host_status=_lib.TBK_ERR_MEMORY)
         assert int(status[0]) == _lib.TBK_ERR_MEMORY and not out.any()
+        # a failure of THIS rank behind the argument checks (here: more k-points than its slab has rows) does not end the
+        # call in front of the collectives -- the peers would wait in them: it travels as the status word, after the same
+        # sequence of gathers, and comes back as the return code
+        out, status, rc = _gather_call(lib, comm, handle, rand[:1000], 900, 256, 0)
+        assert rc == _lib.TBK_ERR_ARGUMENT and int(status[0]) == _lib.TBK_ERR_ARGUMENT and not out.any()
+        # the landing area is allocated in the agreement step (sharding.py): same results afterwards, bad shapes refused
+        _lib.check(lib.tbk_comm_prepare_gather(comm, 12, 50_000))
+        assert lib.tbk_comm_prepare_gather(comm, 0, 10) == _lib.TBK_ERR_ARGUMENT
+        out, status, rc = _gather_call(lib, comm, handle, rand[:3000], 3000, 700, 1024)
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 1024))
+        plain = model.eigenval_array(rand[:3000])
+        _lib.check(lib.tbk_model_set_option(handle, _lib.TBK_OPT_K_CHUNK, 0))
+        assert rc == 0 and status[0] == 0 and np.array_equal(out, plain)
         verdict = np.full(1, -1.0)
         _lib.check(lib.tbk_comm_agree(comm, 3, _lib.ptr(verdict)))
         assert verdict[0] == 3.0

@@ -490,6 +490,27 @@ def test_non_finite_k_is_value_error(silicon, kdotp_golden):
     assert np.isfinite(constant.eigenval(k)).all()
 
 
+@pytest.mark.parametrize("n_orb,solver", [(40, "rocsolver"), (64, "rocsolver"), (1030, "auto")])
+def test_one_k_calls_on_the_library_solver_branch_follow_k(n_orb, solver):
+    """ONE k-point per call (the Z2Pack call shape, `_tb_model.py:1103-1108`) on the branch that hands the matrices to
+    rocSOLVER (on request, or above the own kernels' range): the k-point of the CURRENT call must reach H(k) -- the chunk
+    pipeline takes it from the kernel arguments and skips the upload, this branch reads the uploaded copy (it
+    was evaluated at the previous call's k)."""
+    from tbmodels_amd import _lib
+
+    r_vec, hop, pos = syn.dense_model_arrays(n_orb, 3, syn.MODEL_SEED + 700 + n_orb)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.set_option(_lib.TBK_OPT_EIGENSOLVER, {"auto": _lib.TBK_EIG_AUTO, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[solver])
+    ks = syn.random_kpoints(3, seed=900 + n_orb)
+    batch = model.eigenval_array(ks)
+    ref = np.array(oracle.eigenval(r_vec, hop, ks))
+    _close(batch, ref)
+    for i in (2, 0, 1, 1):  # every call after one at a different k (and once at the same)
+        one = model.eigenval(ks[i])
+        assert one.shape == (n_orb,)
+        _close(one, ref[i])
+
+
 @pytest.mark.parametrize("n_orb,n_k", [(8, 5), (8, 6000), (40, 3), (64, 50000), (100, 4), (300, 2)])
 def test_non_finite_hopping_is_value_error(n_orb, n_k):
     """NaN / Inf in the model: every eigensolver path (1-wave and 4-wave reduction, QL and bisection, streaming
