@@ -61,6 +61,29 @@ __device__ unsigned long long tbk_band_clock[32];
 constexpr int PB = 8;    // panel height = band half-width
 constexpr int TS = 16;   // MFMA tile edge
 
+// Round 5: the 8 x 8 Gram-type sums of a panel -- P^H P of the panel QR, V^H V of the T factor, V^H X of the W phase -- on the
+// MATRIX pipe: the rows go through a wave-private LDS plane into operand order ([Re | Im] as 16 real columns, 16 MFMAs per 64
+// rows), the waves' 16 x 16 partial products meet ONCE, and the panel QR takes ALL its reflectors from that one Gram matrix
+// (tools/two_stage_model.py: panel_qr_gram).  Before: one round of vector products, 64-bit DPP wave sums and
+// a workgroup barrier PER REFLECTOR (8 per panel) plus two more for T and W.  TBK_PANEL_GRAM=0 builds the round-4 form (A/B).
+// One row per thread only (up to 256 orbitals, and every call of a few matrices): with two rows per thread the recurrence's
+// tracked block beside both rows did not fit the register file (60 - 340 B of scratch in every arrangement tried).
+#ifndef TBK_PANEL_GRAM
+#define TBK_PANEL_GRAM 1
+#endif
+constexpr int GP = 17;   // pitch (doubles) of a wave's transposition plane [64 rows][16 values]
+// a column whose remaining norm^2 (a difference of Gram sums) has cancelled below this fraction of its full norm^2 ends the
+// round: the rows apply the reflectors found so far and a fresh Gram matrix is formed (errors ~ eps sqrt(1 / fraction))
+constexpr double GRAM_THRESH = 1.0 / 64.0;
+
+// bytes of the X (+ V) area at the head of the dynamic LDS: [npad][8] complex once or twice, and at least the waves'
+// transposition planes, which live there while X and V are dead
+__host__ __device__ inline size_t band_xv_bytes(int npad, bool vn_lds, int nw, int rows) {
+    const size_t xv = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1);
+    const size_t planes = (TBK_PANEL_GRAM && rows == 1) ? (size_t)nw * 64 * GP * 8 : 0;
+    return xv > planes ? xv : planes;
+}
+
 __device__ __forceinline__ d2 cmul(d2 a, d2 b) { return (d2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
 __device__ __forceinline__ d2 cmulc(d2 a, d2 b) { return (d2){a[0] * b[0] + a[1] * b[1], a[1] * b[0] - a[0] * b[1]}; }  // a conj(b)
 __device__ __forceinline__ d2 conjd(d2 a) { return (d2){a[0], -a[1]}; }
@@ -105,6 +128,36 @@ __device__ __forceinline__ void cfma_bc(d2& acc, d2 a, d2 b_bc) {
     fnmac_bc<T>(re, b_bc[1], a[1]);
     fmac_bc<T>(im, b_bc[0], a[1]);
     acc = (d2){re, im};
+}
+
+// acc -= conj(a) b with a = the value lane T of `a_bc` holds in this lane's row of 16 lanes
+template <int T>
+__device__ __forceinline__ void cfnmacj_bc(d2& acc, d2 a_bc, d2 b) {
+    double re = acc[0], im = acc[1];
+    fnmac_bc<T>(re, a_bc[0], b[0]);
+    fnmac_bc<T>(re, a_bc[1], b[1]);
+    fnmac_bc<T>(im, a_bc[0], b[1]);
+    fmac_bc<T>(im, a_bc[1], b[0]);
+    acc = (d2){re, im};
+}
+
+// acc -= a b with b = the value lane T of `b_bc` holds in this lane's row of 16 lanes
+template <int T>
+__device__ __forceinline__ void cfnma_bc(d2& acc, d2 a, d2 b_bc) {
+    double re = acc[0], im = acc[1];
+    fnmac_bc<T>(re, b_bc[0], a[0]);
+    fmac_bc<T>(re, b_bc[1], a[1]);
+    fnmac_bc<T>(im, b_bc[1], a[0]);
+    fnmac_bc<T>(im, b_bc[0], a[1]);
+    acc = (d2){re, im};
+}
+
+// the value lane L of the wave holds, as a wave-uniform scalar
+template <int L>
+__device__ __forceinline__ double lane_value(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), L);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), L);
+    return __hiloint2double(hi, lo);
 }
 
 template <int CTRL>
@@ -553,7 +606,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     const int npad = nbk * TS;
     d2* sX = reinterpret_cast<d2*>(br_smem);               // [npad][8]   A V of the next panel
     d2* sVnL = sX + (size_t)npad * PB;                     // [npad][8]   next panel's V (rows < s are zero), VN_LDS only
-    double* sTr = reinterpret_cast<double*>(sVnL + (VN_LDS ? (size_t)npad * PB : 0));  // [NW][16][17] tile transposition planes
+    double* sTr = reinterpret_cast<double*>(reinterpret_cast<char*>(br_smem) + band_xv_bytes(npad, VN_LDS, NW, ROWS));  // [NW][16][17] tile transposition planes
     double* sPart = sTr + NW * 16 * 17;                    // [NW][64]
     double* sTot = sPart + NW * 64;                        // [64]
     d2* sRow = reinterpret_cast<d2*>(sTot + 64);           // [2][8] row c of the panel (QR), broadcast; alternating
@@ -593,6 +646,71 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #endif
 
     auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
+
+    constexpr bool GRAM = TBK_PANEL_GRAM && ROWS == 1;  // the panel's Gram-type sums on the matrix pipe (see TBK_PANEL_GRAM)
+#if TBK_PANEL_GRAM
+    // ---- C = A^H B (8 x 8 complex) of two row-distributed [rows][8] arrays, on the matrix pipe (PHASE 0 / 1 only) ----
+    // gram_rows: this wave's 64 rows of the operands go through its LDS plane (which lives at the head of the X / V area: the
+    // callers use it only while X and V are dead) into MFMA operand order -- O = [Re | Im] as 16 real columns, lane
+    // (g, j) holds O[row 16 g + rho][j] in register rho, A and B operand alike -- and 16 MFMAs add O_a^T O_b to `acc`.
+    // gram_finish: the waves' partial products meet ONCE (partials alternate between two areas of the tile-transposition
+    // planes, free outside the pass: the next meeting may be written while a slow wave still reads this one); every wave
+    // adds them in wave order -- identical bits everywhere -- and leaves C in sG[c][t].
+    double* const gplane = reinterpret_cast<double*>(br_smem) + (size_t)wave * (64 * GP);
+    d2* const gpart = reinterpret_cast<d2*>(sTr);  // [2][NW][64]
+    d2* const sG = reinterpret_cast<d2*>(sPart);   // [8][8]
+    int gram_parity = 0;
+    const int g_lrow = lane & 15, g_lq = lane >> 4;
+    auto gram_rows = [&](const d2 (&a)[PB], const d2 (&b)[PB], bool same, d4& acc) {
+        double opa[16], opb[16];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            gplane[lane * GP + j] = a[j][0];
+            gplane[lane * GP + PB + j] = a[j][1];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int rho = 0; rho < 16; ++rho) opa[rho] = gplane[(16 * g_lq + rho) * GP + g_lrow];
+        asm volatile("" ::: "memory");
+        if (!same) {  // (a wave's LDS operations are performed in order: the plane is reused without a wait)
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                gplane[lane * GP + j] = b[j][0];
+                gplane[lane * GP + PB + j] = b[j][1];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int rho = 0; rho < 16; ++rho) opb[rho] = gplane[(16 * g_lq + rho) * GP + g_lrow];
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int rho = 0; rho < 16; ++rho) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[rho], same ? opa[rho] : opb[rho], acc, 0, 0, 0);
+    };
+    auto gram_finish = [&](const d4& acc) {
+        // acc: lane (q, j), register r = M[q + 4 r][j], M = O_a^T O_b;  C[c][t] = M[c][t] + M[8 + c][8 + t] + i (M[c][8 + t] - M[8 + c][t])
+        const double sgn = g_lrow < 8 ? 1.0 : -1.0;
+        d2 mine;
+        mine[0] = fma(dpp_mov<0x128>(acc[2]), sgn, acc[0]);  // c = q:     Re C[c][j] (j < 8) / Im C[c][j - 8]
+        mine[1] = fma(dpp_mov<0x128>(acc[3]), sgn, acc[1]);  // c = q + 4
+        gpart[(gram_parity * NW + wave) * 64 + lane] = mine;
+        lds_fence();
+        __syncthreads();
+        d2 tot = gpart[(gram_parity * NW) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const d2 v = gpart[(gram_parity * NW + w) * 64 + lane];
+            tot[0] += v[0];
+            tot[1] += v[1];
+        }
+        gram_parity ^= 1;
+        // every wave writes the same 128 values (and reads them back behind its own writes)
+        double* gd = reinterpret_cast<double*>(sG);
+        gd[((g_lq)*PB + (g_lrow & 7)) * 2 + (g_lrow >> 3)] = tot[0];
+        gd[((g_lq + 4) * PB + (g_lrow & 7)) * 2 + (g_lrow >> 3)] = tot[1];
+        asm volatile("" ::: "memory");
+    };
+#endif
 
     // ---- one pass over the tiles of the trailing triangle (model: big_pass) ----
     // s: rows / columns below s are finished (their V / W / Vn rows are zero);  with_hemm: accumulate X = A Vn.
@@ -992,6 +1110,118 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
         }
         if (tid < PB) sTau[tid] = (d2){0.0, 0.0};  // (read after the barriers of the Gram sums below)
+        if constexpr (GRAM) {
+#if TBK_PANEL_GRAM
+            // All reflectors of a round from ONE Gram matrix (model: panel_qr_gram).  Every 16-lane row of every wave runs the
+            // recurrence for itself -- lane t holds column t % 8 of G and of the tracked top rows, values every lane needs come
+            // out of lane c as scalars (v_readlane) or as row_newbcast operands -- and each reflector is applied to the rows as
+            // soon as its coefficients exist: no meeting, no LDS traffic inside a round.
+            const int last = min(PB, m - 1);  // columns c < last have a row below the diagonal
+            d2* const sTop = sS;              // [8][8] rows s + i of the panel (S only lives inside the W phase)
+            const int t8 = lane & 7;
+            int c0 = 0;
+            while (c0 < last) {  // rounds: one, unless a column's remaining norm cancels (structured matrices)
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int i_top = row_of(rr) - s;
+                    if (qr_row[rr] && i_top >= c0 && i_top < PB) {
+#pragma unroll
+                        for (int cp = 0; cp < PB; ++cp) sTop[i_top * PB + cp] = y[rr][cp];
+                    }
+                    const bool in_sum = qr_row[rr] && i_top >= c0;  // (rows above c0 are finished rows of R)
+                    if (!__any(in_sum)) continue;                  // wave-uniform
+                    d2 op[PB];
+#pragma unroll
+                    for (int cp = 0; cp < PB; ++cp) op[cp] = in_sum ? y[rr][cp] : (d2){0.0, 0.0};
+                    gram_rows(op, op, true, acc);
+                }
+                TBK_CLK(12);  // QR: transposition + Gram products
+                gram_finish(acc);
+                TBK_CLK(13);  // QR: the meeting
+                // (row c of G is read one step ahead of its use: all eight rows held from the start were 14 more live registers)
+                d2 top[PB];
+#pragma unroll
+                for (int c = 0; c < PB; ++c) top[c] = (c >= c0 && c < m) ? sTop[c * PB + t8] : (d2){0.0, 0.0};
+                d2 g_next = sG[min(c0, PB - 1) * PB + t8];
+                bool stopped = false;
+                int c1 = last;
+                static_for<0, PB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if (c >= c0 && c < last && !stopped) {  // uniform
+                        // g[t] = sum over the rows from s + c on of conj(y_c) y_t = G[c][t] - sum_{i < c} conj(R[i][c]) R[i][t]
+                        const d2 g_row = g_next;
+                        g_next = sG[min(c + 1, PB - 1) * PB + t8];
+                        d2 g = g_row;
+                        static_for<0, c>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            cfnmacj_bc<c>(g, top[i], top[i]);  // (rows above c0: zero)
+                        });
+                        const double gcc = lane_value<c>(g[0]);
+                        const double Gcc = lane_value<c>(g_row[0]);
+                        if (c > c0 && !(gcc >= GRAM_THRESH * Gcc)) {  // cancelled: the round ends in front of this column
+                            stopped = true;
+                            c1 = c;
+                        } else {
+                            const d2 alpha = (d2){lane_value<c>(top[c][0]), lane_value<c>(top[c][1])};
+                            const d2 rowv = top[c];
+                            const double sigma = gcc - (alpha[0] * alpha[0] + alpha[1] * alpha[1]);
+                            if (!(gcc == 0.0 || (sigma == 0.0 && alpha[1] == 0.0))) {  // uniform
+                                double root, rroot;
+                                fast_sqrt_rsqrt(gcc, root, rroot);
+                                const double beta = -copysign(root, alpha[0]);
+                                const double rbeta = -copysign(rroot, alpha[0]);
+                                const d2 tau_c = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                                if (tid == 0) sTau[c] = tau_c;
+                                const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+                                const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+                                const d2 scale = (d2){qr_ * qn, -qi_ * qn};  // 1 / (alpha - beta)
+                                // z = v^H y_t = conj(scale) (g - conj(alpha) row) + row;  f = conj(tau) z, columns t > c
+                                d2 tz = g;
+                                cfnmac(tz, rowv, alpha);
+                                d2 z = cmulc(tz, scale);
+                                z[0] += rowv[0];
+                                z[1] += rowv[1];
+                                d2 f = cmul(conjd(tau_c), z);
+                                if (t8 <= c) f = (d2){0.0, 0.0};
+                                // row c of R; the tracked rows below it
+                                top[c] = t8 > c ? (d2){rowv[0] - f[0], rowv[1] - f[1]} : (t8 == c ? (d2){beta, 0.0} : (d2){0.0, 0.0});
+                                static_for<c + 1, PB>([&](auto ic) {
+                                    constexpr int i = decltype(ic)::value;
+                                    d2 vt = (d2){0.0, 0.0};
+                                    cfma_bc<c>(vt, scale, top[i]);  // v[i] = scale y[i][c]
+                                    cfma(top[i], (d2){-vt[0], -vt[1]}, f);
+                                });
+                                // the rows' side, every row for itself: v = scale y_c, y_t -= v f[t]
+#pragma unroll
+                                for (int rr = 0; rr < ROWS; ++rr) {
+                                    const bool below = qr_row[rr] && row_of(rr) >= s + c;
+                                    const bool head = row_of(rr) == s + c;
+                                    d2 v = cmul(y[rr][c], scale);
+                                    v = below ? (head ? (d2){1.0, 0.0} : v) : (d2){0.0, 0.0};
+                                    vn[rr][c] = v;
+                                    static_for<c + 1, PB>([&](auto cpc) {
+                                        constexpr int cp = decltype(cpc)::value;
+                                        cfnma_bc<cp>(y[rr][cp], v, f);  // (every lane takes part: v is zero outside the rows)
+                                    });
+                                    if (below) y[rr][c] = head ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                                }
+                            }
+                        }
+                    }
+                });
+                TBK_CLK(14);  // QR: recurrence + rows
+                c0 = c1;
+                if (c0 < last) {  // (rare) another round: the top rows and partial areas are written again
+                    lds_fence();
+                    __syncthreads();
+                }
+            }
+            // (sTop = the S area and sG = the partial-sum area are written again by the T block's Gram matrix below)
+            lds_fence();
+            __syncthreads();
+#endif
+        } else {
 #pragma unroll
         for (int c = 0; c < PB; ++c) {
             if (c <= m - 2) {  // uniform: a row below the diagonal exists
@@ -1091,6 +1321,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // (1 wrong matrix in ~250 000; tools/race_check2.py).
         lds_fence();
         __syncthreads();
+        }
         TBK_CLK(15);  // QR: reflector + update (and whatever follows the last step)
         // the thread of row s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
 #pragma unroll
@@ -1106,6 +1337,16 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         TBK_CLK(1);
         // ---- T of the compact WY form from the Gram matrix of V (model: t_factor); kept in LDS over the big pass ----
         {
+            if constexpr (GRAM) {
+#if TBK_PANEL_GRAM
+                // G = V^H V on the matrix pipe; the planes sit on the X / V area, so V is handed over BEHIND the meeting
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr)
+                    if (__any(qr_row[rr])) gram_rows(vn[rr], vn[rr], true, acc);  // (vn is zero outside the trailing rows)
+                gram_finish(acc);
+#endif
+            } else {
             // G[c2][c] = sum_i conj(v_c2) v_c for c2 < c: 28 complex sums, pair (c, c2) at slot 2 (c (c - 1) / 2 + c2)
             double hold[4];
             int k = 0;
@@ -1122,6 +1363,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     if ((k & 3) == 0) wave_partial4(k - 4, hold[0], hold[1], hold[2], hold[3], sPart, lane, wave);
                 }
             }
+            }
             // hand-over of Vn (LDS or global) HERE, in front of the T block: nobody reads it before the pass, and with the
             // rows of V dead the eight lanes that build T (28 Gram sums + tau + a row of T: 176 registers) fit
 #pragma unroll
@@ -1132,7 +1374,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     for (int c = 0; c < PB; ++c) sVn[(size_t)i_row * PB + c] = vn[rr][c];
                 }
             }
-            wg_finish<NW>(56, sPart, sTot, tid);
+            if constexpr (!GRAM) wg_finish<NW>(56, sPart, sTot, tid);
             // lane a of the first wave builds row a of T: T[a][c] = -tau_c sum_{c2 = a}^{c - 1} T[a][c2] G[c2][c]
             if (tid < PB) {
                 // (the three other waves wait for these eight lanes: all Gram sums and tau first, in flight together, then
@@ -1140,8 +1382,20 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 // one of the 64 reads was a round trip on the chain)
                 const int a = tid;
                 d2 gm[28], tauv[PB], trow[PB];
+                if constexpr (GRAM) {
+#if TBK_PANEL_GRAM
+                    static_for<1, PB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        static_for<0, c>([&](auto c2c) {
+                            constexpr int c2 = decltype(c2c)::value;
+                            gm[c * (c - 1) / 2 + c2] = sG[c2 * PB + c];  // conj(v_c2) v_c
+                        });
+                    });
+#endif
+                } else {
 #pragma unroll
-                for (int k = 0; k < 28; ++k) gm[k] = *reinterpret_cast<const d2*>(sTot + 2 * k);
+                    for (int k = 0; k < 28; ++k) gm[k] = *reinterpret_cast<const d2*>(sTot + 2 * k);
+                }
 #pragma unroll
                 for (int c = 0; c < PB; ++c) tauv[c] = sTau[c];
 #pragma unroll
@@ -1199,6 +1453,17 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
         }
         {
+            if constexpr (GRAM) {
+#if TBK_PANEL_GRAM
+                // M = V^H (A V) on the matrix pipe.  Every thread holds its row of X and V now: behind this meeting the
+                // waves' planes may overwrite the X / V area
+                lds_fence();
+                __syncthreads();
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                if (__any(qr_row[0])) gram_rows(vr[0], xr[0], false, acc);
+                gram_finish(acc);
+#endif
+            } else {
             // M = V^H (A V) is Hermitian: upper triangle, row a at slot a (16 - a): the real diagonal entry, then
             // (re, im) of M[a][b] for b > a -- 64 values
             double hold[4];
@@ -1228,6 +1493,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 }
             }
             wg_finish<NW>(64, sPart, sTot, tid);
+            }
             // 64 threads: S[i][j] = sum_ab conj(T[a][i]) M[a][b] T[b][j]
             if (tid < 64) {
                 const int si = tid >> 3, sj = tid & 7;
@@ -1238,7 +1504,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
                     for (int b = 0; b < PB; ++b) {
                         d2 mab;
-                        if (b == a) {
+                        if constexpr (GRAM) {  // (the upper triangle and its mirror, like the packed form)
+#if TBK_PANEL_GRAM
+                            const d2 mu = sG[min(a, b) * PB + max(a, b)];
+                            mab = (d2){mu[0], b == a ? 0.0 : (b > a ? mu[1] : -mu[1])};
+#endif
+                        } else if (b == a) {
                             mab = (d2){sTot[a * (16 - a)], 0.0};
                         } else if (b > a) {
                             const int at = a * (16 - a) + 1 + 2 * (b - a - 1);
@@ -1473,7 +1744,8 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     static const bool wide_env = !(getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 0);
     const bool wide = wide_env && n <= 512 && std::max<int64_t>(m->call_nk, nk) <= 128;
     const int nw = (n > 512 || wide) ? 8 : 4;
-    size_t lds = (size_t)npad * PB * 16 * (vn_lds ? 2 : 1) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
+    const int rows_per_thread = (n > 512 || (n > 256 && !wide)) ? 2 : 1;  // (the instantiation chosen below)
+    size_t lds = band_xv_bytes(npad, vn_lds, nw, rows_per_thread) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
     // d_de_fused: the workgroup runs the second stage too (same LDS) and writes (d, e) itself; d_band is not used
     const int np = chase_pitch(n);
     double* d_D = d_de_fused;
@@ -1486,10 +1758,10 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
     if (d_de_fused == nullptr && tbk_band_split(m, nk)) {
         // the launch chain: one row per thread where the rows allow it (the serial phases are thread-per-row)
-        auto lds_for = [&](int waves) { return (size_t)npad * PB * 16 + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16; };
-        if (n <= 256) return launch_split<256, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(4));
-        if (n <= 512) return launch_split<512, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8));
-        return launch_split<512, 2>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8));
+        auto lds_for = [&](int waves, int rows) { return band_xv_bytes(npad, false, waves, rows) + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16; };
+        if (n <= 256) return launch_split<256, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(4, 1));
+        if (n <= 512) return launch_split<512, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8, 1));
+        return launch_split<512, 2>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8, 2));
     }
     static std::atomic<bool> raised[6][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
@@ -1503,7 +1775,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // matrix; 38 KiB of LDS, second stage in its own launch
     static const bool narrow_env = getenv("TBK_BAND_NARROW") && atoi(getenv("TBK_BAND_NARROW")) != 0;
     if (narrow_env && !wide && n <= 256 && d_de_fused == nullptr) {
-        lds = (size_t)npad * PB * 16 + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
+        lds = band_xv_bytes(npad, false, 2, 2) + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
         TBK_REDUCE(128, 2, false, 5);
     } else if (wide && vn_lds)
         TBK_REDUCE(512, 1, true, 3);

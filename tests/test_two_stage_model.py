@@ -83,3 +83,83 @@ def test_pass_chain_keeps_the_addition_order_of_the_partner_products():
                     assert not bad, (na, n_waves, members, bad[:2])
                 unordered_somewhere |= bool(bad)
     assert unordered_somewhere  # (the check can fail: eight waves on 5 - 11 blocks are unordered, and keep the barrier)
+
+
+def _band_eig_error(h, panel_qr):
+    """Scaled eigenvalue error of the band the model's first stage leaves with `panel_qr` as its panel factorisation."""
+    n = len(h)
+    saved = model.panel_qr
+    model.panel_qr = panel_qr
+    try:
+        band, _ = model.stage1_band(h)
+    finally:
+        model.panel_qr = saved
+    hb = np.zeros((n, n), dtype=complex)
+    for i in range(n):
+        for dd in range(min(model.B, n - 1 - i) + 1):
+            hb[i, i + dd] = band[i, dd]
+            hb[i + dd, i] = np.conj(band[i, dd])
+    ref = np.linalg.eigvalsh(h)
+    return np.abs(np.linalg.eigvalsh(hb) - ref).max() / max(1e-300, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n", [40, 97])
+def test_gram_panel_qr_is_as_accurate_as_the_sequential_one_and_restarts_where_it_must(n):
+    """Round 5 (csrc/tbk_eig_band.hip, TBK_PANEL_GRAM): all reflectors of a panel from ONE Gram matrix.  The remaining norm
+    of a column is a difference of Gram sums; a column where it has cancelled below 1/64 of the full norm ends the round and a
+    fresh Gram matrix is formed (model.panel_qr_gram).  Random matrices never need a second round; the structured matrices of
+    tests/test_gpu_parity.py::test_eigensolver_structured_matrices that make columns (nearly) dependent -- graded, rank one,
+    two equal blocks, rank 3 + noise, a tridiagonal one -- do, and stay as accurate as with one round of sums per reflector;
+    WITHOUT the threshold the same matrices lose all accuracy."""
+    rng = np.random.default_rng(100 + n)
+    rand = _hermitian(rng, n)
+    graded = rand * np.outer(10.0 ** -np.arange(n) / max(1, n // 8), np.ones(n))
+    blk = np.zeros((n, n), dtype=complex)
+    h = n // 2
+    blk[:h, :h] = rand[:h, :h]
+    blk[h:, h:] = rand[:n - h, :n - h]
+    low = rand[:, :3] @ rand[:, :3].conj().T
+    cases = {  # name: (matrix, must the QR take extra rounds?)
+        "random": (rand, False), "tiny": (rand * 1e-30, False), "huge": (rand * 1e30, False),
+        "diagonal": (np.diag(rng.standard_normal(n)).astype(complex), False),
+        "identity": (np.eye(n, dtype=complex) * 0.75, False),
+        "graded": ((graded + graded.conj().T) / 2, True),
+        "imag_offdiag": (np.diag(np.arange(n, dtype=float)) + 1j * (np.eye(n, k=1) - np.eye(n, k=-1)), True),
+        "two_equal_blocks": (blk, None),  # (restarts at some sizes only)
+        "rank_one": (np.outer(rand[:, 0], rand[:, 0].conj()), True),
+        "rank3_plus_1e-9": (low + 1e-9 * rand, True),
+    }
+    worst_without = 0.0
+    for name, (mat, restarts) in cases.items():
+        sequential = _band_eig_error(mat, model.panel_qr)
+        model.GRAM_STATS.update(rounds=0, panels=0, columns=0)
+        gram = _band_eig_error(mat, model.panel_qr_gram)
+        stats = dict(model.GRAM_STATS)
+        assert gram <= max(4.0 * sequential, 2e-14), (name, gram, sequential)
+        if restarts:
+            assert stats["rounds"] > stats["panels"], (name, stats)
+        elif restarts is not None:
+            assert stats["rounds"] <= stats["panels"], (name, stats)  # (panels without a row below the diagonal: no round)
+        if restarts:
+            worst_without = max(worst_without, _band_eig_error(mat, lambda y: model.panel_qr_gram(y, thresh=0.0)))
+    assert worst_without > 1e-9  # the threshold is part of the algorithm
+
+
+def test_gram_panel_qr_returns_the_factors_of_the_sequential_one():
+    """Same V, tau and R to rounding on a well-conditioned panel; a panel with an exactly dependent column takes a second
+    round and still reproduces Q R."""
+    rng = np.random.default_rng(8)
+    y = rng.standard_normal((50, model.B)) + 1j * rng.standard_normal((50, model.B))
+    v1, t1, r1 = model.panel_qr(y)
+    v2, t2, r2 = model.panel_qr_gram(y)
+    assert np.abs(v1 - v2).max() < 1e-13 and np.abs(t1 - t2).max() < 1e-13 and np.abs(r1 - r2).max() < 1e-12
+    y[:, 5] = y[:, 1] * (0.3 - 0.2j) + y[:, 2]  # exactly dependent
+    model.GRAM_STATS.update(rounds=0, panels=0, columns=0)
+    v, tau, r = model.panel_qr_gram(y)
+    assert model.GRAM_STATS["rounds"] >= 2
+    q = np.eye(50, dtype=complex)
+    for c in range(model.B):
+        q = q @ (np.eye(50) - tau[c] * np.outer(v[:, c], v[:, c].conj()))
+    full = np.zeros((50, model.B), dtype=complex)
+    full[:model.B] = np.triu(r)
+    assert np.abs(q @ full - y).max() < 1e-12 and np.abs(q.conj().T @ q - np.eye(50)).max() < 1e-13

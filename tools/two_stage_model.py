@@ -58,6 +58,88 @@ def panel_qr(y):
     return V, tau, y[:min(m, B), :]
 
 
+# Threshold of the Gram-matrix panel QR below: a column whose remaining norm^2 g = G_cc - sum_{i<c} |R_ic|^2 has cancelled
+# below GRAM_THRESH x G_cc ends the round -- the rows apply the reflectors found so far and a fresh Gram matrix is formed.
+# Errors of the reflectors found from differences scale with eps x sqrt(G_cc / g): <= 8 eps at 1 / 64.
+GRAM_THRESH = 1.0 / 64.0
+GRAM_STATS = {"rounds": 0, "panels": 0, "columns": 0}
+
+
+def panel_qr_gram(y, thresh=None):
+    """
+    The panel QR of csrc/tbk_eig_band.hip with TBK_PANEL_GRAM (round 5): ALL reflectors of a round from ONE Gram matrix
+    G = P^H P of the panel's rows (formed on the matrix pipe, one meeting of the workgroup) and the explicitly tracked top
+    rows -- the inner products every later reflector needs follow from G, which the reflectors leave invariant, minus the
+    finished rows R[i]:  g_c[t] = G[c][t] - sum_{i<c} conj(R[i][c]) R[i][t].  Every wave runs the 8-step recurrence on
+    8 x 8 data for itself; the rows then apply the reflectors of the round without meeting in between.  g_c[c] is a
+    difference: when it has cancelled below `thresh` x G[c][c] the round ends in front of column c, the rows bring the
+    panel up to date and the next round starts from a fresh Gram matrix of the rows and columns that are left (a column
+    right behind a fresh Gram matrix never triggers: there is nothing to subtract).  Same return values as panel_qr.
+    """
+    if thresh is None:
+        thresh = GRAM_THRESH
+    m = y.shape[0]
+    y = y.copy()
+    V = np.zeros((m, B), dtype=complex)
+    tau = np.zeros(B, dtype=complex)
+    last = min(B, m - 1)  # columns c <= m - 2 have a row below the diagonal
+    GRAM_STATS["panels"] += 1
+    GRAM_STATS["columns"] += max(last, 0)
+    c0 = 0
+    while c0 < last:
+        GRAM_STATS["rounds"] += 1
+        G = y[c0:, :].conj().T @ y[c0:, :]           # ONE reduction round (rows above c0 are finished)
+        top = y[c0:min(m, B), :].copy()              # rows c0 .. 7 of the panel, tracked by every wave for itself
+        R = {}
+        steps = []                                   # (c, scale, f, tau_c, beta) handed to the rows
+        c = c0
+        while c < last:
+            g = G[c, :].copy()
+            for i in range(c0, c):
+                g -= np.conj(R[i][c]) * R[i]
+            gcc = g[c].real
+            if c > c0 and not gcc >= thresh * G[c, c].real:
+                break                                # cancelled: this round ends in front of column c
+            row = top[c - c0].copy()
+            alpha = row[c]
+            sigma = gcc - abs(alpha) ** 2
+            if gcc == 0.0 or (sigma == 0.0 and alpha.imag == 0.0):
+                R[c] = row                           # H_c = I: the row stays, tau = 0, v = 0
+                steps.append((c, 0.0, np.zeros(B, dtype=complex), 0.0, None))
+                c += 1
+                continue
+            beta = -np.copysign(np.sqrt(gcc), alpha.real)
+            tau_c = (beta - alpha) / beta
+            scale = 1.0 / (alpha - beta)
+            z = np.conj(scale) * (g - np.conj(alpha) * row) + row
+            f = np.conj(tau_c) * z
+            f[:c + 1] = 0.0
+            Rc = row - f
+            Rc[c] = beta
+            Rc[:c] = 0.0
+            R[c] = Rc
+            for i in range(c + 1, min(m, B)):        # the tracked rows below
+                vtop = top[i - c0][c] * scale
+                top[i - c0] = top[i - c0] - vtop * f
+                top[i - c0][c] = 0.0
+            steps.append((c, scale, f, tau_c, beta))
+            c += 1
+        # the rows' side, every row for itself
+        for (cc, scale, f, tau_c, beta) in steps:
+            if beta is None:
+                continue
+            v = y[:, cc] * scale
+            v[:cc] = 0.0
+            v[cc] = 1.0
+            V[:, cc] = v
+            tau[cc] = tau_c
+            y[cc:, :] -= np.outer(v[cc:], f)
+            y[cc, cc] = beta
+            y[cc + 1:, cc] = 0.0
+        c0 = c
+    return V, tau, y[:min(m, B), :]
+
+
 def t_factor(V, tau):
     """Upper triangular T of the compact WY form Q = I - V T V^H from the Gram matrix G = V^H V (one reduction round)."""
     G = V.conj().T @ V
