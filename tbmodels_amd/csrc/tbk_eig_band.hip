@@ -1318,7 +1318,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         }
         // The last step's totals are read from the partial-sum area as they are used; the Gram sums below write it
         // again: without this meeting a wave that had run ahead overwrote partials another wave was still adding up
-        // (1 wrong matrix in ~250 000; tools/race_check2.py).
+        // (1 wrong matrix in ~250 000; tools/race_check.py --model).
         lds_fence();
         __syncthreads();
         }
@@ -1742,7 +1742,8 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // rows per thread in the thread-per-row phases.  By the size of the CALL (TBK_OPT_K_CHUNK must not change a result:
     // the partial sums of eight waves differ from those of four in the last bit).  TBK_BAND_WIDE=0: off (measurements).
     static const bool wide_env = !(getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 0);
-    const bool wide = wide_env && n <= 512 && std::max<int64_t>(m->call_nk, nk) <= 128;
+    static const bool wide_all = getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 2;  // (measurements: every call size)
+    const bool wide = wide_env && n <= 512 && (wide_all || std::max<int64_t>(m->call_nk, nk) <= 128);
     const int nw = (n > 512 || wide) ? 8 : 4;
     const int rows_per_thread = (n > 512 || (n > 256 && !wide)) ? 2 : 1;  // (the instantiation chosen below)
     size_t lds = band_xv_bytes(npad, vn_lds, nw, rows_per_thread) + (size_t)(nw * 16 * 17 + nw * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
