@@ -1016,7 +1016,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
         }
         prog_base += n_visits;
-        wg_sync();  // tile stores complete before anybody re-reads the matrix
+        // The pass ends on an LDS-only meeting (X is complete).  Its tile stores drain under whatever follows: nobody reads
+        // the matrix before the next meeting that waits for the stores -- the end of the W phase in the panel loop, the
+        // explicit one behind the last pass, the end of the kernel in the launch chain (round 5: the wait for the stores
+        // here was a memory round trip per panel with nothing to do).
+        lds_fence();
+        __syncthreads();
     };
 
     // thread t <-> global rows / columns t + rr NT, rr < ROWS, in the thread-per-row phases
@@ -1052,8 +1057,10 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // ---- look-ahead: block row p (8 rows, columns >= 8 p) brought up to date with the pending (V, W) ----
         // the 8 pending rows [V | W][g0 + r][0 .. 15]: lane t of every row of 16 lanes holds entry t, and the FMAs below
         // take it from there (row_newbcast) -- through LDS they were 128 broadcast reads per thread and panel, and two
-        // more workgroup barriers (the staging area is the partial-sum area of the reductions)
-        wg_sync();
+        // more workgroup barriers (the staging area is the partial-sum area of the reductions).
+        // (No meeting here: the W phase of the previous panel ended on one that waited for its stores of VW and for the
+        // pass' stores of the tiles, and the first panel reads nothing anybody wrote.)
+        asm volatile("" ::: "memory");  // (compiler fence: the loads below stay here)
         d2 pend[PB];
 #pragma unroll
         for (int r = 0; r < PB; ++r) pend[r] = have_update ? VW[vw_index(min(g0 + r, n - 1), lane & 15)] : (d2){0.0, 0.0};
@@ -1138,6 +1145,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 }
                 TBK_CLK(12);  // QR: transposition + Gram products
                 gram_finish(acc);
+                // everybody is through the look-ahead: the pending rows it consumed are zeroed HERE, so that the stores are
+                // long done when the hand-over waits for them (issued there, their round trip was exposed)
+                if (c0 == 0 && have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
                 TBK_CLK(13);  // QR: the meeting
                 // (row c of G is read one step ahead of its use: all eight rows held from the start were 14 more live registers)
                 d2 top[PB];
@@ -1416,7 +1426,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // (X is cleared in linear order: a thread clearing its own row of 128 bytes shares its banks with every second
         // lane -- the V stores above pay that, the rows being the threads' own)
         for (int i = tid; i < npad * PB; i += NT) sX[i] = (d2){0.0, 0.0};
-        if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
+        if constexpr (!GRAM) {
+            if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
+        }
         wg_sync();
         TBK_CLK(3);
         if (PHASE == 1) {  // the pass of this panel is the next launch; T waits for the W phase in global memory
@@ -1497,6 +1509,27 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             // 64 threads: S[i][j] = sum_ab conj(T[a][i]) M[a][b] T[b][j]
             if (tid < 64) {
                 const int si = tid >> 3, sj = tid & 7;
+                if constexpr (GRAM) {
+#if TBK_PANEL_GRAM
+                    // in two steps through the wave's own LDS queue (round 5): (M T)[a][j] once per entry instead of once per
+                    // (i, j) -- 16 instead of 72 complex products per thread, on the one wave the other three wait for.
+                    // (M as the matrix pipe delivered it, both triangles; the diagonal real)
+                    d2* const sMT = sG + 64;  // (behind M in the partial-sum area: 2 KiB with four waves)
+                    d2 inner = (d2){0.0, 0.0};  // (M T)[si][sj]
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        d2 mab = sG[si * PB + b];
+                        if (b == si) mab[1] = 0.0;
+                        cfma(inner, mab, sT[b * PB + sj]);
+                    }
+                    sMT[si * PB + sj] = inner;
+                    asm volatile("" ::: "memory");  // (one wave: its LDS operations are performed in order)
+                    d2 acc = (d2){0.0, 0.0};
+#pragma unroll
+                    for (int a = 0; a < PB; ++a) cfmac(acc, sMT[a * PB + sj], sT[a * PB + si]);  // conj(T[a][si]) (M T)[a][sj]
+                    sS[tid] = acc;
+#endif
+                } else {
                 d2 acc = (d2){0.0, 0.0};
 #pragma unroll
                 for (int a = 0; a < PB; ++a) {
@@ -1504,12 +1537,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
                     for (int b = 0; b < PB; ++b) {
                         d2 mab;
-                        if constexpr (GRAM) {  // (the upper triangle and its mirror, like the packed form)
-#if TBK_PANEL_GRAM
-                            const d2 mu = sG[min(a, b) * PB + max(a, b)];
-                            mab = (d2){mu[0], b == a ? 0.0 : (b > a ? mu[1] : -mu[1])};
-#endif
-                        } else if (b == a) {
+                        if (b == a) {
                             mab = (d2){sTot[a * (16 - a)], 0.0};
                         } else if (b > a) {
                             const int at = a * (16 - a) + 1 + 2 * (b - a - 1);
@@ -1523,6 +1551,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     cfmac(acc, inner, sT[a * PB + si]);  // conj(T[a][si]) inner
                 }
                 sS[tid] = acc;
+                }
             }
             wg_sync();
         }
