@@ -152,6 +152,13 @@ __device__ __forceinline__ void cfnma_bc(d2& acc, d2 a, d2 b_bc) {
     acc = (d2){re, im};
 }
 
+// a wave-uniform double, moved to scalar registers
+__device__ __forceinline__ double to_scalar(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // the value lane L of the wave holds, as a wave-uniform scalar
 template <int L>
 __device__ __forceinline__ double lane_value(double v) {
@@ -648,6 +655,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
 
     constexpr bool GRAM = TBK_PANEL_GRAM && ROWS == 1;  // the panel's Gram-type sums on the matrix pipe (see TBK_PANEL_GRAM)
+    // Two rows per thread (257 - 1024 orbitals in batches): both rows of the panel beside the recurrence's tracked block do not fit
+    // the register file, so the panel's rows live in the X AREA OF THE LDS during the QR ([row][8] complex, X's own layout; X is
+    // dead there) and pass through the registers one row at a time.  The matrix instructions read that layout directly -- lane
+    // (g, j) takes [row 16 g + rho][Re j] / [Im j - 8] -- so there are no planes: the QR's and T's sums read the rows where they
+    // lie, and X itself is an operand of the W phase's sum without being disturbed (V comes from global memory there).
+    constexpr bool GRAM2 = TBK_PANEL_GRAM && ROWS > 1 && !VN_LDS;
 #if TBK_PANEL_GRAM
     // ---- C = A^H B (8 x 8 complex) of two row-distributed [rows][8] arrays, on the matrix pipe (PHASE 0 / 1 only) ----
     // gram_rows: this wave's 64 rows of the operands go through its LDS plane (which lives at the head of the X / V area: the
@@ -660,8 +673,8 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
     d2* const gpart = reinterpret_cast<d2*>(sTr);  // [2][NW][64]
     d2* const sG = reinterpret_cast<d2*>(sPart);   // [8][8]
     int gram_parity = 0;
-    const int g_lrow = lane & 15, g_lq = lane >> 4;
     auto gram_rows = [&](const d2 (&a)[PB], const d2 (&b)[PB], bool same, d4& acc) {
+        const int g_lrow = lane & 15, g_lq = lane >> 4;
         double opa[16], opb[16];
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -687,8 +700,39 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
 #pragma unroll
         for (int rho = 0; rho < 16; ++rho) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[rho], same ? opa[rho] : opb[rho], acc, 0, 0, 0);
     };
+    // GRAM2: acc += O_a^T O_b over the 64 rows from base_row on; the operands [row][8] complex in LDS (a_lds / b_lds) or, when
+    // a_glob is set, the A operand in global memory (same layout).  Rows before first_row and from npad on count as zero.
+    auto gram_direct = [&](const d2* a_lds, const d2* a_glob, const d2* b_lds, int base_row, int first_row, d4& acc) {
+        // (the lane's place is worked out HERE, from a copy of the lane number the compiler cannot see through: hoisted out of
+        // the panel loop, three more registers lived across the tile pass -- which sits at 253 with two rows per thread -- and
+        // the allocator answered with 100 - 700 B of scratch)
+        int lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
+        const int g_lrow = lane_here & 15, g_lq = lane_here >> 4;
+        const int col = g_lrow < 8 ? 2 * g_lrow : 2 * (g_lrow - 8) + 1;  // Re j / Im (j - 8) of a row of 16 doubles
+        const bool plain = base_row >= first_row && base_row + 64 <= npad;  // wave-uniform
+        double opa[16], opb[16];
+#pragma unroll
+        for (int rho = 0; rho < 16; ++rho) {
+            const int row = base_row + 16 * g_lq + rho;
+            const int at = (plain ? row : min(row, npad - 1)) * 16 + col;
+            double va = a_glob ? reinterpret_cast<const double*>(a_glob)[at] : reinterpret_cast<const double*>(a_lds)[at];
+            if (!plain) va = (row >= first_row && row < npad) ? va : 0.0;
+            opa[rho] = va;
+            if (b_lds) {
+                double vb = reinterpret_cast<const double*>(b_lds)[at];
+                if (!plain) vb = (row >= first_row && row < npad) ? vb : 0.0;
+                opb[rho] = vb;
+            }
+        }
+#pragma unroll
+        for (int rho = 0; rho < 16; ++rho) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[rho], b_lds ? opb[rho] : opa[rho], acc, 0, 0, 0);
+    };
     auto gram_finish = [&](const d4& acc) {
         // acc: lane (q, j), register r = M[q + 4 r][j], M = O_a^T O_b;  C[c][t] = M[c][t] + M[8 + c][8 + t] + i (M[c][8 + t] - M[8 + c][t])
+        int lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
+        const int g_lrow = lane_here & 15, g_lq = lane_here >> 4;
         const double sgn = g_lrow < 8 ? 1.0 : -1.0;
         d2 mine;
         mine[0] = fma(dpp_mov<0x128>(acc[2]), sgn, acc[0]);  // c = q:     Re C[c][j] (j < 8) / Im C[c][j - 8]
@@ -1061,9 +1105,11 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // (No meeting here: the W phase of the previous panel ended on one that waited for its stores of VW and for the
         // pass' stores of the tiles, and the first panel reads nothing anybody wrote.)
         asm volatile("" ::: "memory");  // (compiler fence: the loads below stay here)
+        int lane_la = lane;  // (opaque copy: what is derived from the lane number here does not live across the tile pass)
+        asm volatile("" : "+v"(lane_la));
         d2 pend[PB];
 #pragma unroll
-        for (int r = 0; r < PB; ++r) pend[r] = have_update ? VW[vw_index(min(g0 + r, n - 1), lane & 15)] : (d2){0.0, 0.0};
+        for (int r = 0; r < PB; ++r) pend[r] = have_update ? VW[vw_index(min(g0 + r, n - 1), lane_la & 15)] : (d2){0.0, 0.0};
         d2 x[ROWS][PB];
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -1117,7 +1163,165 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
         }
         if (tid < PB) sTau[tid] = (d2){0.0, 0.0};  // (read after the barriers of the Gram sums below)
-        if constexpr (GRAM) {
+        if constexpr (GRAM2) {
+#if TBK_PANEL_GRAM
+            // The panel's rows go to the X area (every thread its own rows; zero outside the trailing rows), the registers are
+            // free for the recurrence.  One round = Gram matrix of the rows where they lie, the recurrence on every wave (as in the
+            // one-row form, but the coefficients of ALL its reflectors are kept: f per lane, the wave-uniform scale and beta in
+            // scalar registers), then every row passes through the registers once: its reflectors are applied, its entry of R
+            // goes to the matrix, its row of V to global memory AND back into the X area -- the T factor's sum reads it there.
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                if (row_of(rr) < npad) {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) sX[(size_t)row_of(rr) * PB + c] = y[rr][c];
+                }
+            }
+            const int last = min(PB, m - 1);
+            int lane_here = lane;  // (see gram_direct: nothing derived from the lane number may live across the tile pass)
+            asm volatile("" : "+v"(lane_here));
+            const int t8 = lane_here & 7;
+            int c0 = 0;
+            while (c0 < last) {
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {  // this wave's own rows (its threads wrote them: no meeting in front)
+                    const int base_row = wave * 64 + rr * NT;
+                    if (base_row + 64 <= s + c0 || base_row >= n) continue;  // wave-uniform: nothing of the sum here
+                    gram_direct(sX, nullptr, nullptr, base_row, s + c0, acc);
+                }
+                TBK_CLK(12);
+                gram_finish(acc);
+                TBK_CLK(13);
+                if (c0 == 0 && have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
+                d2 top[PB];
+#pragma unroll
+                for (int c = 0; c < PB; ++c) top[c] = (c >= c0 && c < m) ? sX[(size_t)min(s + c, npad - 1) * PB + t8] : (d2){0.0, 0.0};
+                d2 g_next = sG[min(c0, PB - 1) * PB + t8];
+                bool stopped = false;
+                int c1 = last;
+                // the coefficients of the round's reflectors wait in LDS for the rows (every wave writes the same values and
+                // reads its own writes back): f per column in the S area, (scale, beta, applied?) in the row buffer
+                d2* const sF = sS;
+                unsigned has_mask = 0;
+                static_for<0, PB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if (c >= c0 && c < last && !stopped) {  // uniform
+                        const d2 g_row = g_next;
+                        g_next = sG[min(c + 1, PB - 1) * PB + t8];
+                        d2 g = g_row;
+                        static_for<0, c>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            cfnmacj_bc<c>(g, top[i], top[i]);
+                        });
+                        const double gcc = lane_value<c>(g[0]);
+                        const double Gcc = lane_value<c>(g_row[0]);
+                        if (c > c0 && !(gcc >= GRAM_THRESH * Gcc)) {
+                            stopped = true;
+                            c1 = c;
+                        } else {
+                            const d2 alpha = (d2){lane_value<c>(top[c][0]), lane_value<c>(top[c][1])};
+                            const d2 rowv = top[c];
+                            const double sigma = gcc - (alpha[0] * alpha[0] + alpha[1] * alpha[1]);
+                            if (!(gcc == 0.0 || (sigma == 0.0 && alpha[1] == 0.0))) {  // uniform
+                                double root, rroot;
+                                fast_sqrt_rsqrt(gcc, root, rroot);
+                                const double beta = -copysign(root, alpha[0]);
+                                const double rbeta = -copysign(rroot, alpha[0]);
+                                const d2 tau_c = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                                if (tid == 0) sTau[c] = tau_c;
+                                const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+                                const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+                                const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+                                d2 tz = g;
+                                cfnmac(tz, rowv, alpha);
+                                d2 z = cmulc(tz, scale);
+                                z[0] += rowv[0];
+                                z[1] += rowv[1];
+                                d2 f = cmul(conjd(tau_c), z);
+                                if (t8 <= c) f = (d2){0.0, 0.0};
+                                top[c] = t8 > c ? (d2){rowv[0] - f[0], rowv[1] - f[1]} : (t8 == c ? (d2){beta, 0.0} : (d2){0.0, 0.0});
+                                static_for<c + 1, PB>([&](auto ic) {
+                                    constexpr int i = decltype(ic)::value;
+                                    d2 vt = (d2){0.0, 0.0};
+                                    cfma_bc<c>(vt, scale, top[i]);
+                                    cfma(top[i], (d2){-vt[0], -vt[1]}, f);
+                                });
+                                sF[c * PB + t8] = f;
+                                sRow[c] = scale;
+                                sRow[PB + c] = (d2){beta, 0.0};
+                                has_mask |= 1u << c;
+                            }
+                        }
+                    }
+                });
+                TBK_CLK(14);
+                // the rows, one at a time through the registers
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int i_row = row_of(rr);
+                    // (wave-uniform.  Rows of the block the trailing matrix starts in are rewritten although they are finished:
+                    // the pass reads whole blocks of V, and their rows of the previous panel's V must become zero)
+                    if (!__any(i_row < npad && i_row >= (s & ~(TS - 1)))) continue;
+                    const int i_at = min(i_row, npad - 1);
+                    d2 yr[PB], vrow[PB];
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        yr[c] = sX[(size_t)i_at * PB + c];
+                        vrow[c] = (d2){0.0, 0.0};
+                    }
+                    static_for<0, PB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (c >= c0 && c < c1 && (has_mask >> c & 1u)) {  // uniform
+                            const bool below = qr_row[rr] && i_row >= s + c;
+                            const bool head = i_row == s + c;
+                            const d2 f_c = sF[c * PB + t8];
+                            const d2 sc_c = sRow[c];
+                            const double beta_c = sRow[PB + c][0];
+                            d2 v = cmul(yr[c], sc_c);
+                            v = below ? (head ? (d2){1.0, 0.0} : v) : (d2){0.0, 0.0};
+                            vrow[c] = v;
+                            static_for<c + 1, PB>([&](auto cpc) {
+                                constexpr int cp = decltype(cpc)::value;
+                                cfnma_bc<cp>(yr[cp], v, f_c);  // (every lane takes part: v is zero outside the rows)
+                            });
+                            if (below) yr[c] = head ? (d2){beta_c, 0.0} : (d2){0.0, 0.0};
+                        }
+                    });
+                    // the thread of row s + c holds row c of R (final once reflector c is through): column s + c of the block row
+                    if (qr_row[rr] && i_row - s >= c0 && i_row - s < c1) {
+                        const int c = i_row - s;
+#pragma unroll
+                        for (int r = 0; r < PB; ++r)
+                            if (g0 + r < n) *Hat(g0 + r, i_row) = (r >= c) ? conjd(yr[r]) : (d2){0.0, 0.0};
+                    }
+                    if (i_row < npad) {
+                        // columns of this round: the row of V (global memory for the pass, the X area for the T factor's sum);
+                        // behind them what is left of the panel for the next round -- or, behind the last column with a row
+                        // below the diagonal, zeros
+#pragma unroll
+                        for (int c = 0; c < PB; ++c) {
+                            if (c >= c0 && c < c1) {
+                                sX[(size_t)i_row * PB + c] = vrow[c];
+                                sVn[(size_t)i_row * PB + c] = vrow[c];
+                            } else if (c >= c1) {
+                                const d2 keep = c1 < last ? yr[c] : (d2){0.0, 0.0};
+                                sX[(size_t)i_row * PB + c] = keep;
+                                if (c1 >= last) sVn[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
+                            }
+                        }
+                    }
+                }
+                c0 = c1;
+                if (c0 < last) {
+                    lds_fence();
+                    __syncthreads();
+                }
+            }
+            lds_fence();
+            __syncthreads();
+#endif
+        } else if constexpr (GRAM) {
 #if TBK_PANEL_GRAM
             // All reflectors of a round from ONE Gram matrix (model: panel_qr_gram).  Every 16-lane row of every wave runs the
             // recurrence for itself -- lane t holds column t % 8 of G and of the tracked top rows, values every lane needs come
@@ -1334,8 +1538,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         }
         TBK_CLK(15);  // QR: reflector + update (and whatever follows the last step)
         // the thread of row s + c holds row c of R: column s + c of the block row is conj(R[c][r]) for r >= c
+        // (GRAM2: stored where the row passed through the registers)
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
+        for (int rr = 0; rr < (GRAM2 ? 0 : ROWS); ++rr) {
             const int i_row = row_of(rr);
             if (qr_row[rr] && i_row < s + PB) {
                 const int c = i_row - s;
@@ -1347,7 +1552,19 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         TBK_CLK(1);
         // ---- T of the compact WY form from the Gram matrix of V (model: t_factor); kept in LDS over the big pass ----
         {
-            if constexpr (GRAM) {
+            if constexpr (GRAM2) {
+#if TBK_PANEL_GRAM
+                // G = V^H V from the rows of V where the QR left them (the X area), this wave's own rows
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int base_row = wave * 64 + rr * NT;
+                    if (base_row + 64 <= s || base_row >= n) continue;  // wave-uniform
+                    gram_direct(sX, nullptr, nullptr, base_row, 0, acc);
+                }
+                gram_finish(acc);
+#endif
+            } else if constexpr (GRAM) {
 #if TBK_PANEL_GRAM
                 // G = V^H V on the matrix pipe; the planes sit on the X / V area, so V is handed over BEHIND the meeting
                 d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1376,23 +1593,25 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
             // hand-over of Vn (LDS or global) HERE, in front of the T block: nobody reads it before the pass, and with the
             // rows of V dead the eight lanes that build T (28 Gram sums + tau + a row of T: 176 registers) fit
+            // (GRAM2: every row of V went out where it passed through the registers)
 #pragma unroll
-            for (int rr = 0; rr < ROWS; ++rr) {
+            for (int rr = 0; rr < (GRAM2 ? 0 : ROWS); ++rr) {
                 const int i_row = row_of(rr);
                 if (i_row < npad) {
 #pragma unroll
                     for (int c = 0; c < PB; ++c) sVn[(size_t)i_row * PB + c] = vn[rr][c];
                 }
             }
-            if constexpr (!GRAM) wg_finish<NW>(56, sPart, sTot, tid);
+            if constexpr (!GRAM && !GRAM2) wg_finish<NW>(56, sPart, sTot, tid);
             // lane a of the first wave builds row a of T: T[a][c] = -tau_c sum_{c2 = a}^{c - 1} T[a][c2] G[c2][c]
             if (tid < PB) {
                 // (the three other waves wait for these eight lanes: all Gram sums and tau first, in flight together, then
                 // the recurrence on registers, then the row -- read where they are used, between the stores of T, every
                 // one of the 64 reads was a round trip on the chain)
-                const int a = tid;
+                int a = tid;  // (opaque: the 64 comparisons with it below are not to be hoisted out of the panel loop as masks)
+                asm volatile("" : "+v"(a));
                 d2 gm[28], tauv[PB], trow[PB];
-                if constexpr (GRAM) {
+                if constexpr (GRAM || GRAM2) {
 #if TBK_PANEL_GRAM
                     static_for<1, PB>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
@@ -1426,7 +1645,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         // (X is cleared in linear order: a thread clearing its own row of 128 bytes shares its banks with every second
         // lane -- the V stores above pay that, the rows being the threads' own)
         for (int i = tid; i < npad * PB; i += NT) sX[i] = (d2){0.0, 0.0};
-        if constexpr (!GRAM) {
+        if constexpr (!GRAM && !GRAM2) {
             if (have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
         }
         wg_sync();
@@ -1455,8 +1674,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
         }
         // ---- W = X T - V S / 2,  S = T^H (V^H X) T  (model: stage1_band) ----
         d2 xr[ROWS][PB], vr[ROWS][PB];  // this thread's rows of A V and of V, read back (nothing lives in registers over the pass)
+        // (GRAM2: the sum below reads X and V where they lie; the rows are read one at a time further down)
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
+        for (int rr = 0; rr < (GRAM2 ? 0 : ROWS); ++rr) {
             const int i_row = min(row_of(rr), npad - 1);
 #pragma unroll
             for (int c = 0; c < PB; ++c) {
@@ -1465,7 +1685,20 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
         }
         {
-            if constexpr (GRAM) {
+            if constexpr (GRAM2) {
+#if TBK_PANEL_GRAM
+                // M = V^H (A V): X from the LDS where the pass left it (undisturbed), V from global memory, both in the operands'
+                // own layout.  (Rows in front of the trailing matrix: V is zero there, whatever X holds.)
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int base_row = wave * 64 + rr * NT;
+                    if (base_row + 64 <= s || base_row >= n) continue;  // wave-uniform
+                    gram_direct(nullptr, sVn, sX, base_row, 0, acc);
+                }
+                gram_finish(acc);
+#endif
+            } else if constexpr (GRAM) {
 #if TBK_PANEL_GRAM
                 // M = V^H (A V) on the matrix pipe.  Every thread holds its row of X and V now: behind this meeting the
                 // waves' planes may overwrite the X / V area
@@ -1509,7 +1742,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             // 64 threads: S[i][j] = sum_ab conj(T[a][i]) M[a][b] T[b][j]
             if (tid < 64) {
                 const int si = tid >> 3, sj = tid & 7;
-                if constexpr (GRAM) {
+                if constexpr (GRAM || GRAM2) {
 #if TBK_PANEL_GRAM
                     // in two steps through the wave's own LDS queue (round 5): (M T)[a][j] once per entry instead of once per
                     // (i, j) -- 16 instead of 72 complex products per thread, on the one wave the other three wait for.
@@ -1560,10 +1793,12 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             // them from there (row_newbcast: every lane of a wave takes part; xr, vr are zero outside the trailing rows)
             // -- 100 LDS broadcast reads per thread before
             d2 tb[4], sb[4];
+            int lane_w = lane;
+            asm volatile("" : "+v"(lane_w));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                tb[k] = sT[16 * k + (lane & 15)];
-                sb[k] = sS[16 * k + (lane & 15)];
+                tb[k] = sT[16 * k + (lane_w & 15)];
+                sb[k] = sS[16 * k + (lane_w & 15)];
             }
             if (ROWS > 1) asm volatile("" ::: "memory");  // (the re-reads below stay behind the Gram sums above)
 #pragma unroll
