@@ -1289,7 +1289,8 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                         }
                     });
                     // the thread of row s + c holds row c of R (final once reflector c is through): column s + c of the block row
-                    if (qr_row[rr] && i_row - s >= c0 && i_row - s < c1) {
+                    // (rows s + c with c >= last have no reflector of their own: they are final once the round's are through)
+                    if (qr_row[rr] && i_row - s < PB && ((i_row - s >= c0 && i_row - s < c1) || (c1 >= last && i_row - s >= last))) {
                         const int c = i_row - s;
 #pragma unroll
                         for (int r = 0; r < PB; ++r)
@@ -1688,13 +1689,14 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             if constexpr (GRAM2) {
 #if TBK_PANEL_GRAM
                 // M = V^H (A V): X from the LDS where the pass left it (undisturbed), V from global memory, both in the operands'
-                // own layout.  (Rows in front of the trailing matrix: V is zero there, whatever X holds.)
+                // own layout.  Rows in front of the trailing matrix are masked: X holds products of finished rows there, and
+                // the rows of V in blocks the pass no longer reads are not rewritten (they hold an earlier panel's V).
                 d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) {
                     const int base_row = wave * 64 + rr * NT;
                     if (base_row + 64 <= s || base_row >= n) continue;  // wave-uniform
-                    gram_direct(nullptr, sVn, sX, base_row, 0, acc);
+                    gram_direct(nullptr, sVn, sX, base_row, s, acc);
                 }
                 gram_finish(acc);
 #endif
