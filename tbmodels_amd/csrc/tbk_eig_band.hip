@@ -1743,7 +1743,9 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
             }
             // 64 threads: S[i][j] = sum_ab conj(T[a][i]) M[a][b] T[b][j]
             if (tid < 64) {
-                const int si = tid >> 3, sj = tid & 7;
+                int tid_s = tid;  // (opaque: the comparisons and addresses below are not to live across the panel loop)
+                asm volatile("" : "+v"(tid_s));
+                const int si = tid_s >> 3, sj = tid_s & 7;
                 if constexpr (GRAM || GRAM2) {
 #if TBK_PANEL_GRAM
                     // in two steps through the wave's own LDS queue (round 5): (M T)[a][j] once per entry instead of once per
@@ -1762,7 +1764,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     d2 acc = (d2){0.0, 0.0};
 #pragma unroll
                     for (int a = 0; a < PB; ++a) cfmac(acc, sMT[a * PB + sj], sT[a * PB + si]);  // conj(T[a][si]) (M T)[a][sj]
-                    sS[tid] = acc;
+                    sS[tid_s] = acc;
 #endif
                 } else {
                 d2 acc = (d2){0.0, 0.0};
