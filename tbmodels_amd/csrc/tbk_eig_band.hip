@@ -1889,6 +1889,517 @@ __global__ void __launch_bounds__(256) band_extract_kernel(const double* __restr
     }
 }
 
+
+// ================================================================================================
+// stage 1 ABOVE 1024 orbitals (round 5): the same algorithm as a chain of launches with nothing per row in
+// registers or LDS.  The kernels above keep a row of the panel per thread (two at most) and X = A V in LDS
+// ([npad][8] complex: 128 KiB at 1024 orbitals) -- neither scales.  Here every panel is three launches:
+//   band_xl_serial_kernel   one workgroup per matrix: the W phase of the previous panel, then look-ahead, panel QR from
+//                           ONE Gram matrix (the GRAM2 form: the panel's rows in the X / Y buffer in GLOBAL memory, one
+//                           row at a time through the registers, matrix instructions reading the [row][8] layout where
+//                           it lies) and the T factor;
+//   band_xl_update_kernel   a workgroup per block row I of the trailing matrix: tile(I, J) -= [V | W]_I ([W | V]_J)^H, J >= I;
+//   band_xl_product_kernel  a workgroup per block row I: X_I = sum_J tile(I, J) Vn_J over ALL J -- the tiles left of the
+//                           diagonal read as the transposed stored ones -- so every block of X has ONE owner, complete in
+//                           registers: no partner sums, no LDS for X, any number of rows.  (Every tile is read twice: 1.5 x
+//                           the tile traffic of the one-pass form.)
+// Stream order is the only synchronisation between them.  Same arithmetic as the kernels above (tools/two_stage_model.py:
+// panel_qr_gram, stage1_band); band_extract_kernel, the global-memory chase and the bisection follow.
+// ================================================================================================
+template <int NT>
+__global__ void __launch_bounds__(NT, 1)
+band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ XYall,
+                      d2* __restrict__ Tall, int p) {
+    constexpr int NW = NT / 64;
+    __shared__ d2 sPartG[2 * NW * 64];  // the waves' partial Gram products, two areas in turn
+    __shared__ d2 sG[128];              // C of the Gram routine; (M T) behind it in the W phase
+    __shared__ d2 sS[64], sT[64], sF[64], sTau[PB], sCo[2 * PB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const size_t mat = blockIdx.x;
+    double* H = Hall + mat * (size_t)n * n * 2;
+    d2* VW = VWall + mat * (size_t)nbk * 256;   // pending [V | W] rows, fragment order
+    d2* VN = VNall + mat * (size_t)npad * PB;   // the panel's V, [npad][8]
+    d2* XY = XYall + mat * (size_t)npad * PB;   // X = A V between the product sweep and the W phase; the panel's rows in the QR
+    d2* gT = Tall + mat * 64;                   // T of the panel, for the W phase in the next launch
+    auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
+    const int lane15 = lane & 15, t8 = lane & 7;
+
+    int gram_parity = 0;
+    // acc += O_a^T O_b over the rows [base_row, base_row + 64) that lie in [first_row, npad); a, b: [npad][8] complex in global memory
+    auto gram_direct = [&](const d2* a, const d2* b, int base_row, int first_row, d4& acc) {
+        const int g_lq = lane >> 4;
+        const int col = lane15 < 8 ? 2 * lane15 : 2 * (lane15 - 8) + 1;
+        const bool plain = base_row >= first_row && base_row + 64 <= npad;  // wave-uniform
+        double opa[16], opb[16];
+#pragma unroll
+        for (int rho = 0; rho < 16; ++rho) {
+            const int row = base_row + 16 * g_lq + rho;
+            const size_t at = (size_t)(plain ? row : min(row, npad - 1)) * 16 + col;
+            double va = reinterpret_cast<const double*>(a)[at];
+            if (!plain) va = (row >= first_row && row < npad) ? va : 0.0;
+            opa[rho] = va;
+            if (b != a) {
+                double vb = reinterpret_cast<const double*>(b)[at];
+                if (!plain) vb = (row >= first_row && row < npad) ? vb : 0.0;
+                opb[rho] = vb;
+            }
+        }
+#pragma unroll
+        for (int rho = 0; rho < 16; ++rho) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[rho], b != a ? opb[rho] : opa[rho], acc, 0, 0, 0);
+    };
+    // the workgroup's total -> sG[c][t]; the meeting also waits for this wave's global stores (rows other waves read next)
+    auto gram_finish = [&](const d4& acc) {
+        const int g_lq = lane >> 4;
+        const double sgn = lane15 < 8 ? 1.0 : -1.0;
+        d2 mine;
+        mine[0] = fma(dpp_mov<0x128>(acc[2]), sgn, acc[0]);
+        mine[1] = fma(dpp_mov<0x128>(acc[3]), sgn, acc[1]);
+        sPartG[(gram_parity * NW + wave) * 64 + lane] = mine;
+        wg_sync();
+        d2 tot = sPartG[(gram_parity * NW) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const d2 v = sPartG[(gram_parity * NW + w) * 64 + lane];
+            tot[0] += v[0];
+            tot[1] += v[1];
+        }
+        gram_parity ^= 1;
+        double* gd = reinterpret_cast<double*>(sG);
+        gd[((g_lq)*PB + (lane15 & 7)) * 2 + (lane15 >> 3)] = tot[0];
+        gd[((g_lq + 4) * PB + (lane15 & 7)) * 2 + (lane15 >> 3)] = tot[1];
+        asm volatile("" ::: "memory");
+    };
+
+    if (p == 0)
+        for (int i = tid; i < nbk * 256; i += NT) VW[i] = (d2){0.0, 0.0};
+
+    // ---- W of panel p - 1:  W = X T - V S / 2,  S = T^H (V^H X) T ----
+    if (p > 0) {
+        const int s = PB * p;            // start of that panel's trailing matrix
+        const int lo = s & ~(TS - 1);
+        if (tid < 64) sT[tid] = gT[tid];
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int q = wave; lo + 64 * q < n; q += NW) gram_direct(VN, XY, lo + 64 * q, s, acc);
+        gram_finish(acc);
+        if (tid < 64) {
+            const int si = tid >> 3, sj = tid & 7;
+            d2* const sMT = sG + 64;
+            d2 inner = (d2){0.0, 0.0};
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                d2 mab = sG[si * PB + b];
+                if (b == si) mab[1] = 0.0;
+                cfma(inner, mab, sT[b * PB + sj]);
+            }
+            sMT[si * PB + sj] = inner;
+            asm volatile("" ::: "memory");
+            d2 sacc = (d2){0.0, 0.0};
+#pragma unroll
+            for (int a = 0; a < PB; ++a) cfmac(sacc, sMT[a * PB + sj], sT[a * PB + si]);
+            sS[tid] = sacc;
+        }
+        wg_sync();
+        d2 tb[4], sb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tb[k] = sT[16 * k + lane15];
+            sb[k] = sS[16 * k + lane15];
+        }
+        for (int q = wave; lo + 64 * q < n; q += NW) {
+            const int i_row = lo + 64 * q + lane;
+            const bool qr = i_row >= s && i_row < n;
+            const int ic = min(i_row, npad - 1);
+            d2 xr[PB], vr[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                xr[c] = qr ? XY[(size_t)ic * PB + c] : (d2){0.0, 0.0};
+                vr[c] = qr ? VN[(size_t)ic * PB + c] : (d2){0.0, 0.0};
+            }
+            d2 xt[PB], vs[PB];
+            static_for<0, PB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                d2 a1 = (d2){0.0, 0.0};
+                static_for<0, c + 1>([&](auto c2c) {
+                    constexpr int c2 = decltype(c2c)::value;
+                    cfma_bc<8 * (c2 & 1) + c>(a1, xr[c2], tb[c2 >> 1]);  // T[c2][c]
+                });
+                xt[c] = a1;
+                d2 a2 = (d2){0.0, 0.0};
+                static_for<0, PB>([&](auto c2c) {
+                    constexpr int c2 = decltype(c2c)::value;
+                    cfma_bc<8 * (c2 & 1) + c>(a2, vr[c2], sb[c2 >> 1]);  // S[c2][c]
+                });
+                vs[c] = a2;
+            });
+            if (qr) {
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    VW[vw_index(i_row, c)] = vr[c];
+                    VW[vw_index(i_row, PB + c)] = (d2){xt[c][0] - 0.5 * vs[c][0], xt[c][1] - 0.5 * vs[c][1]};
+                }
+            }
+        }
+        wg_sync();
+    }
+
+    const int g0 = PB * p, s = g0 + PB, m = n - s;
+    if (m < 2) return;  // (behind the last panel: only its W phase)
+    const bool have_update = p > 0;
+    const int lo = g0 & ~(TS - 1);  // first row of the row chunks of this panel: wave w has the rows lo + 64 q + lane, q = w, w + NW, ...
+
+    // ---- look-ahead: block row p brought up to date with the pending (V, W); the panel's rows y = conj(x) go to XY ----
+    {
+        d2 pend[PB];
+#pragma unroll
+        for (int r = 0; r < PB; ++r) pend[r] = have_update ? VW[vw_index(g0 + r, lane15)] : (d2){0.0, 0.0};
+        for (int q = wave; lo + 64 * q < npad; q += NW) {
+            const int i_row = lo + 64 * q + lane;
+            const bool in_rows = i_row >= g0 && i_row < n;
+            const int ic = min(max(i_row, g0), n - 1);
+            d2 x[PB];
+#pragma unroll
+            for (int r = 0; r < PB; ++r) {
+                const int g = g0 + r;
+                const bool upper = ic >= g;
+                const d2 v = *Hat(upper ? g : ic, upper ? ic : g);
+                x[r] = in_rows ? (upper ? v : conjd(v)) : (d2){0.0, 0.0};
+            }
+            if (have_update && __any(in_rows)) {
+                d2 vw[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) vw[c] = VW[vw_index(ic, c)];
+                static_for<0, PB>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    static_for<0, PB>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        cfnmac_bc<t>(x[r], pend[r], vw[PB + t]);       // - V[g][t] conj(W[i][t])
+                        cfnmac_bc<PB + t>(x[r], pend[r], vw[t]);       // - W[g][t] conj(V[i][t])
+                    });
+                });
+            }
+            if (in_rows && i_row < s) {
+#pragma unroll
+                for (int r = 0; r < PB; ++r)
+                    if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[r];
+            }
+            if (i_row < npad) {
+                const bool below = in_rows && i_row >= s;
+#pragma unroll
+                for (int c = 0; c < PB; ++c) XY[(size_t)i_row * PB + c] = below ? conjd(x[c]) : (d2){0.0, 0.0};
+            }
+        }
+    }
+    if (tid < PB) sTau[tid] = (d2){0.0, 0.0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows of the panel are in memory: its sums below read them
+
+    // ---- panel QR: all reflectors of a round from ONE Gram matrix (model: panel_qr_gram) ----
+    {
+        const int last = min(PB, m - 1);
+        int c0 = 0;
+        while (c0 < last) {
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int q = wave; lo + 64 * q < n; q += NW) {
+                if (lo + 64 * q + 64 <= s + c0) continue;  // wave-uniform
+                gram_direct(XY, XY, lo + 64 * q, s + c0, acc);
+            }
+            gram_finish(acc);
+            if (c0 == 0 && have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
+            d2 top[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) top[c] = (c >= c0 && c < m) ? XY[(size_t)min(s + c, npad - 1) * PB + t8] : (d2){0.0, 0.0};
+            d2 g_next = sG[min(c0, PB - 1) * PB + t8];
+            bool stopped = false;
+            int c1 = last;
+            unsigned has_mask = 0;
+            static_for<0, PB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (c >= c0 && c < last && !stopped) {  // uniform
+                    const d2 g_row = g_next;
+                    g_next = sG[min(c + 1, PB - 1) * PB + t8];
+                    d2 g = g_row;
+                    static_for<0, c>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        cfnmacj_bc<c>(g, top[i], top[i]);
+                    });
+                    const double gcc = lane_value<c>(g[0]);
+                    const double Gcc = lane_value<c>(g_row[0]);
+                    if (c > c0 && !(gcc >= GRAM_THRESH * Gcc)) {
+                        stopped = true;
+                        c1 = c;
+                    } else {
+                        const d2 alpha = (d2){lane_value<c>(top[c][0]), lane_value<c>(top[c][1])};
+                        const d2 rowv = top[c];
+                        const double sigma = gcc - (alpha[0] * alpha[0] + alpha[1] * alpha[1]);
+                        if (!(gcc == 0.0 || (sigma == 0.0 && alpha[1] == 0.0))) {  // uniform
+                            double root, rroot;
+                            fast_sqrt_rsqrt(gcc, root, rroot);
+                            const double beta = -copysign(root, alpha[0]);
+                            const double rbeta = -copysign(rroot, alpha[0]);
+                            const d2 tau_c = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                            if (tid == 0) sTau[c] = tau_c;
+                            const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+                            const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+                            const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+                            d2 tz = g;
+                            cfnmac(tz, rowv, alpha);
+                            d2 z = cmulc(tz, scale);
+                            z[0] += rowv[0];
+                            z[1] += rowv[1];
+                            d2 f = cmul(conjd(tau_c), z);
+                            if (t8 <= c) f = (d2){0.0, 0.0};
+                            top[c] = t8 > c ? (d2){rowv[0] - f[0], rowv[1] - f[1]} : (t8 == c ? (d2){beta, 0.0} : (d2){0.0, 0.0});
+                            static_for<c + 1, PB>([&](auto ic) {
+                                constexpr int i = decltype(ic)::value;
+                                d2 vt = (d2){0.0, 0.0};
+                                cfma_bc<c>(vt, scale, top[i]);
+                                cfma(top[i], (d2){-vt[0], -vt[1]}, f);
+                            });
+                            sF[c * PB + t8] = f;
+                            sCo[c] = scale;
+                            sCo[PB + c] = (d2){beta, 0.0};
+                            has_mask |= 1u << c;
+                        }
+                    }
+                }
+            });
+            // the rows, one at a time through the registers
+            for (int q = wave; lo + 64 * q < npad; q += NW) {
+                const int i_row = lo + 64 * q + lane;
+                const bool in_mat = i_row < npad;
+                const bool qr = i_row >= s && i_row < n;
+                const int ic = min(i_row, npad - 1);
+                d2 yr[PB], vrow[PB];
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    yr[c] = XY[(size_t)ic * PB + c];
+                    vrow[c] = (d2){0.0, 0.0};
+                }
+                static_for<0, PB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if (c >= c0 && c < c1 && (has_mask >> c & 1u)) {  // uniform
+                        const bool below = qr && i_row >= s + c;
+                        const bool head = i_row == s + c;
+                        const d2 f_c = sF[c * PB + t8];
+                        const d2 sc_c = sCo[c];
+                        const double beta_c = sCo[PB + c][0];
+                        d2 v = cmul(yr[c], sc_c);
+                        v = below ? (head ? (d2){1.0, 0.0} : v) : (d2){0.0, 0.0};
+                        vrow[c] = v;
+                        static_for<c + 1, PB>([&](auto cpc) {
+                            constexpr int cp = decltype(cpc)::value;
+                            cfnma_bc<cp>(yr[cp], v, f_c);
+                        });
+                        if (below) yr[c] = head ? (d2){beta_c, 0.0} : (d2){0.0, 0.0};
+                    }
+                });
+                if (qr && i_row - s < PB && ((i_row - s >= c0 && i_row - s < c1) || (c1 >= last && i_row - s >= last))) {
+                    const int c = i_row - s;
+#pragma unroll
+                    for (int r = 0; r < PB; ++r) *Hat(g0 + r, i_row) = (r >= c) ? conjd(yr[r]) : (d2){0.0, 0.0};
+                }
+                if (in_mat) {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        if (c >= c0 && c < c1) {
+                            XY[(size_t)i_row * PB + c] = vrow[c];
+                            VN[(size_t)i_row * PB + c] = vrow[c];
+                        } else if (c >= c1) {
+                            XY[(size_t)i_row * PB + c] = c1 < last ? yr[c] : (d2){0.0, 0.0};
+                            if (c1 >= last) VN[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
+                        }
+                    }
+                }
+            }
+            c0 = c1;
+            if (c0 < last) wg_sync();
+        }
+    }
+    // ---- T of the compact WY form from G = V^H V ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's rows of V)
+    {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int q = wave; lo + 64 * q < n; q += NW) {
+            if (lo + 64 * q + 64 <= s) continue;  // wave-uniform
+            gram_direct(VN, VN, lo + 64 * q, s, acc);
+        }
+        gram_finish(acc);
+        if (tid < PB) {
+            const int a = tid;
+            d2 gm[28], tauv[PB], trow[PB];
+            static_for<1, PB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                static_for<0, c>([&](auto c2c) {
+                    constexpr int c2 = decltype(c2c)::value;
+                    gm[c * (c - 1) / 2 + c2] = sG[c2 * PB + c];
+                });
+            });
+#pragma unroll
+            for (int c = 0; c < PB; ++c) tauv[c] = sTau[c];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                d2 tacc = (d2){0.0, 0.0};
+#pragma unroll
+                for (int c2 = 0; c2 < c; ++c2)
+                    if (c2 >= a) cfma(tacc, trow[c2], gm[c * (c - 1) / 2 + c2]);
+                const d2 t = cmul(tauv[c], tacc);
+                trow[c] = (c == a) ? tauv[c] : (c > a ? (d2){-t[0], -t[1]} : (d2){0.0, 0.0});
+            }
+#pragma unroll
+            for (int c = 0; c < PB; ++c) gT[a * PB + c] = trow[c];
+        }
+    }
+}
+
+// tile(I, J) -= [V | W]_I ([W | V]_J)^H for the block row I = i0 + blockIdx.x, J = I .. nbk - 1 (the waves take every NW-th tile)
+template <int NT>
+__global__ void __launch_bounds__(NT, 2)
+band_xl_update_kernel(double* __restrict__ Hall, int n, const d2* __restrict__ VWall, int i0) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbk = (n + TS - 1) / TS;
+    const size_t mat = blockIdx.y;
+    double* H = Hall + mat * (size_t)n * n * 2;
+    const d2* VW = VWall + mat * (size_t)nbk * 256;
+    const int I = i0 + (int)blockIdx.x;
+    const int lrow = lane & 15, lq = lane >> 4;
+    Frag own;
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+        const d2 v2 = VW[((size_t)I * 4 + sg) * 64 + lane];
+        own.re[sg] = v2[0];
+        own.im[sg] = v2[1];
+    }
+    for (int J = I + wave; J < nbk; J += NW) {
+        Frag par;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const d2 v2 = VW[((size_t)J * 4 + sg) * 64 + lane];
+            par.re[sg] = v2[0];
+            par.im[sg] = v2[1];
+        }
+        const bool interior = (I + 1) * TS <= n && (J + 1) * TS <= n;
+        const unsigned gc = (unsigned)min(J * TS + lrow, n - 1);
+        d4 tre, tim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned gr = (unsigned)min(I * TS + lq + 4 * r, n - 1);
+            const d2 v2 = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(H) + (size_t)gr * (size_t)n * 16 + (size_t)gc * 16);
+            const bool inside = interior || (I * TS + lq + 4 * r < n && J * TS + lrow < n);
+            tre[r] = inside ? v2[0] : 0.0;
+            tim[r] = inside ? v2[1] : 0.0;
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const int sb = (sg + 2) & 3;
+            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], par.re[sb], tre, 0, 0, 1);  // -ar br
+            tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], par.im[sb], tre, 0, 0, 1);  // -ai bi
+            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], par.re[sb], tim, 0, 0, 1);  // -ai br
+            tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], par.im[sb], tim, 0, 0, 0);  // +ar bi
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = I * TS + lq + 4 * r;
+            if (interior || (gr < n && J * TS + lrow < n))
+                *reinterpret_cast<d2*>(reinterpret_cast<char*>(H) + (size_t)gr * (size_t)n * 16 + (size_t)(J * TS + lrow) * 16) = (d2){tre[r], tim[r]};
+        }
+    }
+}
+
+// X_I = sum_J tile(I, J) Vn_J over J = i0 .. nbk - 1 for the block row I = i0 + blockIdx.x: the tiles right of the diagonal
+// as stored, those left of it as the transposed stored ones, the diagonal tile completed from its upper part.  The waves
+// take every NW-th tile and add their partial blocks in wave order.
+template <int NT>
+__global__ void __launch_bounds__(NT, 2)
+band_xl_product_kernel(const double* __restrict__ Hall, int n, const d2* __restrict__ VNall, d2* __restrict__ XYall, int i0) {
+    constexpr int NW = NT / 64;
+    __shared__ double sTr[NW * 16 * 17];
+    __shared__ double sRed[NW * 4 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const size_t mat = blockIdx.y;
+    const double* H = Hall + mat * (size_t)n * n * 2;
+    const double* VNd = reinterpret_cast<const double*>(VNall + mat * (size_t)npad * PB);
+    double* XYd = reinterpret_cast<double*>(XYall + mat * (size_t)npad * PB);
+    const int I = i0 + (int)blockIdx.x;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int lane_x = lq * 16 + 2 * (lrow & 7) + (lrow >> 3);
+    const double lane_sgn = (lrow < 8) ? -1.0 : 1.0;
+    double* tr = sTr + wave * (16 * 17);
+    d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = own1;
+    for (int J = i0 + wave; J < nbk; J += NW) {
+        const int Ir = min(I, J), Jc = max(I, J);
+        const bool interior = (Ir + 1) * TS <= n && (Jc + 1) * TS <= n;
+        const unsigned gc = (unsigned)min(Jc * TS + lrow, n - 1);
+        d4 tre, tim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned gr = (unsigned)min(Ir * TS + lq + 4 * r, n - 1);
+            const d2 v2 = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(H) + (size_t)gr * (size_t)n * 16 + (size_t)gc * 16);
+            const bool inside = interior || (Ir * TS + lq + 4 * r < n && Jc * TS + lrow < n);
+            tre[r] = inside ? v2[0] : 0.0;
+            tim[r] = inside ? v2[1] : 0.0;
+        }
+        double pb[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) pb[sg] = (VNd + (size_t)J * (TS * 16) + lane_x)[sg * 64];
+        if (J >= I) {
+            // the own block is the row block of the stored tile: the operand is the transposed copy [lrow][lq + 4 sg]
+            double ttre[4], ttim[4];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tre[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) ttre[sg] = tr[lrow * 17 + lq + 4 * sg];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tim[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
+            asm volatile("" ::: "memory");
+            if (J == I) {  // Hermitian tile of which only the upper part is valid
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const bool upper = lrow <= lq + 4 * sg;
+                    const double ar = upper ? ttre[sg] : tre[sg];
+                    const double ai = upper ? ttim[sg] : -tim[sg];
+                    own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, pb[sg], own1, 0, 0, 0);
+                    own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, pb[sg], own2, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], pb[sg], own1, 0, 0, 0);
+                    own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], pb[sg], own2, 0, 0, 0);
+                }
+            }
+        } else {
+            // the own block is the column block: X_I += tile^H Vn_J, the stored tile is the operand as it is (conjugated)
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], pb[sg], own1, 0, 0, 0);
+                own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], pb[sg], own2, 0, 0, 1);  // conj
+            }
+        }
+    }
+    // lane (row lq + 4 r, c = lrow): Re X[row][c] (c < 8) or Im X[row][c - 8]; the waves' partial blocks in wave order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[(wave * 4 + r) * 64 + lane] = fma(dpp_mov<0x128>(own2[r]), lane_sgn, own1[r]);
+    lds_fence();
+    __syncthreads();
+    for (int r = wave; r < 4; r += NW) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += sRed[(w * 4 + r) * 64 + lane];
+        (XYd + (size_t)I * (TS * 16) + lane_x)[r * 64] = tot;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1896,7 +2407,17 @@ __global__ void __launch_bounds__(256) band_extract_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 // per matrix: the pending [V | W] rows in fragment order (16 complex per row) + the next panel's V (8 complex per row; used
 // when it does not live in LDS)
-size_t tbk_band_scratch_per_matrix(int n) { return (size_t)((n + TS - 1) / TS) * (256 + TS * PB) * sizeof(d2); }
+// the sizes that take the launch chain of band_xl_*: above 1024 orbitals (TBK_BAND_XL_FROM=n: above n -- tests run the chain
+// at sizes the NumPy model is quick at, and A/B it against the one-workgroup kernels)
+static bool band_xl(int n) {
+    static const int from = getenv("TBK_BAND_XL_FROM") ? atoi(getenv("TBK_BAND_XL_FROM")) : 1024;
+    return n > from;
+}
+// (+ for the launch chain of band_xl_*: X / the panel's rows [npad][8] and T of the panel)
+size_t tbk_band_scratch_per_matrix(int n) {
+    const size_t nbk = (size_t)((n + TS - 1) / TS);
+    return (nbk * (256 + TS * PB) + (band_xl(n) ? nbk * TS * PB + 64 : 0)) * sizeof(d2);
+}
 
 static int chase_pitch(int n) {
     // TBK_CHASE_PITCH=r (measurements): pitch = r mod 16.  Bank model of the four-sweeps-per-wave layout (DESIGN_LOG R4.2): 148 LDS
@@ -1908,7 +2429,15 @@ static int chase_pitch(int n) {
 }
 
 bool tbk_band_fused(int n);
-constexpr int BAND_MAXN = 1024;  // two rows per thread of 512 threads; X (8 complex per row) is 128 KiB of LDS there
+constexpr int BAND_ONE_WG_MAXN = 1024;  // one workgroup per matrix: two rows per thread of 512 threads, X (8 complex per row) is 128 KiB of LDS
+// above: every panel as three launches with nothing per row in registers or LDS (band_xl_*).  The limit is what has been
+// validated (tests/test_gpu_parity.py: 1030 / 1536 / 2048); nothing in the kernels depends on it.  TBK_BAND_XL=0: rocSOLVER above
+// 1024 orbitals, as until round 4 (measurements).
+static int band_maxn() {
+    static const bool xl = getenv("TBK_BAND_XL") && atoi(getenv("TBK_BAND_XL")) != 0;  // (off until validated on the GPU)
+    return xl ? 2048 : BAND_ONE_WG_MAXN;
+}
+#define BAND_MAXN band_maxn()
 constexpr int BAND_LDS_CHASE_MAXN = 512;  // above: the chase keeps its 16 diagonals in global memory
 // TBK_CHASE_GLOBAL=1 (measurements): the global-memory chase at every size that runs it as its own launch -- 9 KiB of LDS
 // and 158 registers per wave instead of 133 KiB at 512 orbitals, so its workgroups fit beside those of other kernels
@@ -1928,6 +2457,7 @@ static bool chase_global(int n) {
 // forces one (measurements).
 bool tbk_band_fused(int n) {
     static const int forced = getenv("TBK_BAND_FUSE") ? atoi(getenv("TBK_BAND_FUSE")) : -1;
+    if (band_xl(n)) return false;  // (the launch chain ends in the band's way out; the second stage is a launch of its own)
     return forced >= 0 ? forced != 0 : n <= 256;
 }
 
@@ -1957,7 +2487,7 @@ bool tbk_band_split(const tbk_model* m, int64_t nk) {
     static const bool on = !(getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 0);
     static const int64_t forced_limit = getenv("TBK_BAND_SPLIT_MAX") ? atoll(getenv("TBK_BAND_SPLIT_MAX")) : 0;
     const int n = m->n_orb;
-    if (!on || n <= 128 || n > BAND_MAXN) return false;
+    if (!on || n <= 128 || n > BAND_ONE_WG_MAXN || band_xl(n)) return false;
     // as long as every member workgroup of every matrix finds a CU of its own: n_cu / members matrices (on 256 CUs: 64 up to
     // 512 orbitals, 32 at 1024).  Measured (one k-point per call, reduction stage): 256 orbitals 2.11 -> 2.04 ms, 384: 4.62 -> 3.80, 512: 8.31 ->
     // 6.01, 1024: 49.0 -> 24.4
@@ -1994,12 +2524,42 @@ static int launch_split(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t
     return TBK_OK;
 }
 
+// The first stage above 1024 orbitals: three launches per panel (serial phases / update sweep / product sweep), one more update
+// sweep for the last pending update, then the band's way out.
+static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t nk, d2* d_scratch, d2* d_band) {
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    d2* d_VW = d_scratch;
+    d2* d_VN = d_VW + (size_t)nk * nbk * 256;
+    d2* d_XY = d_VN + (size_t)nk * npad * PB;
+    d2* d_T = d_XY + (size_t)nk * npad * PB;
+    const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
+    int p_end = 0;  // first panel without a trailing matrix behind it
+    while (n - PB * (p_end + 1) >= 2) ++p_end;
+    constexpr int NTS = 512, NTP = 256;
+    for (int p = 0; p <= p_end; ++p) {
+        hipLaunchKernelGGL((band_xl_serial_kernel<NTS>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p);
+        if (p == p_end) break;
+        const int i0 = PB * (p + 1) / TS, na = nbk - i0;
+        if (p > 0)
+            hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VW, i0);
+        hipLaunchKernelGGL((band_xl_product_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VN, d_XY, i0);
+    }
+    if (p_end > 0) {  // the last pending update (no look-ahead consumed any of its rows)
+        const int i0 = PB * p_end / TS;
+        hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)(nbk - i0), (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VW, i0);
+    }
+    hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)nk), dim3(256), 0, s, d_H, n, d_band, stride);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
 // Stage one: the upper triangle of every d_H matrix is overwritten; d_vw: scratch of tbk_band_scratch_per_matrix(n)
 // bytes per matrix; d_band receives the band, tbk_band_bytes_per_matrix(n) bytes per matrix.
 int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band, double* d_de_fused) {
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_EIG, s);
+    if (band_xl(n)) return launch_band_xl(m, s, d_H, n, nk, static_cast<d2*>(d_vw), static_cast<d2*>(d_band));
     const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
     // up to 256 orbitals a row per thread, V and X in LDS; above, TWO rows per thread and V in global memory, so that two
     // workgroups still fit a CU (76 KiB each at 512 orbitals) -- with 512 threads / V in LDS only one did and nothing

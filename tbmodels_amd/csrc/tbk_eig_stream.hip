@@ -515,15 +515,15 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const size_t mat = blockIdx.x;
     double lo_g = 1e300, hi_g = -1e300;
     int bad = 0;
-    double d = 0.0, e = 0.0;
-    if (tid < n) {
-        d = D[mat * n + tid];
-        e = (tid < n - 1) ? E[mat * n + tid] : 0.0;
-        const double em = (tid > 0) ? E[mat * n + tid - 1] : 0.0;
+    // (round 5: above 1024 orbitals a thread holds more than one row of (d, e) and gridDim.y workgroups share the eigenvalues)
+    for (int i = tid; i < n; i += (int)blockDim.x) {
+        const double d = D[mat * n + i];
+        const double e = (i < n - 1) ? E[mat * n + i] : 0.0;
+        const double em = (i > 0) ? E[mat * n + i - 1] : 0.0;
         const double rad = fabs(e) + fabs(em);  // Gershgorin disc
-        lo_g = d - rad;
-        hi_g = d + rad;
-        bad = !(isfinite(d) && isfinite(e));
+        lo_g = fmin(lo_g, d - rad);
+        hi_g = fmax(hi_g, d + rad);
+        bad |= !(isfinite(d) && isfinite(e));
     }
     lo_g = wave_min(lo_g);
     hi_g = wave_max(hi_g);
@@ -534,8 +534,10 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     // NaN / Inf anywhere in H(k) reaches (d, e); fmin / fmax and the sign tests below would quietly drop it.
     // The caller maps non-finite eigenvalues to the ValueError of scipy's check_finite (_tb_model.py:1147-1150).
     if (__syncthreads_or(bad)) {
-        if (tid < n) out[mat * n + tid] = __builtin_nan("");
-        if (tid == 0) atomicAdd(flags + 1, 1);  // flags[1]: non-finite input (tbk_eigenval_check -> TBK_ERR_NOT_FINITE)
+        if (blockIdx.y == 0) {
+            for (int i = tid; i < n; i += (int)blockDim.x) out[mat * n + i] = __builtin_nan("");
+            if (tid == 0) atomicAdd(flags + 1, 1);  // flags[1]: non-finite input (tbk_eigenval_check -> TBK_ERR_NOT_FINITE)
+        }
         return;
     }
     double gl = sred[0][0], gu = sred[1][0];
@@ -550,11 +552,13 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     // followed by -e_i^2 p_{i-1} != 0; the perturbation of the spectrum is below 1e-30 of its scale.
     const double scale_raw = fmax(fabs(gl), fabs(gu));
     const int sc_exp = (scale_raw > 0.0) ? -ilogb(scale_raw) : 0;
-    if (tid < n) {
+    for (int i = tid; i < n; i += (int)blockDim.x) {
+        const double d = D[mat * n + i];
+        const double e = (i < n - 1) ? E[mat * n + i] : 0.0;
         const double es = ldexp(e, sc_exp);
-        sde[2 * tid] = ldexp(d, sc_exp);
-        if (tid + 1 < n) sde[2 * (tid + 1) + 1] = fmax(es * es, 1e-60);
-        if (tid == 0) sde[1] = 0.0;
+        sde[2 * i] = ldexp(d, sc_exp);
+        if (i + 1 < n) sde[2 * (i + 1) + 1] = fmax(es * es, 1e-60);
+        if (i == 0) sde[1] = 0.0;
     }
     __syncthreads();
     gl = ldexp(gl, sc_exp);
@@ -652,7 +656,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
         int* scnt = reinterpret_cast<int*>(sde + 2 * n_pad);
         const double width = hi - lo;
         const double step_w = width / (n + 1);
-        if (tid < n) scnt[tid] = sturm_count(lo + (tid + 1) * step_w);
+        for (int t = tid; t < n; t += (int)blockDim.x) scnt[t] = sturm_count(lo + (t + 1) * step_w);
         __syncthreads();
         // smallest point index t with count(x_t) > m: the m-th eigenvalue lies in (x_{t-1}, x_t]
         int first = 0, len = n;  // binary search over t in [0, n): first t with scnt[t] > m, n if none
@@ -850,6 +854,11 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     if (lpe > 1)
         while (parts < 4 && (threads / (parts * 2)) % 64 == 0 && threads / (parts * 2) >= (unsigned)n_pad && n % (int)(parts * 2) == 0) parts *= 2;
     threads /= parts;
+    if (threads > 1024) {  // above 1024 orbitals (one lane per eigenvalue there): the eigenvalues in `parts` workgroups of <= 1024 lanes
+        parts = (threads + 1023) / 1024;
+        const unsigned per = ((unsigned)n + parts - 1) / parts;  // eigenvalues per workgroup (the kernel's m_per)
+        threads = (per * (unsigned)lpe + 63) / 64 * 64;
+    }
 #define TBK_BISECT(L) \
     hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk, parts), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
     switch (lpe) {

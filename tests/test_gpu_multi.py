@@ -378,7 +378,8 @@ def test_bench_strong_scaling_leg_with_a_one_rank_communicator():
     """The cfg4 leg of ``bench.py --gpus N`` (the 100^3 mesh in N slabs through ``tbk_eigenval_device_gather``, the gather
     inside its timing) with a one-rank communicator: its entry sits under ``configs``, its checks (oracle rows of the first
     and the last slab, trace identity on 4096 rows of the whole mesh) hold, the gather adds next to nothing at one rank.
-    And the safety net: a leg that does not come back within its time limit must not take the main line with it."""
+    And the safety net: a leg that does not come back within its time limit must not take the main line with it -- the line is
+    printed with "strong_scaling": "timeout" and the process ends with status 3."""
     env = {"TBK_BENCH_FORCE_COMM": "1", "TBK_BENCH_STRONG": "1"}
     done = _bench(["--gpus", "1", "--steps", "2"], env)
     assert done.returncode == 0, done.stderr.decode()[-2000:]
@@ -391,12 +392,16 @@ def test_bench_strong_scaling_leg_with_a_one_rank_communicator():
     assert leg["max_abs_err_vs_oracle"] <= TOL and leg["max_trace_identity_err_4096_rows"] <= TOL
     assert leg["value"] > 0.5 * 10 ** 6  # the folded path (a direct evaluation of the mesh runs at ~0.95 M k-points/s)
     assert abs(leg["per_rank"]["exposed_gather_ms"][0]) < 0.1 * leg["per_rank"]["compute_ms"][0]
+    assert line["strong_scaling"] == "ok"
+    # (round 5: the line is still printed, with a top-level verdict, and the STATUS tells the launcher -- the process exits, it is
+    # never re-executed)
     done = _bench(["--gpus", "1", "--steps", "2"], dict(env, TBK_BENCH_STRONG_TIMEOUT="0.01"))
-    assert done.returncode == 0, done.stderr.decode()[-2000:]
+    assert done.returncode == 3, done.stderr.decode()[-2000:]
     lines = [ln for ln in done.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["value"] > 0 and "did not finish" in line["configs"]["cfg4_one_rank_communicator"]["error"]
+    assert line["strong_scaling"] == "timeout"
 
 
 def test_bench_starts_its_own_ranks_and_fails_for_rccl_reasons_on_one_gpu():

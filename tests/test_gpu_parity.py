@@ -553,7 +553,7 @@ def _onsite_model(mat):
 @pytest.mark.parametrize("solver", ["auto", "rocsolver"])
 @pytest.mark.parametrize(
     "n", [1, 2, 3, 8, 9, 12, 13, 16, 17, 32, 33, 40, 48, 49, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 200, 256, 257, 300, 384, 385, 512,
-          513, 520, 768, 1000, 1024, 1030]
+          513, 520, 768, 1000, 1024, 1030, 1536, 2048, 2050]
 )
 def test_eigensolver_structured_matrices(solver, n):
     """
@@ -566,7 +566,7 @@ def test_eigensolver_structured_matrices(solver, n):
     if solver == "rocsolver" and n > 64 and n not in (65, 128, 256, 520):
         pytest.skip("rocSOLVER path sampled at a few sizes only (slow)")
     if solver == "rocsolver" and n > 1024:
-        pytest.skip("above 1024 orbitals 'auto' is the rocSOLVER path already")
+        pytest.skip("rocSOLVER path sampled at a few sizes only (slow); above 2048 orbitals 'auto' is that path")
 
     rng = np.random.default_rng(100 + n)
     rand = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
@@ -628,7 +628,7 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
-@pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512, 513, 700, 1024])
+@pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512, 513, 700, 1024, 1030, 1300])
 def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     """``tbk_tridiagonal_reduce``: the reduction stage of the eigensolver alone (scipy's eigvalsh at _tb_model.py:1149 is
     this plus the tridiagonal stage) on random Hermitian batches whose lower triangle is poisoned with NaN -- only the
@@ -647,7 +647,7 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
 
     lib = _lib.lib()
     rng = np.random.default_rng(1000 + n)
-    nk = 9 if n <= 512 else 5
+    nk = 9 if n <= 512 else 5  # (above 1024 orbitals: the launch chain of band_xl_*, round 5)
     m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
     h = (m + m.conj().transpose(0, 2, 1)) / 2
     h[1] *= 1e-30  # no absolute thresholds
@@ -689,10 +689,68 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
             ref = np.linalg.eigvalsh(h[i])
             got = la.eigvalsh_tridiagonal(d2[i], e2[i, :-1]) if n > 1 else d2[i]
             assert np.abs(got - ref).max() <= 1e-13 * n * np.abs(ref).max(), (other, i)
-    bad = lib.tbk_tridiagonal_reduce(0, 1025, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
+    bad = lib.tbk_tridiagonal_reduce(0, 2049, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
     assert bad == _lib.TBK_ERR_ARGUMENT
     if n <= 64:
         assert lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(poisoned), 2, _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
+
+
+@pytest.mark.parametrize("n", [66, 97, 130, 200, 300])
+def test_launch_chain_above_1024_orbitals_equals_the_model_at_small_sizes(n):
+    """Above 1024 orbitals the first stage is a chain of launches with nothing per row in registers or LDS
+    (csrc/tbk_eig_band.hip, band_xl_*: serial phases / update sweep / product sweep per panel).  TBK_BAND_XL_FROM=64 (read
+    once per process) sends EVERY two-stage size down that chain: the band it leaves must equal the NumPy model of the
+    algorithm (tools/two_stage_model.py with the Gram-matrix panel QR) entry by entry, the tridiagonal behind the second
+    stage must have the matrix' spectrum, a batch with scaled / diagonal members included, and the chain is deterministic."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import scipy.linalg as la
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import two_stage_model as model
+
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from tbmodels_amd import _lib\n"
+        "n = %d; nk = 5; rng = np.random.default_rng(4000 + n)\n"
+        "m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))\n"
+        "h = (m + m.conj().transpose(0, 2, 1)) / 2\n"
+        "h[1] *= 1e-30; h[2] *= 1e30; h[3] = np.diag(np.diagonal(h[3]))\n"
+        "p = np.ascontiguousarray(h.copy()); il = np.tril_indices(n, -1); p[:, il[0], il[1]] = np.nan\n"
+        "d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(p)\n"
+        "lib = _lib.lib()\n"
+        "_lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(p), _lib.TBK_REDUCE_TWO_STAGE, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))\n"
+        "d2, e2 = np.empty_like(d), np.empty_like(e)\n"
+        "_lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(p), _lib.TBK_REDUCE_TWO_STAGE, _lib.ptr(d2), _lib.ptr(e2), None))\n"
+        "assert np.array_equal(d, d2) and np.array_equal(e, e2)\n"
+        "np.savez(sys.argv[1], h=h, d=d, e=e, red=red)\n" % (root, n)
+    )
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "xl.npz")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, TBK_BAND_XL_FROM="64"), timeout=600)
+        got = np.load(out)
+    h, d, e, red = got["h"], got["d"], got["e"], got["red"]
+    assert np.isfinite(d).all() and np.isfinite(e).all()
+    for i in range(len(h)):
+        ref = np.linalg.eigvalsh(h[i])
+        scale = np.abs(ref).max()
+        assert np.abs(la.eigvalsh_tridiagonal(d[i], e[i, :-1]) - ref).max() <= 1e-13 * n * scale, i
+        up = np.triu(red[i])
+        band = up - np.triu(up, model.B + 1)
+        hb = band + np.triu(band, 1).conj().T
+        assert np.abs(np.linalg.eigvalsh(hb) - ref).max() <= 1e-13 * n * scale, i
+    saved = model.panel_qr
+    model.panel_qr = model.panel_qr_gram
+    try:
+        mband, _ = model.stage1_band(h[0])
+    finally:
+        model.panel_qr = saved
+    gband = np.array([[red[0][r, r + dd] if r + dd < n else 0.0 for dd in range(model.B + 1)] for r in range(n)])
+    assert np.abs(gband - mband).max() < 1e-12 * n
 
 
 @pytest.mark.parametrize("n_orb", [200, 300, 520])
