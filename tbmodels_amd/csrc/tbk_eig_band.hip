@@ -2434,7 +2434,7 @@ constexpr int BAND_ONE_WG_MAXN = 1024;  // one workgroup per matrix: two rows pe
 // validated (tests/test_gpu_parity.py: 1030 / 1536 / 2048); nothing in the kernels depends on it.  TBK_BAND_XL=0: rocSOLVER above
 // 1024 orbitals, as until round 4 (measurements).
 static int band_maxn() {
-    static const bool xl = getenv("TBK_BAND_XL") && atoi(getenv("TBK_BAND_XL")) != 0;  // (off until validated on the GPU)
+    static const bool xl = !(getenv("TBK_BAND_XL") && atoi(getenv("TBK_BAND_XL")) == 0);
     return xl ? 2048 : BAND_ONE_WG_MAXN;
 }
 #define BAND_MAXN band_maxn()
