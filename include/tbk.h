@@ -59,7 +59,7 @@ typedef enum tbk_status {
 /* eigensolver selection for tbk_model_set_option(TBK_OPT_EIGENSOLVER, ...):
  *   WAVE      hand-written register-resident Householder reduction (n_orb <= 64 only) + tridiagonal stage
  *   ROCSOLVER rocsolver_zheevd_strided_batched
- *   AUTO      WAVE when n_orb <= 64; the own one- / two-stage Householder kernels up to n_orb = 2048 (above 1024 orbitals the
+ *   AUTO      WAVE when n_orb <= 64; the own one- / two-stage Householder kernels up to n_orb = 4096 (above 1024 orbitals the
  *             first stage is a chain of launches per panel, csrc/tbk_eig_band.hip band_xl_*); ROCSOLVER above.
  * Tridiagonal stage of the two hand-written paths: lane-per-matrix QL for large batches of n_orb <= 64,
  * bisection on Sturm counts otherwise (n_orb > 64, calls of <= max(4096, 768 n_orb) k-points, and the last
@@ -143,10 +143,10 @@ int tbk_synchronize(tbk_model* m);
 /* ---- the eigensolver's reduction stage alone (scipy.linalg.eigvalsh of _tb_model.py:1149 = this + the tridiagonal stage)
  * nk Hermitian matrices H[nk][n_orb][n_orb][2] (row-major; only the upper triangle i <= j is read) are reduced to real
  * symmetric tridiagonal form with the same eigenvalues: d[nk][n_orb] diagonals, e[nk][n_orb] off-diagonals (e[.][n-1] = 0).
- * n_orb <= 2048.  method: TBK_REDUCE_AUTO = what tbk_eigenval takes for this size (register-resident reduction up to 64
+ * n_orb <= 4096.  method: TBK_REDUCE_AUTO = what tbk_eigenval takes for this size (register-resident reduction up to 64
  * orbitals, one-stage reduction up to 188 -- in registers up to 128, streaming above -- two-stage reduction -- dense ->
- * band of half-width 8 on the matrix pipe, band -> tridiagonal by bulge chasing -- from 185 to 2048); _ONE_STAGE / _TWO_STAGE force one of them (one-stage:
- * n_orb <= 512 only; two-stage: 64 < n_orb <= 2048 only).  H_reduced (may be NULL) receives the work copy of the matrices as the reduction left it:
+ * band of half-width 8 on the matrix pipe, band -> tridiagonal by bulge chasing -- from 185 to 4096); _ONE_STAGE / _TWO_STAGE force one of them (one-stage:
+ * n_orb <= 512 only; two-stage: 64 < n_orb <= 4096 only).  H_reduced (may be NULL) receives the work copy of the matrices as the reduction left it:
  * after the two-stage reduction its upper triangle holds the band form of stage one.
  * Host buffers; synchronous.  For tests and for callers that bring their own matrices. */
 enum { TBK_REDUCE_AUTO = 0, TBK_REDUCE_ONE_STAGE = 1, TBK_REDUCE_TWO_STAGE = 2 };

@@ -1217,9 +1217,9 @@ extern "C" int tbk_tridiagonal_reduce(int device, int n_orb, int64_t nk, const d
                                       double* H_reduced) {
     TBK_ARG(nk >= 0, "nk < 0");
     TBK_ARG(n_orb >= 1 && (n_orb <= 64 || tbk_eig_stream_supported(n_orb)),
-            "n_orb must be in [1, 2048] (larger matrices go through rocSOLVER as a whole)");
+            "n_orb must be in [1, 4096] (larger matrices go through rocSOLVER as a whole)");
     TBK_ARG(method >= TBK_REDUCE_AUTO && method <= TBK_REDUCE_TWO_STAGE, "unknown reduction method");
-    TBK_ARG(method != TBK_REDUCE_TWO_STAGE || tbk_eig_band_supported(n_orb), "the two-stage reduction handles 64 < n_orb <= 2048");
+    TBK_ARG(method != TBK_REDUCE_TWO_STAGE || tbk_eig_band_supported(n_orb), "the two-stage reduction handles 64 < n_orb <= 4096");
     TBK_ARG(method != TBK_REDUCE_ONE_STAGE || n_orb <= 512, "the one-stage reduction handles n_orb <= 512");
     if (nk == 0) return TBK_OK;
     TBK_ARG(H && d && e, "H / d / e is NULL");
@@ -1270,7 +1270,7 @@ __global__ void __launch_bounds__(256) random_hermitian_kernel(double* __restric
 extern "C" int tbk_reduce_standalone(int device, int n_orb, int64_t nk, int reps, double* us_per_matrix) {
     TBK_ARG(us_per_matrix != nullptr, "us_per_matrix is NULL");
     TBK_ARG(nk >= 1 && reps >= 1, "nk / reps < 1");
-    TBK_ARG(n_orb >= 1 && (n_orb <= 64 || tbk_eig_stream_supported(n_orb)), "n_orb must be in [1, 2048]");
+    TBK_ARG(n_orb >= 1 && (n_orb <= 64 || tbk_eig_stream_supported(n_orb)), "n_orb must be in [1, 4096]");
     for (int q = 0; q < 3; ++q) us_per_matrix[q] = 0.0;
     tbk_model* m = nullptr;
     TBK_CHECK(create_common(device, 1, n_orb, 0, nullptr, 2, &m));

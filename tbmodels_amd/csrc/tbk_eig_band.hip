@@ -2431,11 +2431,11 @@ static int chase_pitch(int n) {
 bool tbk_band_fused(int n);
 constexpr int BAND_ONE_WG_MAXN = 1024;  // one workgroup per matrix: two rows per thread of 512 threads, X (8 complex per row) is 128 KiB of LDS
 // above: every panel as three launches with nothing per row in registers or LDS (band_xl_*).  The limit is what has been
-// validated (tests/test_gpu_parity.py: 1030 / 1536 / 2048); nothing in the kernels depends on it.  TBK_BAND_XL=0: rocSOLVER above
+// validated (tests/test_gpu_parity.py: 1030 / 1536 / 2048 / 2050 / 3000 / 4096); nothing in the kernels depends on it.  TBK_BAND_XL=0: rocSOLVER above
 // 1024 orbitals, as until round 4 (measurements).
 static int band_maxn() {
     static const bool xl = !(getenv("TBK_BAND_XL") && atoi(getenv("TBK_BAND_XL")) == 0);
-    return xl ? 2048 : BAND_ONE_WG_MAXN;
+    return xl ? 4096 : BAND_ONE_WG_MAXN;
 }
 #define BAND_MAXN band_maxn()
 constexpr int BAND_LDS_CHASE_MAXN = 512;  // above: the chase keeps its 16 diagonals in global memory

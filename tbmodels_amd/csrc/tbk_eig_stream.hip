@@ -859,6 +859,10 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
         const unsigned per = ((unsigned)n + parts - 1) / parts;  // eigenvalues per workgroup (the kernel's m_per)
         threads = (per * (unsigned)lpe + 63) / 64 * 64;
     }
+    if (lds > (size_t(64) << 10)) {  // (above ~3270 orbitals the (d, e^2) table and the shared round's counts pass 64 KiB; lpe is 1 there)
+        static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&tridiag_bisect_kernel<1>), 160 * 1024, raised));
+    }
 #define TBK_BISECT(L) \
     hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk, parts), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
     switch (lpe) {

@@ -566,7 +566,7 @@ def test_eigensolver_structured_matrices(solver, n):
     if solver == "rocsolver" and n > 64 and n not in (65, 128, 256, 520):
         pytest.skip("rocSOLVER path sampled at a few sizes only (slow)")
     if solver == "rocsolver" and n > 1024:
-        pytest.skip("rocSOLVER path sampled at a few sizes only (slow); above 2048 orbitals 'auto' is that path")
+        pytest.skip("rocSOLVER path sampled at a few sizes only (slow); above 4096 orbitals 'auto' is that path")
 
     rng = np.random.default_rng(100 + n)
     rand = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
@@ -689,10 +689,27 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
             ref = np.linalg.eigvalsh(h[i])
             got = la.eigvalsh_tridiagonal(d2[i], e2[i, :-1]) if n > 1 else d2[i]
             assert np.abs(got - ref).max() <= 1e-13 * n * np.abs(ref).max(), (other, i)
-    bad = lib.tbk_tridiagonal_reduce(0, 2049, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
+    bad = lib.tbk_tridiagonal_reduce(0, 4097, 1, _lib.ptr(poisoned), 0, _lib.ptr(d), _lib.ptr(e), None)
     assert bad == _lib.TBK_ERR_ARGUMENT
     if n <= 64:
         assert lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(poisoned), 2, _lib.ptr(d), _lib.ptr(e), None) == _lib.TBK_ERR_ARGUMENT
+
+
+@pytest.mark.parametrize("n", [3000, 4096])
+def test_largest_sizes_of_the_own_path(n):
+    """The launch chain above 1024 orbitals at the top of its validated range (the structured-matrix test stops at 2050: LAPACK
+    on the host needs ~10 - 30 s per matrix here): a random and a graded Hermitian matrix through ``eigenval`` against
+    numpy.linalg.eigvalsh, two k-points (the bisection's eigenvalues span three / four workgroups per matrix)."""
+    rng = np.random.default_rng(7000 + n)
+    rand = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    rand = (rand + rand.conj().T) / 2
+    graded = rand * np.outer(10.0 ** -np.arange(n) / (n // 8), np.ones(n))
+    for name, mat in (("random", rand), ("graded", (graded + graded.conj().T) / 2)):
+        model = _onsite_model(mat)
+        eig = np.array(model.eigenval([[0.1, 0.2, 0.3], [0.0, 0.0, 0.0]]))
+        ref = np.linalg.eigvalsh(mat)
+        assert np.abs(eig - ref[None]).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * n, name
+        assert np.array_equal(eig[0], eig[1])
 
 
 @pytest.mark.parametrize("n", [66, 97, 130, 200, 300])
