@@ -589,6 +589,13 @@ def test_eigensolver_structured_matrices(solver, n):
         cases["two_equal_blocks"] = blk
         proj = np.outer(rand[:, 0], rand[:, 0].conj())
         cases["rank_one"] = proj
+        # exactly dependent columns inside panels (round 5: the panel QR takes all reflectors of a round from ONE Gram matrix
+        # and must notice that a column's remaining norm has cancelled): every fourth row / column a copy of its neighbour
+        dup = rand.copy()
+        for q in range(1, n - 1, 4):
+            dup[q + 1, :] = dup[q, :]
+            dup[:, q + 1] = dup[:, q]
+        cases["duplicate_columns"] = (dup + dup.conj().T) / 2
     # (rocSOLVER's zheevd deflates against absolute thresholds -- on "tiny" its eigenvalues were 17 % off at n = 17 --
     # so tbk_eig_batched scales every matrix to unit size first, like LAPACK's zheev* do)
     code = {"auto": _lib.TBK_EIG_AUTO, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[solver]

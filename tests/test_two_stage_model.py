@@ -129,6 +129,11 @@ def test_gram_panel_qr_is_as_accurate_as_the_sequential_one_and_restarts_where_i
         "rank_one": (np.outer(rand[:, 0], rand[:, 0].conj()), True),
         "rank3_plus_1e-9": (low + 1e-9 * rand, True),
     }
+    dup = rand.copy()  # exactly dependent columns inside the first panels (every fourth row / column copies its neighbour)
+    for q in range(1, n - 1, 4):
+        dup[q + 1, :] = dup[q, :]
+        dup[:, q + 1] = dup[:, q]
+    cases["duplicate_columns"] = ((dup + dup.conj().T) / 2, True)
     worst_without = 0.0
     for name, (mat, restarts) in cases.items():
         sequential = _band_eig_error(mat, model.panel_qr)

@@ -36,7 +36,8 @@ NK_EDGES = [1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 500, 10
 
 
 def pick_case():
-    n = int(rng.choice([300, 383, 384, 385, 448, 449, 511, 512, 513, 520, 600, 700, 1000, 1024, 1025] if big else N_EDGES))
+    # (1025 - 1600: the launch chain of band_xl_*, round 5)
+    n = int(rng.choice([300, 383, 384, 385, 448, 449, 511, 512, 513, 520, 600, 700, 1000, 1024, 1025, 1040, 1200, 1600] if big else N_EDGES))
     dim = int(rng.choice([1, 2, 3, 3, 3, 4]))
     box = {1: 12, 2: 12, 3: 12, 4: 3}[dim]
     max_r = {1: 13, 2: 313, 3: 3000, 4: 1000}[dim]
