@@ -861,7 +861,8 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     }
     if (lds > (size_t(64) << 10)) {  // (above ~3270 orbitals the (d, e^2) table and the shared round's counts pass 64 KiB; lpe is 1 there)
         static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&tridiag_bisect_kernel<1>), 160 * 1024, raised));
+        // (96 KiB: 20 bytes per orbital up to 4096 orbitals; the kernel has static LDS beside it, so not the whole 160 KiB)
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&tridiag_bisect_kernel<1>), 96 * 1024, raised));
     }
 #define TBK_BISECT(L) \
     hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk, parts), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
