@@ -2632,14 +2632,20 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
         const int np = chase_pitch(n);
         // 32 sweeps in flight, two steps apart, from 512 orbitals on (a sweep is n / 8 >= 64 steps long); 16 below
         static const int env_nwg = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
-        const int nwg = env_nwg ? env_nwg : (n <= 256 ? 4 : 8);
+        // Calls of a few matrices (round 5): TWELVE waves = 48 sweeps in flight.  A sweep is n / 8 steps long and sweeps may
+        // start two ticks apart, so from 512 orbitals on the 32 slots of eight waves, not the stagger, bound the number of ticks
+        // -- and a tick is a global-memory round trip whatever the number of waves (three per SIMD at 152 registers).  The
+        // schedule keeps every dependence, so the results are the same bits.  By the size of the CALL.
+        const int nwg = env_nwg ? env_nwg : (n <= 256 ? 4 : (n > 640 && std::max<int64_t>(m->call_nk, nk) <= 64 ? 12 : 8));
         const size_t ldsg = (size_t)nwg * 64 * 16 + (size_t)n * sizeof(int) + 16;
         d2* d_b = static_cast<d2*>(const_cast<void*>(d_band));
         const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
         if (nwg <= 4)
             hipLaunchKernelGGL(band_chase4g_kernel<4>, dim3((unsigned)nk), dim3(256), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
-        else
+        else if (nwg <= 8)
             hipLaunchKernelGGL(band_chase4g_kernel<8>, dim3((unsigned)nk), dim3(512), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
+        else
+            hipLaunchKernelGGL(band_chase4g_kernel<12>, dim3((unsigned)nk), dim3(768), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
