@@ -283,7 +283,7 @@ def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
     eig_flops = 16.0 / 3.0 * n_orb ** 3
     eig_tf = eig_flops * matrices / (eig_ms * 1e-3) / 1e12
     hbm = None
-    if 128 < n_orb <= 512:
+    if 128 < n_orb <= 1024:
         # The two-stage reduction streams the stored triangle of the trailing matrix once per panel of 8 columns (read,
         # rank-16 update, store, product with the next panel's V in the same visit): by construction
         # 2 x 16 B x sum_p T(n - 8 (p + 1)) bytes per matrix, T(m) = m (m + 1) / 2 -- against 16 n^2 compulsory.  The [V | W] /
@@ -299,7 +299,8 @@ def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
         "kernel": ("herm_tridiag_packed_kernel" if n_orb <= 32 else
                    "herm_tridiag4_kernel (first n - 32 steps) + herm_tridiag_packed_kernel (trailing 32 x 32)" if n_orb <= 64 else
                    "herm_tridiag_stream_kernel" if n_orb <= 128 else
-                   "band_reduce_kernel (+ chase)" if n_orb <= 512 else "rocsolver zheevd"),
+                   "band_reduce_kernel (+ chase)" if n_orb <= 1024 else
+                   "band_xl_* launch chain (+ chase)" if n_orb <= 4096 else "rocsolver zheevd"),
         "bound": "valu-f64" if n_orb <= 128 else "mfma",
         "flops_per_matrix": eig_flops, "achieved": round(eig_tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": round(eig_tf / FP64_MFMA_PEAK_TFLOPS, 4),
