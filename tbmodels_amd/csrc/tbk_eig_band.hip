@@ -2632,11 +2632,10 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
         const int np = chase_pitch(n);
         // 32 sweeps in flight, two steps apart, from 512 orbitals on (a sweep is n / 8 >= 64 steps long); 16 below
         static const int env_nwg = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
-        // Calls of a few matrices (round 5): TWELVE waves = 48 sweeps in flight.  A sweep is n / 8 steps long and sweeps may
-        // start two ticks apart, so from 512 orbitals on the 32 slots of eight waves, not the stagger, bound the number of ticks
-        // -- and a tick is a global-memory round trip whatever the number of waves (three per SIMD at 152 registers).  The
-        // schedule keeps every dependence, so the results are the same bits.  By the size of the CALL.
-        const int nwg = env_nwg ? env_nwg : (n <= 256 ? 4 : (n > 640 && std::max<int64_t>(m->call_nk, nk) <= 64 ? 12 : 8));
+        // (TBK_CHASE_NW=12, round 5: twelve waves = 48 sweeps in flight for calls of a few matrices -- measured: one-k eigenval
+        // 13.88 -> 14.09 ms at 768 orbitals, 24.90 -> 25.17 at 1024, the same bits: the ticks' global-memory round trips, not the
+        // 32 slots, bound it.  Eight stay.)
+        const int nwg = env_nwg ? env_nwg : (n <= 256 ? 4 : 8);
         const size_t ldsg = (size_t)nwg * 64 * 16 + (size_t)n * sizeof(int) + 16;
         d2* d_b = static_cast<d2*>(const_cast<void*>(d_band));
         const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
