@@ -2416,7 +2416,7 @@ static bool band_xl(int n) {
 // (+ for the launch chain of band_xl_*: X / the panel's rows [npad][8] and T of the panel)
 size_t tbk_band_scratch_per_matrix(int n) {
     const size_t nbk = (size_t)((n + TS - 1) / TS);
-    return (nbk * (256 + TS * PB) + (band_xl(n) ? nbk * TS * PB + 64 : 0)) * sizeof(d2);
+    return (nbk * (256 + TS * PB) + nbk * TS * PB + 64) * sizeof(d2);  // (calls of a few matrices take that chain at every size)
 }
 
 static int chase_pitch(int n) {
@@ -2492,7 +2492,15 @@ bool tbk_band_split(const tbk_model* m, int64_t nk) {
     // 512 orbitals, 32 at 1024).  Measured (one k-point per call, reduction stage): 256 orbitals 2.11 -> 2.04 ms, 384: 4.62 -> 3.80, 512: 8.31 ->
     // 6.01, 1024: 49.0 -> 24.4
     // (up to 256 orbitals the serial launches dominate and 64 matrices in one launch are as fast: 2.49 vs 2.40 ms -- 8 there)
-    const int64_t limit = forced_limit > 0 ? forced_limit : (n <= 256 ? 8 : std::max(1, m->n_cu) / tbk_band_split_members(n, 8));
+    // Round 5: the chain these calls take is the one of band_xl_* (three launches per panel, sweeps on a workgroup per block row
+    // = every CU for ONE matrix; TBK_BAND_SPLIT=2: the round-4 chain, PHASE 1 / 2 of band_reduce_kernel with 4 - 8 member
+    // workgroups per matrix).  One-k eigenval, round-4 chain -> band_xl chain: 2.05 -> 1.94 ms at 256 orbitals, 3.99 -> 3.50 at 384,
+    // 6.05 -> 5.03 at 512, 13.98 -> 10.28 at 768, 24.35 -> 16.84 at 1024; 64 matrices: 2.23 -> 2.31 / 4.39 -> 4.43 / 6.80 -> 7.16 /
+    // 22.5 -> 17.6 / 46.3 -> 35.1 -- so up to 512 orbitals for calls of up to 16 matrices (8 up to 256), above for up to 96.
+    static const bool old_chain = getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 2;
+    const int64_t limit = forced_limit > 0 ? forced_limit
+                          : old_chain      ? (n <= 256 ? 8 : std::max(1, m->n_cu) / tbk_band_split_members(n, 8))
+                                           : (n <= 256 ? 8 : n <= 512 ? 16 : 96);
     return std::max<int64_t>(m->call_nk, nk) <= limit;
 }
 
@@ -2585,6 +2593,9 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
+    static const bool old_chain = getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 2;
+    if (d_de_fused == nullptr && tbk_band_split(m, nk) && !old_chain)
+        return launch_band_xl(m, s, d_H, n, nk, static_cast<d2*>(d_vw), static_cast<d2*>(d_band));
     if (d_de_fused == nullptr && tbk_band_split(m, nk)) {
         // the launch chain: one row per thread where the rows allow it (the serial phases are thread-per-row)
         auto lds_for = [&](int waves, int rows) { return band_xv_bytes(npad, false, waves, rows) + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16; };
