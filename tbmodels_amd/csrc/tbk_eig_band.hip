@@ -2496,11 +2496,12 @@ bool tbk_band_split(const tbk_model* m, int64_t nk) {
     // = every CU for ONE matrix; TBK_BAND_SPLIT=2: the round-4 chain, PHASE 1 / 2 of band_reduce_kernel with 4 - 8 member
     // workgroups per matrix).  One-k eigenval, round-4 chain -> band_xl chain: 2.05 -> 1.94 ms at 256 orbitals, 3.99 -> 3.50 at 384,
     // 6.05 -> 5.03 at 512, 13.98 -> 10.28 at 768, 24.35 -> 16.84 at 1024; 64 matrices: 2.23 -> 2.31 / 4.39 -> 4.43 / 6.80 -> 7.16 /
-    // 22.5 -> 17.6 / 46.3 -> 35.1 -- so up to 512 orbitals for calls of up to 16 matrices (8 up to 256), above for up to 96.
+    // 22.5 -> 17.6 / 46.3 -> 35.1; 64 matrices of 512 orbitals in ONE launch of the eight-wave kernel: 8.09 ms -- so calls of up to 8
+    // matrices up to 256 orbitals, 64 up to 512, 96 above.
     static const bool old_chain = getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 2;
     const int64_t limit = forced_limit > 0 ? forced_limit
                           : old_chain      ? (n <= 256 ? 8 : std::max(1, m->n_cu) / tbk_band_split_members(n, 8))
-                                           : (n <= 256 ? 8 : n <= 512 ? 16 : 96);
+                                           : (n <= 256 ? 8 : n <= 512 ? 64 : 96);
     return std::max<int64_t>(m->call_nk, nk) <= limit;
 }
 
