@@ -811,6 +811,27 @@ def test_launch_chain_of_small_calls_agrees_with_the_one_launch_kernel(n_orb):
     assert np.abs(other - here).max() < 1e-11
 
 
+def test_launch_chain_above_1024_orbitals_in_the_chunk_pipeline():
+    """1040 orbitals in THREE k chunks: the launch chain of band_xl_* on the reduction stream, the global-memory chase and the
+    bisection of the previous chunk on the tridiagonal stream beside it, two band buffers in turn -- bit for bit what the same
+    k-points give in calls of one chunk each (the chain's launches do not depend on the batch size), the oracle's values on a
+    sample, and (TBK_EIG_ROCSOLVER) the library's to rounding."""
+    from tbmodels_amd import _lib
+
+    r_vec, hop, pos = syn.dense_model_arrays(1040, 3, syn.MODEL_SEED + 1040)
+    k = syn.random_kpoints(250, seed=1040)
+    model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+    model.set_option(_lib.TBK_OPT_K_CHUNK, 100)  # 100 + 100 + 50: calls of more than 96 matrices, chunks that are not
+    whole = model.eigenval_array(k)
+    assert np.all(np.diff(whole, axis=1) >= 0)
+    pieces = np.concatenate([model.eigenval_array(k[i:i + 125]) for i in (0, 125)])  # (two calls of two chunks each)
+    assert np.array_equal(whole, pieces)
+    _close(whole[[0, 99, 100, 249]], np.array(oracle.eigenval(r_vec, hop, k[[0, 99, 100, 249]])))
+    model.set_option(_lib.TBK_OPT_EIGENSOLVER, _lib.TBK_EIG_ROCSOLVER)
+    lib_rows = model.eigenval_array(k[:6])
+    assert np.abs(lib_rows - whole[:6]).max() < 1e-11
+
+
 def test_two_stage_and_one_stage_reductions_agree():
     """TBK_BAND=0 (read once per process) selects the one-stage streaming reduction of tbk_eig_stream.hip: same
     eigenvalues to rounding as the default two-stage path, on a multi-chunk call."""
