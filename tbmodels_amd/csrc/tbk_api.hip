@@ -380,7 +380,7 @@ extern "C" void tbk_model_destroy(tbk_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&m->ws_phase, &m->ws_H, &m->ws_E,   &m->ws_E2,
-                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1], &m->ws_H2, &m->ws_split, &m->ws_posraw};
+                      &m->ws_info,  &m->ws_k, &m->ws_pos, &m->ws_out, &m->ws_out2, &m->ws_flag, &m->ws_orb, &m->ws_part, &m->ws_kfold, &m->ws_kline, &m->ws_band, &m->ws_bandmat[0], &m->ws_bandmat[1], &m->ws_H2, &m->ws_split, &m->ws_xl, &m->ws_posraw};
     for (DevBuf* b : bufs) b->release();
     tbk_fold_release(m);
     delete m;

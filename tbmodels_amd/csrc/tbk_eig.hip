@@ -65,7 +65,9 @@ __global__ void unscale_eigenvalues_kernel(double* __restrict__ E, int n, int64_
 
 size_t tbk_eig_scratch_per_k(const tbk_model* m) {
     return (size_t)m->n_orb * 4 * sizeof(double) + sizeof(int)  // (d, e) + complex tau
-           + (tbk_eig_band_supported(m->n_orb) ? tbk_band_scratch_per_matrix(m->n_orb) + 2 * tbk_band_bytes_per_matrix(m->n_orb) : 0);
+           + (tbk_eig_band_supported(m->n_orb) ? tbk_band_scratch_per_matrix(m->n_orb) + 2 * tbk_band_bytes_per_matrix(m->n_orb) +
+                                                     tbk_band_xl_buffer_per_matrix(m->n_orb)
+                                                   : 0);
 }
 
 int tbk_eig_batched(tbk_model* m, double* d_H, int64_t nk, double* d_E) {

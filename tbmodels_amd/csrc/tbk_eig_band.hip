@@ -1909,7 +1909,7 @@ __global__ void __launch_bounds__(256) band_extract_kernel(const double* __restr
 template <int NT>
 __global__ void __launch_bounds__(NT, 1)
 band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ XYall,
-                      d2* __restrict__ Tall, int p) {
+                      d2* __restrict__ Tall, int p, d2* __restrict__ band_all, size_t band_stride) {
     constexpr int NW = NT / 64;
     __shared__ d2 sPartG[2 * NW * 64];  // the waves' partial Gram products, two areas in turn
     __shared__ d2 sG[128];              // C of the Gram routine; (M T) behind it in the W phase
@@ -1924,6 +1924,17 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
     d2* XY = XYall + mat * (size_t)npad * PB;   // X = A V between the product sweep and the W phase; the panel's rows in the QR
     d2* gT = Tall + mat * 64;                   // T of the panel, for the W phase in the next launch
     auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
+    // The finished entries of the panel's block row (its diagonal block, its rows of R) ARE band entries: with one sweep per
+    // panel (old -> new matrix buffers, band_all != NULL) they go straight to the compact band -- the matrix buffers only ever
+    // hold the trailing matrix there -- otherwise into the matrix, from where band_extract_kernel takes them at the end.
+    d2* const band = band_all ? band_all + mat * band_stride : nullptr;
+    auto put_final = [&](int i, int j, d2 v) {  // entry (i, j), i <= j, of the block row
+        if (band) {
+            if (j - i <= PB) band[(size_t)i * (PB + 1) + (j - i)] = v;
+        } else {
+            *Hat(i, j) = v;
+        }
+    };
     const int lane15 = lane & 15, t8 = lane & 7;
 
     int gram_parity = 0;
@@ -2082,7 +2093,7 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
             if (in_rows && i_row < s) {
 #pragma unroll
                 for (int r = 0; r < PB; ++r)
-                    if (g0 + r <= i_row) *Hat(g0 + r, i_row) = x[r];
+                    if (g0 + r <= i_row) put_final(g0 + r, i_row, x[r]);
             }
             if (i_row < npad) {
                 const bool below = in_rows && i_row >= s;
@@ -2197,7 +2208,7 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
                 if (qr && i_row - s < PB && ((i_row - s >= c0 && i_row - s < c1) || (c1 >= last && i_row - s >= last))) {
                     const int c = i_row - s;
 #pragma unroll
-                    for (int r = 0; r < PB; ++r) *Hat(g0 + r, i_row) = (r >= c) ? conjd(yr[r]) : (d2){0.0, 0.0};
+                    for (int r = 0; r < PB; ++r) put_final(g0 + r, i_row, (r >= c) ? conjd(yr[r]) : (d2){0.0, 0.0});
                 }
                 if (in_mat) {
 #pragma unroll
@@ -2400,6 +2411,163 @@ band_xl_product_kernel(const double* __restrict__ Hall, int n, const d2* __restr
     }
 }
 
+// ONE sweep per panel (default): the workgroup of block row I walks ALL tiles of that row -- those left of the diagonal as the
+// transposed stored ones -- reads every tile from the OLD matrix buffer, applies the pending rank-16 update in registers
+// (either orientation: the row block's [V | W] is the A operand), adds tile Vn_J to its block of X, and writes the updated
+// tile to the NEW buffer when it is the stored orientation (J >= I).  Nobody reads what this launch writes, so there is no
+// order to keep: every tile crosses HBM three times per panel (read twice, written once) instead of four with the two sweeps
+// above, and a panel is two launches instead of three.  The buffers change roles from panel to panel; finished rows never
+// enter them (band_xl_serial_kernel writes those to the compact band).
+template <int NT>
+__global__ void __launch_bounds__(NT, 2)
+band_xl_sweep_kernel(const double* __restrict__ Hsrc_all, double* __restrict__ Hdst_all, int n, const d2* __restrict__ VWall,
+                     const d2* __restrict__ VNall, d2* __restrict__ XYall, int i0, int with_update) {
+    constexpr int NW = NT / 64;
+    __shared__ double sTr[NW * 16 * 17];
+    __shared__ double sRed[NW * 4 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const size_t mat = blockIdx.y;
+    const double* Hs = Hsrc_all + mat * (size_t)n * n * 2;
+    double* Hd = Hdst_all + mat * (size_t)n * n * 2;
+    const d2* VW = VWall + mat * (size_t)nbk * 256;
+    const double* VNd = reinterpret_cast<const double*>(VNall + mat * (size_t)npad * PB);
+    double* XYd = reinterpret_cast<double*>(XYall + mat * (size_t)npad * PB);
+    const int I = i0 + (int)blockIdx.x;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int lane_x = lq * 16 + 2 * (lrow & 7) + (lrow >> 3);
+    const double lane_sgn = (lrow < 8) ? -1.0 : 1.0;
+    double* tr = sTr + wave * (16 * 17);
+    Frag own;
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+        const d2 v2 = with_update ? VW[((size_t)I * 4 + sg) * 64 + lane] : (d2){0.0, 0.0};
+        own.re[sg] = v2[0];
+        own.im[sg] = v2[1];
+    }
+    d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = own1;
+    for (int J = i0 + wave; J < nbk; J += NW) {
+        const int Ir = min(I, J), Jc = max(I, J);
+        const bool interior = (Ir + 1) * TS <= n && (Jc + 1) * TS <= n;
+        const unsigned gc = (unsigned)min(Jc * TS + lrow, n - 1);
+        d4 tre, tim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned gr = (unsigned)min(Ir * TS + lq + 4 * r, n - 1);
+            const d2 v2 = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(Hs) + (size_t)gr * (size_t)n * 16 + (size_t)gc * 16);
+            const bool inside = interior || (Ir * TS + lq + 4 * r < n && Jc * TS + lrow < n);
+            tre[r] = inside ? v2[0] : 0.0;
+            tim[r] = inside ? v2[1] : 0.0;
+        }
+        double pb[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) pb[sg] = (VNd + (size_t)J * (TS * 16) + lane_x)[sg * 64];
+        if (with_update) {  // (uniform)
+            Frag par;
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const d2 v2 = VW[((size_t)J * 4 + sg) * 64 + lane];
+                par.re[sg] = v2[0];
+                par.im[sg] = v2[1];
+            }
+            if (J >= I) {  // tile(I, J) -= [V | W]_I ([W | V]_J)^H
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int sb = (sg + 2) & 3;
+                    tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], par.re[sb], tre, 0, 0, 1);
+                    tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], par.im[sb], tre, 0, 0, 1);
+                    tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], par.re[sb], tim, 0, 0, 1);
+                    tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], par.im[sb], tim, 0, 0, 0);
+                }
+            } else {       // tile(J, I) -= [V | W]_J ([W | V]_I)^H
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int sb = (sg + 2) & 3;
+                    tre = __builtin_amdgcn_mfma_f64_16x16x4f64(par.re[sg], own.re[sb], tre, 0, 0, 1);
+                    tre = __builtin_amdgcn_mfma_f64_16x16x4f64(par.im[sg], own.im[sb], tre, 0, 0, 1);
+                    tim = __builtin_amdgcn_mfma_f64_16x16x4f64(par.im[sg], own.re[sb], tim, 0, 0, 1);
+                    tim = __builtin_amdgcn_mfma_f64_16x16x4f64(par.re[sg], own.im[sb], tim, 0, 0, 0);
+                }
+            }
+        }
+        if (J >= I) {
+            // the stored orientation: the updated tile goes to the new buffer (also without an update: the buffers change roles)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = I * TS + lq + 4 * r;
+                if (interior || (gr < n && J * TS + lrow < n))
+                    *reinterpret_cast<d2*>(reinterpret_cast<char*>(Hd) + (size_t)gr * (size_t)n * 16 + (size_t)(J * TS + lrow) * 16) = (d2){tre[r], tim[r]};
+            }
+            double ttre[4], ttim[4];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tre[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) ttre[sg] = tr[lrow * 17 + lq + 4 * sg];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tim[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
+            asm volatile("" ::: "memory");
+            if (J == I) {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const bool upper = lrow <= lq + 4 * sg;
+                    const double ar = upper ? ttre[sg] : tre[sg];
+                    const double ai = upper ? ttim[sg] : -tim[sg];
+                    own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, pb[sg], own1, 0, 0, 0);
+                    own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, pb[sg], own2, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], pb[sg], own1, 0, 0, 0);
+                    own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], pb[sg], own2, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], pb[sg], own1, 0, 0, 0);
+                own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], pb[sg], own2, 0, 0, 1);  // conj
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[(wave * 4 + r) * 64 + lane] = fma(dpp_mov<0x128>(own2[r]), lane_sgn, own1[r]);
+    lds_fence();
+    __syncthreads();
+    for (int r = wave; r < 4; r += NW) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += sRed[(w * 4 + r) * 64 + lane];
+        (XYd + (size_t)I * (TS * 16) + lane_x)[r * 64] = tot;
+    }
+}
+
+// the band rows from row0 on out of a matrix buffer (the one-sweep chain: the rows behind the last panel), and the whole band back
+// INTO the caller's matrix buffer (tbk_tridiagonal_reduce hands that buffer out as the work copy of the reduction)
+__global__ void __launch_bounds__(256) band_extract_from_kernel(const double* __restrict__ Hall, int n, d2* __restrict__ band_all, size_t band_stride, int row0) {
+    const double* H = Hall + (size_t)blockIdx.x * n * n * 2;
+    d2* band = band_all + (size_t)blockIdx.x * band_stride;
+    for (int idx = row0 * (PB + 1) + threadIdx.x; idx < n * (PB + 1); idx += 256) {
+        const int i = idx / (PB + 1), dd = idx - i * (PB + 1);
+        band[idx] = (i + dd < n) ? *reinterpret_cast<const d2*>(H + ((size_t)i * n + i + dd) * 2) : (d2){0.0, 0.0};
+    }
+}
+__global__ void __launch_bounds__(256) band_deposit_kernel(double* __restrict__ Hall, int n, const d2* __restrict__ band_all, size_t band_stride) {
+    double* H = Hall + (size_t)blockIdx.x * n * n * 2;
+    const d2* band = band_all + (size_t)blockIdx.x * band_stride;
+    for (int idx = threadIdx.x; idx < n * (PB + 1); idx += 256) {
+        const int i = idx / (PB + 1), dd = idx - i * (PB + 1);
+        if (i + dd < n) *reinterpret_cast<d2*>(H + ((size_t)i * n + i + dd) * 2) = band[idx];
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -2413,6 +2581,8 @@ static bool band_xl(int n) {
     static const int from = getenv("TBK_BAND_XL_FROM") ? atoi(getenv("TBK_BAND_XL_FROM")) : 1024;
     return n > from;
 }
+// the second matrix buffer of the chain (ws_xl), per matrix of a chunk: only the sizes that ALWAYS take the chain count for the chunk size
+size_t tbk_band_xl_buffer_per_matrix(int n) { return band_xl(n) ? (size_t)n * n * sizeof(d2) : 0; }
 // (+ for the launch chain of band_xl_*: X / the panel's rows [npad][8] and T of the panel)
 size_t tbk_band_scratch_per_matrix(int n) {
     const size_t nbk = (size_t)((n + TS - 1) / TS);
@@ -2545,19 +2715,48 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     int p_end = 0;  // first panel without a trailing matrix behind it
     while (n - PB * (p_end + 1) >= 2) ++p_end;
     constexpr int NTS = 512, NTP = 256;
+    // TBK_BAND_XL_SWEEPS=2 (measurements): the update sweep and the product sweep as two launches on ONE matrix buffer (the first
+    // form of the chain: every tile crosses HBM four times per panel)
+    static const bool two_sweeps = getenv("TBK_BAND_XL_SWEEPS") && atoi(getenv("TBK_BAND_XL_SWEEPS")) == 2;
+    if (two_sweeps) {
+        for (int p = 0; p <= p_end; ++p) {
+            hipLaunchKernelGGL((band_xl_serial_kernel<NTS>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p,
+                               (d2*)nullptr, (size_t)0);
+            if (p == p_end) break;
+            const int i0 = PB * (p + 1) / TS, na = nbk - i0;
+            if (p > 0)
+                hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VW, i0);
+            hipLaunchKernelGGL((band_xl_product_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VN, d_XY, i0);
+        }
+        if (p_end > 0) {  // the last pending update (no look-ahead consumed any of its rows)
+            const int i0 = PB * p_end / TS;
+            hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)(nbk - i0), (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VW, i0);
+        }
+        hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)nk), dim3(256), 0, s, d_H, n, d_band, stride);
+        TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    }
+    // One sweep per panel between two matrix buffers (the caller's and ws_xl) that change roles; the finished rows go to the band
+    // as the serial phases produce them, the rows behind the last panel come out of the buffer the last update leaves them in,
+    // and the band is put back into the caller's buffer (the work copy tbk_tridiagonal_reduce hands out).
+    TBK_CHECK(m->ws_xl.reserve((size_t)nk * n * n * 2 * sizeof(double)));
+    double* buf[2] = {d_H, m->ws_xl.as<double>()};
+    int cur = 0;
     for (int p = 0; p <= p_end; ++p) {
-        hipLaunchKernelGGL((band_xl_serial_kernel<NTS>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p);
+        hipLaunchKernelGGL((band_xl_serial_kernel<NTS>), dim3((unsigned)nk), dim3(NTS), 0, s, buf[cur], n, d_VW, d_VN, d_XY, d_T, p,
+                           d_band, stride);
         if (p == p_end) break;
         const int i0 = PB * (p + 1) / TS, na = nbk - i0;
-        if (p > 0)
-            hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VW, i0);
-        hipLaunchKernelGGL((band_xl_product_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VN, d_XY, i0);
+        hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, buf[cur], buf[cur ^ 1], n, d_VW,
+                           d_VN, d_XY, i0, p > 0 ? 1 : 0);
+        cur ^= 1;
     }
-    if (p_end > 0) {  // the last pending update (no look-ahead consumed any of its rows)
+    if (p_end > 0) {  // the last pending update, in place (nobody reads tiles in this launch)
         const int i0 = PB * p_end / TS;
-        hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)(nbk - i0), (unsigned)nk), dim3(NTP), 0, s, d_H, n, d_VW, i0);
+        hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)(nbk - i0), (unsigned)nk), dim3(NTP), 0, s, buf[cur], n, d_VW, i0);
     }
-    hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)nk), dim3(256), 0, s, d_H, n, d_band, stride);
+    hipLaunchKernelGGL(band_extract_from_kernel, dim3((unsigned)nk), dim3(256), 0, s, buf[cur], n, d_band, stride, PB * p_end);
+    hipLaunchKernelGGL(band_deposit_kernel, dim3((unsigned)nk), dim3(256), 0, s, d_H, n, d_band, stride);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

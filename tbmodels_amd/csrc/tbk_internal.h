@@ -222,6 +222,7 @@ struct tbk_model {
     std::vector<double> pos_cache;         // host copy of what ws_posraw holds
     DevBuf ws_posraw;
     DevBuf ws_split;  // calls of a few matrices: T and the members' partial X between the launches of the first stage
+    DevBuf ws_xl;     // the launch chain of band_xl_*: the second matrix buffer (the sweep of a panel reads one, writes the other)
     // Set for the duration of one eigenvalue call by tbk_eigenval_device_gather (tbk_comm.hip): the chunk pipeline calls it
     // whenever the eigenvalues of rows [c0, c0 + nkc) of the call have been enqueued, with an event recorded behind
     // them -- the all-gather of finished rows leaves on the communicator's stream while later chunks compute.
@@ -299,6 +300,7 @@ bool tbk_eig_band_supported(int n);
 bool tbk_eig_band_preferred(int n);
 size_t tbk_band_scratch_per_matrix(int n);
 size_t tbk_band_bytes_per_matrix(int n);
+size_t tbk_band_xl_buffer_per_matrix(int n);  // the second matrix buffer of the launch chain above 1024 orbitals
 bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this model (64 < n_orb <= 512, not TBK_BAND=0)
 // d_de_fused != NULL: every workgroup runs the second stage for its matrix too and writes (d, e); d_band is not used
 int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band,
