@@ -1906,11 +1906,15 @@ __global__ void __launch_bounds__(256) band_extract_kernel(const double* __restr
 // Stream order is the only synchronisation between them.  Same arithmetic as the kernels above (tools/two_stage_model.py:
 // panel_qr_gram, stage1_band); band_extract_kernel, the global-memory chase and the bisection follow.
 // ================================================================================================
-template <int NT>
+// YL: the panel's rows live in LDS ([npad][8] complex of dynamic LDS: up to 1024 orbitals) instead of the X / Y buffer in global
+// memory -- what the calls of a few matrices take: for ONE matrix every hand-over of the rows through global memory (look-ahead ->
+// sums -> reflectors -> T) is a round trip with nothing else on the CU to hide it.
+template <int NT, bool YL>
 __global__ void __launch_bounds__(NT, 1)
 band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ XYall,
                       d2* __restrict__ Tall, int p, d2* __restrict__ band_all, size_t band_stride) {
     constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) double xl_smem[];
     __shared__ d2 sPartG[2 * NW * 64];  // the waves' partial Gram products, two areas in turn
     __shared__ d2 sG[128];              // C of the Gram routine; (M T) behind it in the W phase
     __shared__ d2 sS[64], sT[64], sF[64], sTau[PB], sCo[2 * PB];
@@ -1921,7 +1925,8 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
     double* H = Hall + mat * (size_t)n * n * 2;
     d2* VW = VWall + mat * (size_t)nbk * 256;   // pending [V | W] rows, fragment order
     d2* VN = VNall + mat * (size_t)npad * PB;   // the panel's V, [npad][8]
-    d2* XY = XYall + mat * (size_t)npad * PB;   // X = A V between the product sweep and the W phase; the panel's rows in the QR
+    d2* XY = XYall + mat * (size_t)npad * PB;   // X = A V between the sweep and the W phase; the panel's rows in the QR (unless YL)
+    d2* const Yp = YL ? reinterpret_cast<d2*>(xl_smem) : XY;  // the panel's rows during the QR, then its V (for the T factor's sum)
     d2* gT = Tall + mat * 64;                   // T of the panel, for the W phase in the next launch
     auto Hat = [&](int i, int j) -> d2* { return reinterpret_cast<d2*>(H + ((size_t)i * n + j) * 2); };
     // The finished entries of the panel's block row (its diagonal block, its rows of R) ARE band entries: with one sweep per
@@ -2098,7 +2103,7 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
             if (i_row < npad) {
                 const bool below = in_rows && i_row >= s;
 #pragma unroll
-                for (int c = 0; c < PB; ++c) XY[(size_t)i_row * PB + c] = below ? conjd(x[c]) : (d2){0.0, 0.0};
+                for (int c = 0; c < PB; ++c) Yp[(size_t)i_row * PB + c] = below ? conjd(x[c]) : (d2){0.0, 0.0};
             }
         }
     }
@@ -2113,13 +2118,13 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
             d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
             for (int q = wave; lo + 64 * q < n; q += NW) {
                 if (lo + 64 * q + 64 <= s + c0) continue;  // wave-uniform
-                gram_direct(XY, XY, lo + 64 * q, s + c0, acc);
+                gram_direct(Yp, Yp, lo + 64 * q, s + c0, acc);
             }
             gram_finish(acc);
             if (c0 == 0 && have_update && tid < 128) VW[vw_index(g0 + (tid >> 4), tid & 15)] = (d2){0.0, 0.0};
             d2 top[PB];
 #pragma unroll
-            for (int c = 0; c < PB; ++c) top[c] = (c >= c0 && c < m) ? XY[(size_t)min(s + c, npad - 1) * PB + t8] : (d2){0.0, 0.0};
+            for (int c = 0; c < PB; ++c) top[c] = (c >= c0 && c < m) ? Yp[(size_t)min(s + c, npad - 1) * PB + t8] : (d2){0.0, 0.0};
             d2 g_next = sG[min(c0, PB - 1) * PB + t8];
             bool stopped = false;
             int c1 = last;
@@ -2184,7 +2189,7 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
                 d2 yr[PB], vrow[PB];
 #pragma unroll
                 for (int c = 0; c < PB; ++c) {
-                    yr[c] = XY[(size_t)ic * PB + c];
+                    yr[c] = Yp[(size_t)ic * PB + c];
                     vrow[c] = (d2){0.0, 0.0};
                 }
                 static_for<0, PB>([&](auto cc) {
@@ -2214,10 +2219,10 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
 #pragma unroll
                     for (int c = 0; c < PB; ++c) {
                         if (c >= c0 && c < c1) {
-                            XY[(size_t)i_row * PB + c] = vrow[c];
+                            Yp[(size_t)i_row * PB + c] = vrow[c];
                             VN[(size_t)i_row * PB + c] = vrow[c];
                         } else if (c >= c1) {
-                            XY[(size_t)i_row * PB + c] = c1 < last ? yr[c] : (d2){0.0, 0.0};
+                            Yp[(size_t)i_row * PB + c] = c1 < last ? yr[c] : (d2){0.0, 0.0};
                             if (c1 >= last) VN[(size_t)i_row * PB + c] = (d2){0.0, 0.0};
                         }
                     }
@@ -2233,7 +2238,10 @@ band_xl_serial_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, 
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
         for (int q = wave; lo + 64 * q < n; q += NW) {
             if (lo + 64 * q + 64 <= s) continue;  // wave-uniform
-            gram_direct(VN, VN, lo + 64 * q, s, acc);
+            if (YL)
+                gram_direct(Yp, Yp, lo + 64 * q, s, acc);  // (the rows of V where the reflectors left them)
+            else
+                gram_direct(VN, VN, lo + 64 * q, s, acc);
         }
         gram_finish(acc);
         if (tid < PB) {
@@ -2720,7 +2728,7 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     static const bool two_sweeps = getenv("TBK_BAND_XL_SWEEPS") && atoi(getenv("TBK_BAND_XL_SWEEPS")) == 2;
     if (two_sweeps) {
         for (int p = 0; p <= p_end; ++p) {
-            hipLaunchKernelGGL((band_xl_serial_kernel<NTS>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p,
+            hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p,
                                (d2*)nullptr, (size_t)0);
             if (p == p_end) break;
             const int i0 = PB * (p + 1) / TS, na = nbk - i0;
@@ -2742,9 +2750,21 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     TBK_CHECK(m->ws_xl.reserve((size_t)nk * n * n * 2 * sizeof(double)));
     double* buf[2] = {d_H, m->ws_xl.as<double>()};
     int cur = 0;
+    // up to 1024 orbitals (calls of a few matrices): the panel's rows in LDS (TBK_BAND_XL_YLDS=0: in global memory, as above 1024)
+    static const bool y_lds_env = !(getenv("TBK_BAND_XL_YLDS") && atoi(getenv("TBK_BAND_XL_YLDS")) == 0);
+    const bool y_lds = y_lds_env && n <= BAND_ONE_WG_MAXN;
+    const size_t y_bytes = (size_t)npad * PB * sizeof(d2);
+    if (y_lds) {
+        static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_xl_serial_kernel<NTS, true>), 132 * 1024, raised));
+    }
     for (int p = 0; p <= p_end; ++p) {
-        hipLaunchKernelGGL((band_xl_serial_kernel<NTS>), dim3((unsigned)nk), dim3(NTS), 0, s, buf[cur], n, d_VW, d_VN, d_XY, d_T, p,
-                           d_band, stride);
+        if (y_lds)
+            hipLaunchKernelGGL((band_xl_serial_kernel<NTS, true>), dim3((unsigned)nk), dim3(NTS), y_bytes, s, buf[cur], n, d_VW, d_VN, d_XY,
+                               d_T, p, d_band, stride);
+        else
+            hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nk), dim3(NTS), 0, s, buf[cur], n, d_VW, d_VN, d_XY, d_T, p,
+                               d_band, stride);
         if (p == p_end) break;
         const int i0 = PB * (p + 1) / TS, na = nbk - i0;
         hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, buf[cur], buf[cur ^ 1], n, d_VW,
