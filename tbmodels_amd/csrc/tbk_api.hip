@@ -189,6 +189,8 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     }
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_eig, hipStreamNonBlocking)));
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_ql, hipStreamNonBlocking)));
+    for (hipStream_t& st : m->stream_xl) TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)));
+    for (hipEvent_t& e : m->ev_xl) TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)));
     for (int b = 0; b < 2; ++b) {
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_hk[b], hipEventDisableTiming)));
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_tri[b], hipEventDisableTiming)));
@@ -358,9 +360,11 @@ extern "C" int tbk_model_create_csr(int device, int dim, int n_orb, int64_t n_r,
 extern "C" void tbk_model_destroy(tbk_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    hipStream_t streams[] = {m->stream, m->stream_eig, m->stream_ql};
+    hipStream_t streams[] = {m->stream, m->stream_eig, m->stream_ql, m->stream_xl[0], m->stream_xl[1], m->stream_xl[2]};
     for (hipStream_t st : streams)
         if (st) (void)hipStreamSynchronize(st);
+    for (hipEvent_t e : m->ev_xl)
+        if (e) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {
         if (m->ev_hk[b]) (void)hipEventDestroy(m->ev_hk[b]);
         if (m->ev_tri[b]) (void)hipEventDestroy(m->ev_tri[b]);

@@ -2749,7 +2749,6 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     // and the band is put back into the caller's buffer (the work copy tbk_tridiagonal_reduce hands out).
     TBK_CHECK(m->ws_xl.reserve((size_t)nk * n * n * 2 * sizeof(double)));
     double* buf[2] = {d_H, m->ws_xl.as<double>()};
-    int cur = 0;
     // up to 1024 orbitals (calls of a few matrices): the panel's rows in LDS (TBK_BAND_XL_YLDS=0: in global memory, as above 1024)
     static const bool y_lds_env = !(getenv("TBK_BAND_XL_YLDS") && atoi(getenv("TBK_BAND_XL_YLDS")) == 0);
     const bool y_lds = y_lds_env && n <= BAND_ONE_WG_MAXN;
@@ -2758,25 +2757,58 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
         static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_xl_serial_kernel<NTS, true>), 132 * 1024, raised));
     }
-    for (int p = 0; p <= p_end; ++p) {
-        if (y_lds)
-            hipLaunchKernelGGL((band_xl_serial_kernel<NTS, true>), dim3((unsigned)nk), dim3(NTS), y_bytes, s, buf[cur], n, d_VW, d_VN, d_XY,
-                               d_T, p, d_band, stride);
-        else
-            hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nk), dim3(NTS), 0, s, buf[cur], n, d_VW, d_VN, d_XY, d_T, p,
-                               d_band, stride);
-        if (p == p_end) break;
-        const int i0 = PB * (p + 1) / TS, na = nbk - i0;
-        hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nk), dim3(NTP), 0, s, buf[cur], buf[cur ^ 1], n, d_VW,
-                           d_VN, d_XY, i0, p > 0 ? 1 : 0);
-        cur ^= 1;
+    // A batch above 1024 orbitals goes in GROUPS of matrices on streams of their own: the serial phases of a panel occupy one
+    // workgroup per matrix (a latency chain on a quarter of the CUs at 64 matrices) while the sweep is bound by HBM -- one group's
+    // serial phases run under the other groups' sweeps.  Per matrix nothing changes (same launches, same order, same bits).
+    // TBK_BAND_XL_GROUPS=g (1 - 4; measurements): default 2.
+    static const int groups_env = getenv("TBK_BAND_XL_GROUPS") ? std::min(4, std::max(1, atoi(getenv("TBK_BAND_XL_GROUPS")))) : 2;
+    const int groups = (band_xl(n) && nk >= 4 * groups_env) ? groups_env : 1;
+    auto chain = [&](hipStream_t st, int64_t k0, int64_t nkg) {
+        double* b[2] = {buf[0] + (size_t)k0 * n * n * 2, buf[1] + (size_t)k0 * n * n * 2};
+        d2* vw = d_VW + (size_t)k0 * nbk * 256;
+        d2* vn = d_VN + (size_t)k0 * npad * PB;
+        d2* xy = d_XY + (size_t)k0 * npad * PB;
+        d2* tt = d_T + (size_t)k0 * 64;
+        d2* bd = d_band + (size_t)k0 * stride;
+        int cur = 0;
+        for (int p = 0; p <= p_end; ++p) {
+            if (y_lds)
+                hipLaunchKernelGGL((band_xl_serial_kernel<NTS, true>), dim3((unsigned)nkg), dim3(NTS), y_bytes, st, b[cur], n, vw, vn, xy, tt, p,
+                                   bd, stride);
+            else
+                hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nkg), dim3(NTS), 0, st, b[cur], n, vw, vn, xy, tt, p, bd,
+                                   stride);
+            if (p == p_end) break;
+            const int i0 = PB * (p + 1) / TS, na = nbk - i0;
+            hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nkg), dim3(NTP), 0, st, b[cur], b[cur ^ 1], n, vw, vn, xy,
+                               i0, p > 0 ? 1 : 0);
+            cur ^= 1;
+        }
+        if (p_end > 0) {  // the last pending update, in place (nobody reads tiles in this launch)
+            const int i0 = PB * p_end / TS;
+            hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)(nbk - i0), (unsigned)nkg), dim3(NTP), 0, st, b[cur], n, vw, i0);
+        }
+        hipLaunchKernelGGL(band_extract_from_kernel, dim3((unsigned)nkg), dim3(256), 0, st, b[cur], n, bd, stride, PB * p_end);
+        hipLaunchKernelGGL(band_deposit_kernel, dim3((unsigned)nkg), dim3(256), 0, st, b[0], n, bd, stride);
+    };
+    if (groups == 1) {
+        chain(s, 0, nk);
+    } else {
+        TBK_HIP(hipEventRecord(m->ev_xl[0], s));
+        const int64_t per = (nk + groups - 1) / groups;
+        for (int g = 1; g < groups; ++g) TBK_HIP(hipStreamWaitEvent(m->stream_xl[g - 1], m->ev_xl[0], 0));
+        // (the host enqueues group after group; the streams run side by side from the first launch on)
+        for (int g = 0; g < groups; ++g) {
+            const int64_t k0 = g * per, nkg = std::min(per, nk - k0);
+            if (nkg <= 0) break;
+            hipStream_t st = g == 0 ? s : m->stream_xl[g - 1];
+            chain(st, k0, nkg);
+            if (g > 0) {
+                TBK_HIP(hipEventRecord(m->ev_xl[g], st));
+                TBK_HIP(hipStreamWaitEvent(s, m->ev_xl[g], 0));
+            }
+        }
     }
-    if (p_end > 0) {  // the last pending update, in place (nobody reads tiles in this launch)
-        const int i0 = PB * p_end / TS;
-        hipLaunchKernelGGL((band_xl_update_kernel<NTP>), dim3((unsigned)(nbk - i0), (unsigned)nk), dim3(NTP), 0, s, buf[cur], n, d_VW, i0);
-    }
-    hipLaunchKernelGGL(band_extract_from_kernel, dim3((unsigned)nk), dim3(256), 0, s, buf[cur], n, d_band, stride, PB * p_end);
-    hipLaunchKernelGGL(band_deposit_kernel, dim3((unsigned)nk), dim3(256), 0, s, d_H, n, d_band, stride);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

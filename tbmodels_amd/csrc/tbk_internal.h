@@ -187,6 +187,8 @@ struct tbk_model {
     hipStream_t stream = nullptr;      // phase rows, H(k), rocSOLVER, collectives
     hipStream_t stream_eig = nullptr;  // wave eigensolver: reduction to tridiagonal form
     hipStream_t stream_ql = nullptr;   // wave eigensolver: tridiagonal QL (latency-bound, overlaps the rest)
+    hipStream_t stream_xl[3] = {nullptr, nullptr, nullptr};  // band_xl_* above 1024 orbitals: the other groups of a batch (tbk_eig_band.hip)
+    hipEvent_t ev_xl[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, and one join per extra group
     hipEvent_t ev_hk[2] = {nullptr, nullptr};   // H[buf] written
     hipEvent_t ev_tri[2] = {nullptr, nullptr};  // H[buf] consumed, (d, e)[buf] written
     hipEvent_t ev_out[2] = {nullptr, nullptr};  // tbk_hamilton: chunk in ws_out / ws_out2 computed
