@@ -2713,7 +2713,16 @@ static int launch_split(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t
 
 // The first stage above 1024 orbitals: three launches per panel (serial phases / update sweep / product sweep), one more update
 // sweep for the last pending update, then the band's way out.
-static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t nk, d2* d_scratch, d2* d_band) {
+static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_D, double* d_E);
+static int xl_groups(int n, int64_t nk) {
+    // TBK_BAND_XL_GROUPS=g (1 - 4; measurements): default 2
+    static const int groups_env = getenv("TBK_BAND_XL_GROUPS") ? std::min(4, std::max(1, atoi(getenv("TBK_BAND_XL_GROUPS")))) : 2;
+    return (band_xl(n) && nk >= 4 * groups_env) ? groups_env : 1;
+}
+bool tbk_band_xl_grouped(int n, int64_t nk) { return xl_groups(n, nk) > 1; }
+
+// d_de != NULL: the second stage of every group runs behind its first stage on the group's stream and (d, e) are written there
+static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t nk, d2* d_scratch, d2* d_band, double* d_de = nullptr) {
     const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
     d2* d_VW = d_scratch;
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
@@ -2758,11 +2767,10 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_xl_serial_kernel<NTS, true>), 132 * 1024, raised));
     }
     // A batch above 1024 orbitals goes in GROUPS of matrices on streams of their own: the serial phases of a panel occupy one
-    // workgroup per matrix (a latency chain on a quarter of the CUs at 64 matrices) while the sweep is bound by HBM -- one group's
-    // serial phases run under the other groups' sweeps.  Per matrix nothing changes (same launches, same order, same bits).
-    // TBK_BAND_XL_GROUPS=g (1 - 4; measurements): default 2.
-    static const int groups_env = getenv("TBK_BAND_XL_GROUPS") ? std::min(4, std::max(1, atoi(getenv("TBK_BAND_XL_GROUPS")))) : 2;
-    const int groups = (band_xl(n) && nk >= 4 * groups_env) ? groups_env : 1;
+    // workgroup per matrix (a latency chain on a quarter of the CUs at 64 matrices) while the sweep is bound by HBM, and the second
+    // stage is one workgroup per matrix for 2 n ticks -- one group's chains run under the other groups' sweeps.  Per matrix nothing
+    // changes (same launches, same order, same bits).
+    const int groups = xl_groups(n, nk);
     auto chain = [&](hipStream_t st, int64_t k0, int64_t nkg) {
         double* b[2] = {buf[0] + (size_t)k0 * n * n * 2, buf[1] + (size_t)k0 * n * n * 2};
         d2* vw = d_VW + (size_t)k0 * nbk * 256;
@@ -2790,9 +2798,11 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
         }
         hipLaunchKernelGGL(band_extract_from_kernel, dim3((unsigned)nkg), dim3(256), 0, st, b[cur], n, bd, stride, PB * p_end);
         hipLaunchKernelGGL(band_deposit_kernel, dim3((unsigned)nkg), dim3(256), 0, st, b[0], n, bd, stride);
+        if (d_de) return launch_chase(m, st, bd, nkg, d_de + (size_t)k0 * n, d_de + (size_t)(nk + k0) * n);
+        return (int)TBK_OK;
     };
     if (groups == 1) {
-        chain(s, 0, nk);
+        TBK_CHECK(chain(s, 0, nk));
     } else {
         TBK_HIP(hipEventRecord(m->ev_xl[0], s));
         const int64_t per = (nk + groups - 1) / groups;
@@ -2802,7 +2812,7 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
             const int64_t k0 = g * per, nkg = std::min(per, nk - k0);
             if (nkg <= 0) break;
             hipStream_t st = g == 0 ? s : m->stream_xl[g - 1];
-            chain(st, k0, nkg);
+            TBK_CHECK(chain(st, k0, nkg));
             if (g > 0) {
                 TBK_HIP(hipEventRecord(m->ev_xl[g], st));
                 TBK_HIP(hipStreamWaitEvent(s, m->ev_xl[g], 0));
@@ -2819,7 +2829,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     const int n = m->n_orb;
     if (nk == 0) return TBK_OK;
     StageTimer t(m, TBK_T_EIG, s);
-    if (band_xl(n)) return launch_band_xl(m, s, d_H, n, nk, static_cast<d2*>(d_vw), static_cast<d2*>(d_band));
+    if (band_xl(n)) return launch_band_xl(m, s, d_H, n, nk, static_cast<d2*>(d_vw), static_cast<d2*>(d_band), d_de_fused);
     const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
     // up to 256 orbitals a row per thread, V and X in LDS; above, TWO rows per thread and V in global memory, so that two
     // workgroups still fit a CU (76 KiB each at 512 orbitals) -- with 512 threads / V in LDS only one did and nothing
@@ -2885,12 +2895,8 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
 }
 
 // Stage two: d_band -> d_de = d[nk][n] followed by e[nk][n]
-int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de) {
+static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_D, double* d_E) {
     const int n = m->n_orb;
-    if (nk == 0) return TBK_OK;
-    double* d_D = d_de;
-    double* d_E = d_de + (size_t)nk * n;
-    StageTimer t(m, TBK_T_EIG, s);
     if (chase_global(n)) {
         const int np = chase_pitch(n);
         // 32 sweeps in flight, two steps apart, from 512 orbitals on (a sweep is n / 8 >= 64 steps long); 16 below
@@ -2938,4 +2944,10 @@ int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;
+}
+
+int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de) {
+    if (nk == 0) return TBK_OK;
+    StageTimer t(m, TBK_T_EIG, s);
+    return launch_chase(m, s, d_band, nk, d_de, d_de + (size_t)nk * m->n_orb);
 }

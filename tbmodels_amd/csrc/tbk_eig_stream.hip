@@ -799,6 +799,7 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
         TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
         if (tbk_band_fused(n) && !tbk_band_split(m, nk)) return tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, nullptr, d_de);
         TBK_CHECK(m->ws_bandmat[0].reserve((size_t)nk * tbk_band_bytes_per_matrix(n)));
+        if (tbk_band_xl_grouped(n, nk)) return tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, m->ws_bandmat[0].ptr, d_de);
         TBK_CHECK(tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, m->ws_bandmat[0].ptr));
         return tbk_launch_band_chase(m, s, m->ws_bandmat[0].ptr, nk, d_de);
     }

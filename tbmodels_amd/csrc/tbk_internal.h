@@ -310,6 +310,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
 bool tbk_band_fused(int n);  // both stages in one kernel (<= 256 orbitals) or two launches, the second one overlappable
 // calls of a few matrices: the first stage as a chain of launches, every tile pass on several CUs (never fused with stage two)
 bool tbk_band_split(const tbk_model* m, int64_t nk);
+bool tbk_band_xl_grouped(int n, int64_t nk);  // above 1024 orbitals, a batch: tbk_launch_band_reduce(..., d_band, d_de) runs both stages group by group
 int tbk_launch_band_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_de);
 
 // tbk_eig_small.hip

@@ -635,6 +635,34 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
+def test_a_batch_above_1024_orbitals_in_groups_equals_its_matrices_one_at_a_time():
+    """Above 1024 orbitals a batch goes in groups of matrices on streams of their own (csrc/tbk_eig_band.hip, launch_band_xl:
+    one group's serial phases and second stage under the other groups' sweeps).  Per matrix nothing may change: (d, e) and the
+    band left in the work copy of a batch of 11 (two groups of 6 and 5) equal those of the same matrices reduced one per call,
+    bit for bit (the independence of k-points at _tb_model.py:1111-1123)."""
+    from tbmodels_amd import _lib
+
+    lib = _lib.lib()
+    n, nk = 1040, 11
+    rng = np.random.default_rng(77)
+    m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = np.ascontiguousarray((m + m.conj().transpose(0, 2, 1)) / 2)
+    h[4] *= 1e-20
+    d, e, red = np.empty((nk, n)), np.empty((nk, n)), np.empty_like(h)
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(h), _lib.TBK_REDUCE_AUTO, _lib.ptr(d), _lib.ptr(e), _lib.ptr(red)))
+    for i in range(nk):
+        one = np.ascontiguousarray(h[i : i + 1])
+        d1, e1, r1 = np.empty((1, n)), np.empty((1, n)), np.empty_like(one)
+        _lib.check(lib.tbk_tridiagonal_reduce(0, n, 1, _lib.ptr(one), _lib.TBK_REDUCE_AUTO, _lib.ptr(d1), _lib.ptr(e1), _lib.ptr(r1)))
+        assert np.array_equal(d[i], d1[0]) and np.array_equal(e[i], e1[0]), i
+        band = lambda a: np.triu(a) - np.triu(a, 9)  # noqa: E731  (half-width 8)
+        assert np.array_equal(band(red[i]), band(r1[0])), i
+    ref = np.linalg.eigvalsh(h[10])
+    import scipy.linalg as la
+
+    assert np.abs(la.eigvalsh_tridiagonal(d[10], e[10, :-1]) - ref).max() <= 1e-13 * n * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("n", [1, 7, 33, 64, 65, 72, 96, 130, 257, 400, 512, 513, 700, 1024, 1030, 1300])
 def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
     """``tbk_tridiagonal_reduce``: the reduction stage of the eigensolver alone (scipy's eigvalsh at _tb_model.py:1149 is

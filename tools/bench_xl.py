@@ -2,7 +2,8 @@
 """Above 1024 orbitals: the own launch chain (csrc/tbk_eig_band.hip, band_xl_*) against rocsolver_zheevd_strided_batched,
 whole `eigenval` (H(k) of a dense N_R = 4 model + eigenvalues) of nk k-points, and the stage times of the own path.
 
-    python tools/bench_xl.py [sizes ...]        (GPU box; default 1030 1536 2048)
+    python tools/bench_xl.py [--own] [sizes ...]        (GPU box; default 1030 1536 2048; --own: without the rocSOLVER runs,
+                                                          e.g. under rocprofv3 -- rocSOLVER is tens of thousands of launches)
 """
 import os
 import sys
@@ -14,7 +15,8 @@ import numpy as np  # noqa: E402
 import tbmodels_amd  # noqa: E402
 from tbmodels_amd import synthetic as syn, _lib  # noqa: E402
 
-sizes = [int(x) for x in sys.argv[1:]] or [1030, 1536, 2048]
+own_only = "--own" in sys.argv[1:]
+sizes = [int(x) for x in sys.argv[1:] if x != "--own"] or [1030, 1536, 2048]
 for n in sizes:
     r_vec, hop, pos = syn.dense_model_arrays(n, 4, syn.MODEL_SEED + n)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
@@ -23,7 +25,7 @@ for n in sizes:
         row = "N=%4d nk=%3d " % (n, nk)
         results = {}
         for name, code in (("own", _lib.TBK_EIG_AUTO), ("rocsolver", _lib.TBK_EIG_ROCSOLVER)):
-            if name == "rocsolver" and nk > 64:
+            if name == "rocsolver" and (nk > 64 or own_only):
                 continue
             model.set_option(_lib.TBK_OPT_EIGENSOLVER, code)
             model.eigenval_array(k)
