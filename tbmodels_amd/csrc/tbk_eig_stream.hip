@@ -650,7 +650,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     const int sub = tid % LPE;  // ... and which interior point of the bracket it tests
     const int m_end = min(n, ((int)blockIdx.y + 1) * m_per);
     int cnt_lo = 0, cnt_hi = n;  // Sturm counts at the ends of the bracket
-    if (LPE == 1 && n > 64) {
+    if (n > 64) {  // (with LPE > 1 too: one sweep for log2(n + 1) halvings, against log2(LPE + 1) of a multisection sweep)
         // First round shared by the whole matrix: the n lanes count at n evenly spaced points of the Gershgorin
         // interval, and every lane reads ITS bracket off the (monotone) counts -- log2(n + 1) halvings for one sweep.
         int* scnt = reinterpret_cast<int*>(sde + 2 * n_pad);
@@ -677,7 +677,7 @@ tridiag_bisect_kernel(const double* __restrict__ D, const double* __restrict__ E
     // same trip count for every lane: cut the bracket by LPE + 1 per sweep down to `tol`
     int iters = 2;
     {
-        const double w0 = (LPE == 1 && n > 64) ? (gu - gl + 2.0 * slack) / (n + 1) : hi - lo;
+        const double w0 = (n > 64) ? (gu - gl + 2.0 * slack) / (n + 1) : hi - lo;
         for (double w = w0; w > tol && iters < 1100; w *= 1.0 / (LPE + 1)) ++iters;
     }
 
@@ -846,33 +846,57 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     // last bit.  Small matrices get the lanes their first wave would leave idle anyway (8 orbitals: 8 per eigenvalue).
     const int64_t call_nk = std::max(m->call_nk, nk);
     int lpe = call_nk <= 32 ? 16 : call_nk <= 512 ? 4 : 1;
-    while (lpe < 16 && n * lpe * 2 <= 64) lpe *= 2;
-    while (lpe > 1 && n * lpe > 1024) lpe /= 2;
-    unsigned threads = (unsigned)((n * lpe + 63) / 64 * 64);
-    // a few matrices with several lanes per eigenvalue: up to four workgroups per matrix (each still loads all of (d, e),
-    // so at least n threads), their waves on different CUs
-    unsigned parts = 1;
-    if (lpe > 1)
-        while (parts < 4 && (threads / (parts * 2)) % 64 == 0 && threads / (parts * 2) >= (unsigned)n_pad && n % (int)(parts * 2) == 0) parts *= 2;
-    threads /= parts;
-    if (threads > 1024) {  // above 1024 orbitals (one lane per eigenvalue there): the eigenvalues in `parts` workgroups of <= 1024 lanes
-        parts = (threads + 1023) / 1024;
-        const unsigned per = ((unsigned)n + parts - 1) / parts;  // eigenvalues per workgroup (the kernel's m_per)
-        threads = (per * (unsigned)lpe + 63) / 64 * 64;
+    unsigned threads, parts = 1;
+    static const int lpe_env = getenv("TBK_BISECT_LPE") ? atoi(getenv("TBK_BISECT_LPE")) : 0;  // (measurements: 1, 4 or 16 above 64 orbitals)
+    if (n > 64) {
+        // Above 64 orbitals (round 5): 16 or 4 lanes per eigenvalue at every size, over as many workgroups as that takes (until
+        // round 4 the lanes had to fit ONE workgroup: 4 at 256 orbitals, 2 at 512 -- 31 sweeps where one lane with its secant steps
+        // needs ~20 --, 1 above), while the call stays a few waves per CU: the sweeps are latency chains and idle lanes are free,
+        // busy ones are not.  Measured (tools/bench_single_k.py, us of this stage, 1 / 4 / 16 lanes): one k-point at 256 orbitals
+        // 188 / 160 / 114, at 512 414 / 370 / 244, at 1024 1348 / 1118 / 772; 64 k-points at 512 orbitals 462 / 404 / 800, at 1024
+        // 1410 / 1300 / 3230, at 1536 1.8 / 3.5 ms / --.
+        const int64_t eigenvalues = call_nk * (int64_t)n;
+        if (lpe == 16 && eigenvalues * 16 > (int64_t(1) << 17)) lpe = 4;
+        if (lpe == 4 && eigenvalues * 4 > (int64_t(1) << 18)) lpe = 1;
+        if (lpe_env == 1 || lpe_env == 4 || lpe_env == 16) lpe = lpe_env;
+        if (lpe > 1) {
+            threads = (unsigned)std::min(1024, n_pad);  // (the shared first round: one sweep per thread up to 1024 orbitals)
+            const unsigned per = threads / (unsigned)lpe;  // eigenvalues per workgroup (>= the kernel's m_per = ceil(n / parts))
+            parts = ((unsigned)n + per - 1) / per;
+        } else {
+            threads = (unsigned)n_pad;
+            if (threads > 1024) {  // above 1024 orbitals: the eigenvalues in `parts` workgroups of <= 1024 lanes
+                parts = (threads + 1023) / 1024;
+                const unsigned per = ((unsigned)n + parts - 1) / parts;  // eigenvalues per workgroup (the kernel's m_per)
+                threads = (per + 63) / 64 * 64;
+            }
+        }
+    } else {
+        while (lpe < 16 && n * lpe * 2 <= 64) lpe *= 2;
+        while (lpe > 1 && n * lpe > 1024) lpe /= 2;
+        threads = (unsigned)((n * lpe + 63) / 64 * 64);
+        // a few matrices with several lanes per eigenvalue: up to four workgroups per matrix (each still loads all of (d, e),
+        // so at least n threads), their waves on different CUs
+        if (lpe > 1)
+            while (parts < 4 && (threads / (parts * 2)) % 64 == 0 && threads / (parts * 2) >= (unsigned)n_pad && n % (int)(parts * 2) == 0) parts *= 2;
+        threads /= parts;
     }
-    if (lds > (size_t(64) << 10)) {  // (above ~3270 orbitals the (d, e^2) table and the shared round's counts pass 64 KiB; lpe is 1 there)
-        static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
-        // (96 KiB: 20 bytes per orbital up to 4096 orbitals; the kernel has static LDS beside it, so not the whole 160 KiB)
-        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&tridiag_bisect_kernel<1>), 96 * 1024, raised));
-    }
-#define TBK_BISECT(L) \
-    hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk, parts), dim3(threads), lds, s, d_de, d_e, n, d_E, m->ws_flag.as<int>())
+    // (above ~3270 orbitals the (d, e^2) table and the shared round's counts pass 64 KiB -- 96 KiB: 20 bytes per orbital up to 4096
+    // orbitals; the kernel has static LDS beside it, so not the whole 160 KiB)
+    static std::atomic<bool> raised[5][TBK_MAX_DEVICES] = {};
+#define TBK_BISECT(L, SLOT)                                                                                                        \
+    do {                                                                                                                           \
+        if (lds > (size_t(64) << 10))                                                                                              \
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&tridiag_bisect_kernel<L>), 96 * 1024, raised[SLOT]));       \
+        hipLaunchKernelGGL(tridiag_bisect_kernel<L>, dim3((unsigned)nk, parts), dim3(threads), lds, s, d_de, d_e, n, d_E,         \
+                           m->ws_flag.as<int>());                                                                                  \
+    } while (0)
     switch (lpe) {
-        case 16: TBK_BISECT(16); break;
-        case 8: TBK_BISECT(8); break;
-        case 4: TBK_BISECT(4); break;
-        case 2: TBK_BISECT(2); break;
-        default: TBK_BISECT(1); break;
+        case 16: TBK_BISECT(16, 4); break;
+        case 8: TBK_BISECT(8, 3); break;
+        case 4: TBK_BISECT(4, 2); break;
+        case 2: TBK_BISECT(2, 1); break;
+        default: TBK_BISECT(1, 0); break;
     }
 #undef TBK_BISECT
     TBK_HIP(hipGetLastError());
