@@ -2429,8 +2429,9 @@ band_xl_product_kernel(const double* __restrict__ Hall, int n, const d2* __restr
 template <int NT>
 __global__ void __launch_bounds__(NT, 2)
 band_xl_sweep_kernel(const double* __restrict__ Hsrc_all, double* __restrict__ Hdst_all, int n, const d2* __restrict__ VWall,
-                     const d2* __restrict__ VNall, d2* __restrict__ XYall, int i0, int with_update) {
+                     const d2* __restrict__ VNall, d2* __restrict__ XYall, int i0, int flags) {
     constexpr int NW = NT / 64;
+    const int with_update = flags & 1, walk = flags & 2;
     __shared__ double sTr[NW * 16 * 17];
     __shared__ double sRed[NW * 4 * 64];
     const int lane = threadIdx.x & 63;
@@ -2455,7 +2456,15 @@ band_xl_sweep_kernel(const double* __restrict__ Hsrc_all, double* __restrict__ H
         own.im[sg] = v2[1];
     }
     d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = own1;
-    for (int J = i0 + wave; J < nbk; J += NW) {
+    // The walk: at step t block row I visits its partner (t - I) mod m -- whose workgroup visits I at the same step, so the two
+    // reads of a tile (one per orientation) leave their workgroups at about the same time and the second one finds the tile in a
+    // cache (L2 when both sit on one XCD, the memory-side cache otherwise) instead of in HBM.  (walk == 0: every block row walks
+    // J = i0, i0 + 1, ... -- the two reads of a tile are |I - J| / NW steps apart.)
+    const int m_rows = nbk - i0, I_loc = I - i0;
+    for (int t = wave; t < m_rows; t += NW) {
+        int J_loc = walk ? t - I_loc : t;
+        if (J_loc < 0) J_loc += m_rows;
+        const int J = i0 + J_loc;
         const int Ir = min(I, J), Jc = max(I, J);
         const bool interior = (Ir + 1) * TS <= n && (Jc + 1) * TS <= n;
         const unsigned gc = (unsigned)min(Jc * TS + lrow, n - 1);
@@ -2557,6 +2566,176 @@ band_xl_sweep_kernel(const double* __restrict__ Hsrc_all, double* __restrict__ H
     }
 }
 
+// The sweep of a BATCH (launch_band_xl: enough matrices to fill the chip): every tile crosses HBM TWICE per panel -- read once,
+// written once -- instead of three times.  A workgroup takes FOUR block rows (wave w: row I = i0 + 4 blockIdx.x + w) and walks the
+// block columns J together; a wave reads only the stored orientation tile(I, J), J >= I, updates it, writes it to the new buffer
+// and forms BOTH products from it: X_I += tile Vn_J in its registers (as above) and the part tile^H Vn_I of X_J, which the four
+// waves add up through LDS (one barrier per block column) and leave as this workgroup's partial of X_J in P[blockIdx.x][J].
+// band_xl_xsum_kernel then adds the partials to X in a fixed order (workgroup 0, 1, ...): the same sums on every run.  (PMC, 64
+// matrices of 1536 orbitals: the one-row sweep above reads 1.27 x the two reads of every tile its walk asks for and writes 1 x --
+// 276 GB per call against 155 GB of read-once + write-once; a walk that pairs the two reads of a tile in time -- block row I at
+// step t visits (t - I) mod m -- was slower, 1.248 -> 1.366 ms per k-point: the partner's operand blocks are then different for
+// every workgroup of a matrix.  One-row workgroups stay for calls of a few matrices: four times as many, a quarter as long.)
+template <int NT>
+__global__ void __launch_bounds__(NT, 2)
+band_xl_sweep4_kernel(const double* __restrict__ Hsrc_all, double* __restrict__ Hdst_all, int n, const d2* __restrict__ VWall,
+                      const d2* __restrict__ VNall, d2* __restrict__ XYall, double* __restrict__ Pall, size_t p_stride, int i0,
+                      int with_update) {
+    constexpr int NW = NT / 64;
+    static_assert(NW == 4, "four block rows per workgroup, one per wave; the partial sums are four registers per lane");
+    __shared__ double sTr[NW * 16 * 17];
+    __shared__ double sRed[2 * NW * 4 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const size_t mat = blockIdx.y;
+    const double* Hs = Hsrc_all + mat * (size_t)n * n * 2;
+    double* Hd = Hdst_all + mat * (size_t)n * n * 2;
+    const d2* VW = VWall + mat * (size_t)nbk * 256;
+    const double* VNd = reinterpret_cast<const double*>(VNall + mat * (size_t)npad * PB);
+    double* XYd = reinterpret_cast<double*>(XYall + mat * (size_t)npad * PB);
+    double* Pd = Pall + mat * p_stride + (size_t)blockIdx.x * nbk * 256;  // this workgroup's partials: [block column][16 rows][8 complex]
+    const int I0 = i0 + NW * (int)blockIdx.x;
+    const int I = I0 + wave;
+    const bool row_ok = I < nbk;  // (uniform per wave)
+    const int Ic = min(I, nbk - 1);
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int lane_x = lq * 16 + 2 * (lrow & 7) + (lrow >> 3);
+    const double lane_sgn = (lrow < 8) ? -1.0 : 1.0;
+    double* tr = sTr + wave * (16 * 17);
+    Frag own;
+    double pbi[4];
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+        const d2 v2 = with_update ? VW[((size_t)Ic * 4 + sg) * 64 + lane] : (d2){0.0, 0.0};
+        own.re[sg] = v2[0];
+        own.im[sg] = v2[1];
+        pbi[sg] = (VNd + (size_t)Ic * (TS * 16) + lane_x)[sg * 64];
+    }
+    d4 own1 = (d4){0.0, 0.0, 0.0, 0.0}, own2 = own1;
+    // what a step needs from memory: fetched ONE STEP AHEAD (the tile of step J + 1 is on its way while step J computes -- with
+    // three or fewer waves per SIMD nothing else covers the latency of HBM)
+    struct StepIn {
+        d4 tre, tim;
+        double pb[4];
+        Frag par;
+    };
+    auto fetch = [&](int J, StepIn& in) {
+        const bool interior = (I + 1) * TS <= n && (J + 1) * TS <= n;
+        const unsigned gc = (unsigned)min(J * TS + lrow, n - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned gr = (unsigned)min(I * TS + lq + 4 * r, n - 1);
+            const d2 v2 = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(Hs) + (size_t)gr * (size_t)n * 16 + (size_t)gc * 16);
+            const bool inside = interior || (I * TS + lq + 4 * r < n && J * TS + lrow < n);
+            in.tre[r] = inside ? v2[0] : 0.0;
+            in.tim[r] = inside ? v2[1] : 0.0;
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) in.pb[sg] = (VNd + (size_t)J * (TS * 16) + lane_x)[sg * 64];
+        if (with_update) {
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const d2 v2 = VW[((size_t)J * 4 + sg) * 64 + lane];
+                in.par.re[sg] = v2[0];
+                in.par.im[sg] = v2[1];
+            }
+        }
+    };
+    auto step = [&](int J, StepIn& cur, StepIn& nxt) {
+        const int buf = (J - I0) & 1;
+        if (row_ok && J + 1 >= I && J + 1 < nbk) fetch(J + 1, nxt);  // (uniform per wave)
+        d4 t1 = (d4){0.0, 0.0, 0.0, 0.0}, t2 = t1;
+        if (row_ok && J >= I) {  // (uniform per wave)
+            const bool interior = (I + 1) * TS <= n && (J + 1) * TS <= n;
+            d4 tre = cur.tre, tim = cur.tim;
+            if (with_update) {  // tile(I, J) -= [V | W]_I ([W | V]_J)^H
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int sb = (sg + 2) & 3;
+                    tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], cur.par.re[sb], tre, 0, 0, 1);
+                    tre = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], cur.par.im[sb], tre, 0, 0, 1);
+                    tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.im[sg], cur.par.re[sb], tim, 0, 0, 1);
+                    tim = __builtin_amdgcn_mfma_f64_16x16x4f64(own.re[sg], cur.par.im[sb], tim, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = I * TS + lq + 4 * r;
+                if (interior || (gr < n && J * TS + lrow < n))
+                    *reinterpret_cast<d2*>(reinterpret_cast<char*>(Hd) + (size_t)gr * (size_t)n * 16 + (size_t)(J * TS + lrow) * 16) = (d2){tre[r], tim[r]};
+            }
+            double ttre[4], ttim[4];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tre[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) ttre[sg] = tr[lrow * 17 + lq + 4 * sg];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lrow] = tim[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) ttim[sg] = tr[lrow * 17 + lq + 4 * sg];
+            asm volatile("" ::: "memory");
+            if (J == I) {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const bool upper = lrow <= lq + 4 * sg;
+                    const double ar = upper ? ttre[sg] : tre[sg];
+                    const double ai = upper ? ttim[sg] : -tim[sg];
+                    own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, cur.pb[sg], own1, 0, 0, 0);
+                    own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, cur.pb[sg], own2, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    own1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttre[sg], cur.pb[sg], own1, 0, 0, 0);
+                    own2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ttim[sg], cur.pb[sg], own2, 0, 0, 0);
+                    // ... and this tile's part of X_J: tile^H Vn_I (the registers as they were loaded ARE the transposed operand)
+                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tre[sg], pbi[sg], t1, 0, 0, 0);
+                    t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tim[sg], pbi[sg], t2, 0, 0, 1);  // conj
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sRed[((buf * NW + wave) * 4 + r) * 64 + lane] = fma(dpp_mov<0x128>(t2[r]), lane_sgn, t1[r]);
+        lds_fence();
+        __syncthreads();  // (one per block column: a wave that runs ahead writes the OTHER area, and cannot pass the next barrier alone)
+        {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += sRed[((buf * NW + w) * 4 + wave) * 64 + lane];
+            (Pd + (size_t)J * 256 + lane_x)[wave * 64] = tot;
+        }
+    };
+    StepIn in_a, in_b;
+    if (row_ok && I0 >= I) fetch(I0, in_a);  // (wave 0; the others fetch their first tile in the step before it)
+    for (int J = I0; J < nbk; J += 2) {
+        step(J, in_a, in_b);
+        if (J + 1 < nbk) step(J + 1, in_b, in_a);
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (XYd + (size_t)I * (TS * 16) + lane_x)[r * 64] = fma(dpp_mov<0x128>(own2[r]), lane_sgn, own1[r]);
+    }
+}
+
+// X_J += the partials of the workgroups 0 .. (J - i0) / 4 of band_xl_sweep4_kernel, in that order (grid: block columns x matrices)
+__global__ void __launch_bounds__(256)
+band_xl_xsum_kernel(d2* __restrict__ XYall, const double* __restrict__ Pall, size_t p_stride, int n, int i0) {
+    const int nbk = (n + TS - 1) / TS, npad = nbk * TS;
+    const size_t mat = blockIdx.y;
+    const int J = i0 + (int)blockIdx.x;
+    double* X = reinterpret_cast<double*>(XYall + mat * (size_t)npad * PB) + (size_t)J * 256 + threadIdx.x;
+    const double* P = Pall + mat * p_stride + (size_t)J * 256 + threadIdx.x;
+    double acc = *X;
+    const int last = (J - i0) / 4;
+    for (int g = 0; g <= last; ++g) acc += P[(size_t)g * nbk * 256];
+    *X = acc;
+}
+
 // the band rows from row0 on out of a matrix buffer (the one-sweep chain: the rows behind the last panel), and the whole band back
 // INTO the caller's matrix buffer (tbk_tridiagonal_reduce hands that buffer out as the work copy of the reduction)
 __global__ void __launch_bounds__(256) band_extract_from_kernel(const double* __restrict__ Hall, int n, d2* __restrict__ band_all, size_t band_stride, int row0) {
@@ -2590,7 +2769,18 @@ static bool band_xl(int n) {
     return n > from;
 }
 // the second matrix buffer of the chain (ws_xl), per matrix of a chunk: only the sizes that ALWAYS take the chain count for the chunk size
-size_t tbk_band_xl_buffer_per_matrix(int n) { return band_xl(n) ? (size_t)n * n * sizeof(d2) : 0; }
+// (+ the partial sums of band_xl_sweep4_kernel: [workgroups = block rows / 4][block columns][16 x 8 complex])
+static size_t xl_partial_doubles(int n) {
+    const size_t nbk = (size_t)((n + TS - 1) / TS);
+    return (nbk + 3) / 4 * nbk * 256;
+}
+static bool xl_sweep4() {
+    static const bool on = getenv("TBK_BAND_XL_SWEEP4") && atoi(getenv("TBK_BAND_XL_SWEEP4")) != 0;
+    return on;
+}
+size_t tbk_band_xl_buffer_per_matrix(int n) {
+    return band_xl(n) ? (size_t)n * n * sizeof(d2) + (xl_sweep4() ? xl_partial_doubles(n) * sizeof(double) : 0) : 0;
+}
 // (+ for the launch chain of band_xl_*: X / the panel's rows [npad][8] and T of the panel)
 size_t tbk_band_scratch_per_matrix(int n) {
     const size_t nbk = (size_t)((n + TS - 1) / TS);
@@ -2756,8 +2946,14 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     // One sweep per panel between two matrix buffers (the caller's and ws_xl) that change roles; the finished rows go to the band
     // as the serial phases produce them, the rows behind the last panel come out of the buffer the last update leaves them in,
     // and the band is put back into the caller's buffer (the work copy tbk_tridiagonal_reduce hands out).
-    TBK_CHECK(m->ws_xl.reserve((size_t)nk * n * n * 2 * sizeof(double)));
+    // TBK_BAND_XL_SWEEP4=1 (measurements): band_xl_sweep4_kernel -- every tile read once, four block rows per workgroup -- for every
+    // call of the process.  Built in round 5 and not faster (DESIGN_LOG.md R5.12: 64 / 256 matrices of 1536 orbitals 1.256 -> 1.288 /
+    // 0.940 -> 0.893 ms per k-point, of 2048 orbitals 2.585 -> 2.637 / 2.195 -> 2.214): the one-row sweep stays.
+    const bool sweep4 = xl_sweep4();
+    const size_t p_stride = xl_partial_doubles(n);
+    TBK_CHECK(m->ws_xl.reserve((size_t)nk * n * n * 2 * sizeof(double) + (sweep4 ? (size_t)nk * p_stride * sizeof(double) : 0)));
     double* buf[2] = {d_H, m->ws_xl.as<double>()};
+    double* d_P = m->ws_xl.as<double>() + (size_t)nk * n * n * 2;
     // up to 1024 orbitals (calls of a few matrices): the panel's rows in LDS (TBK_BAND_XL_YLDS=0: in global memory, as above 1024)
     static const bool y_lds_env = !(getenv("TBK_BAND_XL_YLDS") && atoi(getenv("TBK_BAND_XL_YLDS")) == 0);
     const bool y_lds = y_lds_env && n <= BAND_ONE_WG_MAXN;
@@ -2771,6 +2967,8 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     // stage is one workgroup per matrix for 2 n ticks -- one group's chains run under the other groups' sweeps.  Per matrix nothing
     // changes (same launches, same order, same bits).
     const int groups = xl_groups(n, nk);
+    // TBK_BAND_XL_WALK=1 (measurements): the pairing walk of band_xl_sweep_kernel
+    static const int walk_flag = (getenv("TBK_BAND_XL_WALK") && atoi(getenv("TBK_BAND_XL_WALK")) != 0) ? 2 : 0;
     auto chain = [&](hipStream_t st, int64_t k0, int64_t nkg) {
         double* b[2] = {buf[0] + (size_t)k0 * n * n * 2, buf[1] + (size_t)k0 * n * n * 2};
         d2* vw = d_VW + (size_t)k0 * nbk * 256;
@@ -2788,8 +2986,15 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
                                    stride);
             if (p == p_end) break;
             const int i0 = PB * (p + 1) / TS, na = nbk - i0;
-            hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nkg), dim3(NTP), 0, st, b[cur], b[cur ^ 1], n, vw, vn, xy,
-                               i0, p > 0 ? 1 : 0);
+            if (sweep4) {
+                hipLaunchKernelGGL((band_xl_sweep4_kernel<NTP>), dim3((unsigned)((na + 3) / 4), (unsigned)nkg), dim3(NTP), 0, st, b[cur], b[cur ^ 1],
+                                   n, vw, vn, xy, d_P + (size_t)k0 * p_stride, p_stride, i0, p > 0 ? 1 : 0);
+                hipLaunchKernelGGL(band_xl_xsum_kernel, dim3((unsigned)na, (unsigned)nkg), dim3(256), 0, st, xy, d_P + (size_t)k0 * p_stride,
+                                   p_stride, n, i0);
+            } else {
+                hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nkg), dim3(NTP), 0, st, b[cur], b[cur ^ 1], n, vw, vn,
+                                   xy, i0, (p > 0 ? 1 : 0) | walk_flag);
+            }
             cur ^= 1;
         }
         if (p_end > 0) {  // the last pending update, in place (nobody reads tiles in this launch)

@@ -635,6 +635,46 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
+def test_the_read_once_sweep_above_1024_orbitals_stays_correct():
+    """``TBK_BAND_XL_SWEEP4=1`` (a measurement switch, read once per process -- hence the child process): the panels' sweeps run four
+    block rows per workgroup, every tile is read once and the transposed products are added up through partial sums
+    (csrc/tbk_eig_band.hip, band_xl_sweep4_kernel + band_xl_xsum_kernel; DESIGN_LOG.md R5.12: built, not faster, off by default).
+    Same function as the one-row sweep: the spectra are those of the matrices (scipy's eigvalsh at _tb_model.py:1149), two runs
+    give the same bits (the partial sums are added in a fixed order)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import numpy as np, scipy.linalg as la
+from tbmodels_amd import _lib
+lib = _lib.lib()
+n, nk = 1040, 9
+rng = np.random.default_rng(78)
+m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+h = np.ascontiguousarray((m + m.conj().transpose(0, 2, 1)) / 2)
+h[5] *= 1e-25
+h[6] = np.diag(np.diagonal(h[6]).real)
+out = []
+for rep in range(2):
+    d, e = np.empty((nk, n)), np.empty((nk, n))
+    _lib.check(lib.tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(h), _lib.TBK_REDUCE_AUTO, _lib.ptr(d), _lib.ptr(e), None))
+    out.append((d, e))
+assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+d, e = out[0]
+assert np.isfinite(d).all() and np.isfinite(e).all()
+for i in (0, 5, 6, 8):
+    ref = np.linalg.eigvalsh(h[i])
+    got = la.eigvalsh_tridiagonal(d[i], e[i, :-1])
+    assert np.abs(got - ref).max() <= 1e-13 * n * np.abs(ref).max(), i
+print("ok")
+"""
+    env = dict(os.environ, TBK_BAND_XL_SWEEP4="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stderr[-2000:]
+
+
 def test_a_batch_above_1024_orbitals_in_groups_equals_its_matrices_one_at_a_time():
     """Above 1024 orbitals a batch goes in groups of matrices on streams of their own (csrc/tbk_eig_band.hip, launch_band_xl:
     one group's serial phases and second stage under the other groups' sweeps).  Per matrix nothing may change: (d, e) and the

@@ -16,11 +16,12 @@ import tbmodels_amd  # noqa: E402
 from tbmodels_amd import synthetic as syn, _lib  # noqa: E402
 
 own_only = "--own" in sys.argv[1:]
-sizes = [int(x) for x in sys.argv[1:] if x != "--own"] or [1030, 1536, 2048]
+batches = (64,) if "--nk64" in sys.argv[1:] else (1, 8, 64, 256)  # (--nk64: one batch size, for profiler runs)
+sizes = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [1030, 1536, 2048]
 for n in sizes:
     r_vec, hop, pos = syn.dense_model_arrays(n, 4, syn.MODEL_SEED + n)
     model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
-    for nk in (1, 8, 64, 256):
+    for nk in batches:
         k = syn.random_kpoints(nk)
         row = "N=%4d nk=%3d " % (n, nk)
         results = {}
