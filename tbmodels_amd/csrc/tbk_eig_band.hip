@@ -1893,18 +1893,22 @@ __global__ void __launch_bounds__(256) band_extract_kernel(const double* __restr
 // ================================================================================================
 // stage 1 ABOVE 1024 orbitals (round 5): the same algorithm as a chain of launches with nothing per row in
 // registers or LDS.  The kernels above keep a row of the panel per thread (two at most) and X = A V in LDS
-// ([npad][8] complex: 128 KiB at 1024 orbitals) -- neither scales.  Here every panel is three launches:
+// ([npad][8] complex: 128 KiB at 1024 orbitals) -- neither scales.  Here every panel is two launches:
 //   band_xl_serial_kernel   one workgroup per matrix: the W phase of the previous panel, then look-ahead, panel QR from
 //                           ONE Gram matrix (the GRAM2 form: the panel's rows in the X / Y buffer in GLOBAL memory, one
 //                           row at a time through the registers, matrix instructions reading the [row][8] layout where
-//                           it lies) and the T factor;
-//   band_xl_update_kernel   a workgroup per block row I of the trailing matrix: tile(I, J) -= [V | W]_I ([W | V]_J)^H, J >= I;
-//   band_xl_product_kernel  a workgroup per block row I: X_I = sum_J tile(I, J) Vn_J over ALL J -- the tiles left of the
-//                           diagonal read as the transposed stored ones -- so every block of X has ONE owner, complete in
-//                           registers: no partner sums, no LDS for X, any number of rows.  (Every tile is read twice: 1.5 x
-//                           the tile traffic of the one-pass form.)
-// Stream order is the only synchronisation between them.  Same arithmetic as the kernels above (tools/two_stage_model.py:
-// panel_qr_gram, stage1_band); band_extract_kernel, the global-memory chase and the bisection follow.
+//                           it lies) and the T factor; the finished entries of the block row go straight to the compact band;
+//   band_xl_sweep_kernel    a workgroup per block row I of the trailing matrix walks ALL tiles of that row -- the ones left of
+//                           the diagonal as the transposed stored tiles -- reads them from the OLD matrix buffer, applies the
+//                           pending update tile(I, J) -= [V | W]_I ([W | V]_J)^H in registers, adds tile Vn_J to ITS block of X
+//                           (one owner per block of X, complete in registers: no partner sums, no LDS for X, any number of
+//                           rows) and writes the stored orientation to the NEW buffer.  Every tile is read twice and written
+//                           once per panel.
+// (band_xl_update_kernel + band_xl_product_kernel: the same as two sweeps on ONE buffer -- the first form, TBK_BAND_XL_SWEEPS=2,
+// and the last pending update of the chain; band_xl_sweep4_kernel + band_xl_xsum_kernel: every tile read once, measured, off.)
+// Stream order is the only synchronisation between them; a batch goes in two groups of matrices on two streams.  Same
+// arithmetic as the kernels above (tools/two_stage_model.py: panel_qr_gram, stage1_band); the global-memory chase and the
+// bisection follow.
 // ================================================================================================
 // YL: the panel's rows live in LDS ([npad][8] complex of dynamic LDS: up to 1024 orbitals) instead of the X / Y buffer in global
 // memory -- what the calls of a few matrices take: for ONE matrix every hand-over of the rows through global memory (look-ahead ->
