@@ -550,6 +550,313 @@ band_chase4g_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
     chase4_body<NW, false, 1, true>(band, nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n, band + (size_t)n * (PB + 1));
 }
 
+// Above 512 orbitals, calls of a few matrices (round 5): the working diagonals in a CYCLIC WINDOW of 512 columns in LDS in front of
+// the global buffer of band_chase4g_kernel.  With the diagonals in global memory a tick is two memory round trips (the loads,
+// then the wait for the stores before the barrier) around a ~1.3 us chain: 3.0 - 3.3 us against the 1.5 us of the LDS form.  But the
+// 32 sweeps in flight only ever touch ~490 consecutive columns: sweep s runs in slot s % 32, the sweeps of generation g = s / 32
+// follow each other 15 columns apart, and the first sweep of generation g + 1 starts at the top when the first sweep of
+// generation g has reached the bottom -- so generation g + 1 sees column j at window column (j + off[g + 1]) mod 512 with
+// off[g + 1] = off[g] + (n + 8 - 32 (g + 1)): its top follows the bottom of generation g in the window as it does in time.  A
+// column enters the window the tick before the generation's first sweep needs it (one element per thread, fetched at the start
+// of the tick, stored to LDS at its end) and leaves the tick after the generation's last sweep touched it; from the first
+// generation whose columns all fit (n + 8 - 32 g <= 512) on nothing leaves any more.  A slot of a generation that leaves is taken
+// again no sooner than 68 ticks after it started, so that a column is back in global memory before the next generation fetches it.
+// tools/two_stage_model.py: stage2_window is this scheme with an occupancy tag per window column (every access finds ITS
+// column, a column only enters a free cell; tests/test_two_stage_model.py).  Same arithmetic per sweep as chase4_body: the same bits.
+constexpr int CW = 512, CWP = 521, CW_SLOTS = 32, CW_GAP = 2 * CW_SLOTS + 4;
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np, double* __restrict__ D, double* __restrict__ E) {
+    static_assert(4 * NW == CW_SLOTS, "eight waves of four sweeps");
+    extern __shared__ __attribute__((aligned(16))) double bw_smem[];
+    constexpr int NSLOT = CW_SLOTS;
+    const size_t mat = blockIdx.x;
+    const d2* band = band_all + mat * band_stride;
+    d2* gband = band_all + mat * band_stride + (size_t)n * (PB + 1);  // [16][np], element (i, j) at (i - j) np + j
+    double* Dm = D + mat * (size_t)n;
+    double* Em = E + mat * (size_t)n;
+    d2* win = reinterpret_cast<d2*>(bw_smem);            // [16][CWP]
+    d2* sScr = win + (size_t)16 * CWP;                   // [NW][4 slots][16]
+    int* sStart = reinterpret_cast<int*>(sScr + NW * 64);  // [n]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 7, h = (lane >> 3) & 1, g = lane >> 4;
+    d2* scr = sScr + (wave * 4 + g) * 16;
+    const int NE = n + PB;
+    const int n_sweeps = n - 2;
+    const int g_res = NE > CW ? (NE - CW + NSLOT - 1) / NSLOT : 0;  // first generation whose columns all fit the window
+    auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };
+    auto off_of = [&](int gen) {
+        const int m = min(gen, g_res);
+        return (m * NE - (NSLOT / 2) * m * (m + 1)) & (CW - 1);
+    };
+
+    for (int i = tid; i < 16 * np; i += NW * 64) gband[i] = (d2){0.0, 0.0};
+    for (int i = tid; i < 16 * CWP; i += NW * 64) win[i] = (d2){0.0, 0.0};
+    wg_sync();
+    for (int i = tid; i < n * (PB + 1); i += NW * 64) {
+        const int j = i / (PB + 1), dd = i % (PB + 1);
+        if (j + dd < n) {
+            const d2 v = band[i];
+            gband[(size_t)dd * np + j] = (d2){v[0], -v[1]};
+        }
+    }
+    if (tid == 0) {
+        for (int s = 0; s < n_sweeps; ++s) {
+            int t0 = 0;
+            if (s > 0) t0 = sStart[s - 1] + 2;
+            if (s >= NSLOT) {
+                const int prev = s - NSLOT;
+                const int len = sweep_len(prev);
+                t0 = max(t0, sStart[prev] + (prev / NSLOT < g_res ? max(len, CW_GAP) : len));
+            }
+            sStart[s] = t0;
+        }
+    }
+    wg_sync();
+    if (n_sweeps > 0) {
+        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
+        const int n_gen = (n_sweeps + NSLOT - 1) / NSLOT;
+        const int last_fetch_gen = min(g_res, n_gen - 1);
+        // the columns generation 0 needs at tick 0
+        for (int e = tid; e < 9 * 16; e += NW * 64) {
+            const int j = e >> 4, dd = e & 15;
+            if (j < NE) win[dd * CWP + j] = j < n ? gband[(size_t)dd * np + j] : (d2){0.0, 0.0};
+        }
+        wg_sync();
+        // per lane and column c: diagonal (row of the window) and column offset inside the block
+        int wd[4], wb[4];   // window rows (x CWP) of the D and Bk elements
+        int cd[4], cb[4];   // their columns relative to r0
+        bool d_low[4];
+        double d_imf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int b = 4 * h + c;
+            wd[c] = abs(a - b) * CWP;
+            cd[c] = min(a, b);
+            wb[c] = (PB + a - b) * CWP;
+            cb[c] = b;
+            d_imf[c] = a < b ? -1.0 : (a == b ? 0.0 : 1.0);
+            d_low[c] = a >= b;
+        }
+        const int wx = (PB + a) * CWP;  // first column of the block below, row a
+        int sw = wave * 4 + g;
+        int off = 0;  // this slot's generation offset
+        int k = -1, k_len = 0;
+        d2 va = (d2){0.0, 0.0}, tau = va;
+        d2 vb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vb[c] = va;
+        auto reflector = [&](d2 xa, const d2 (&xb)[4], d2 alpha, d2& o_va, d2 (&o_vb)[4], d2& o_tau, double& o_beta) {
+            const double sigma = sum_a8(a >= 1 ? xa[0] * xa[0] + xa[1] * xa[1] : 0.0);
+            o_tau = (d2){0.0, 0.0};
+            o_beta = alpha[0];
+            o_va = (a == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o_vb[c] = (4 * h + c == 0) ? (d2){1.0, 0.0} : (d2){0.0, 0.0};
+            const bool trivial = (sigma == 0.0 && alpha[1] == 0.0);
+            const double norm2 = trivial ? 1.0 : alpha[0] * alpha[0] + alpha[1] * alpha[1] + sigma;
+            double root, rroot;
+            fast_sqrt_rsqrt(norm2, root, rroot);
+            const double beta = -copysign(root, alpha[0]);
+            const double rbeta = -copysign(rroot, alpha[0]);
+            const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+            const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+            const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+            if (!trivial) {
+                o_tau = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                o_beta = beta;
+                if (a != 0) o_va = cmul(xa, scale);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * h + c != 0) o_vb[c] = cmul(xb[c], scale);
+            }
+        };
+        // (uniform) trackers of the columns that enter and leave
+        int g_in = 0, t0_in = 0;       // generation whose first sweep leads, its first tick
+        int s_ev = 0;                  // next sweep whose own column leaves (generations that leave only)
+        int g_out = 0;                 // generation whose last sweep trails
+
+        for (int tick = 0; tick < total_ticks; ++tick) {
+            // ---- columns that enter for tick + 1: fetched now, stored to the window at the end of this tick ----
+            int pf_idx = -1;
+            d2 pf_val = (d2){0.0, 0.0};
+            {
+                const int nt = tick + 1;
+                if (g_in < last_fetch_gen && nt >= sStart[NSLOT * (g_in + 1)]) {
+                    ++g_in;
+                    t0_in = sStart[NSLOT * g_in];
+                }
+                const int kk = nt - t0_in;
+                if (kk >= 0 && g_in <= last_fetch_gen) {
+                    const int base = NSLOT * g_in;
+                    const int j_lo = kk == 0 ? base : base + 1 + PB * kk;
+                    const int j_hi = min(base + 9 + PB * kk, NE);
+                    const int j = j_lo + (tid >> 4), dd = tid & 15;
+                    if (j < j_hi) {
+                        pf_idx = dd * CWP + ((j + off_of(g_in)) & (CW - 1));
+                        if (j < n) pf_val = gband[(size_t)dd * np + j];
+                    }
+                }
+            }
+            // ---- columns that leave: untouched since the last tick ----
+            if (s_ev < NSLOT * g_res && s_ev < n_sweeps && sStart[s_ev] + 1 == tick) {
+                if (tid >= 384 && tid < 400) {
+                    const int dd = tid - 384;
+                    gband[(size_t)dd * np + s_ev] = win[dd * CWP + ((s_ev + off_of(s_ev / NSLOT)) & (CW - 1))];
+                }
+                ++s_ev;
+            }
+            if (g_out < g_res) {
+                const int s_l = NSLOT * g_out + NSLOT - 1;
+                const int ks = tick - 1 - sStart[s_l];
+                if (ks >= 0) {
+                    const int j_lo = s_l + 1 + PB * ks;
+                    if (j_lo >= NE) {
+                        ++g_out;
+                    } else if (tid >= 256 && tid < 384) {
+                        const int j = j_lo + ((tid - 256) >> 4), dd = tid & 15;
+                        if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + ((j + off_of(g_out)) & (CW - 1))];
+                    }
+                }
+            }
+
+            const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
+            if (__any(starting)) {
+                const int j = starting ? sw : 0;
+                const int vj = (j + off) & (CW - 1);
+                const d2 xa = win[(1 + a) * CWP + vj];
+                d2 xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[c] = win[(1 + 4 * h + c) * CWP + vj];
+                const d2 alpha = win[CWP + vj];
+                d2 n_va, n_vb[4], n_tau;
+                double beta;
+                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
+                lds_fence();
+                if (starting) {
+                    va = n_va;
+                    tau = n_tau;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                    k = 0;
+                    k_len = sweep_len(sw);
+                    if (h == 0 && j + 1 + a < n) win[(1 + a) * CWP + vj] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                }
+            }
+            const bool active = k >= 0;
+            if (__any(active)) {
+                const int r0 = active ? sw + 1 + PB * k : 0;
+                const int v0 = r0 + off;
+                int id[4], ib[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    id[c] = wd[c] + ((v0 + cd[c]) & (CW - 1));
+                    ib[c] = wb[c] + ((v0 + cb[c]) & (CW - 1));
+                }
+                const int ix = wx + (v0 & (CW - 1));
+                d2 dv[4], bk[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dv[c] = win[id[c]];
+                    bk[c] = win[ib[c]];
+                }
+                const d2 bk0a = win[ix];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dv[c][1] *= d_imf[c];
+                d2 ya = (d2){0.0, 0.0}, ua = ya;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    cfma(ya, dv[c], vb[c]);
+                    cfma(ua, bk[c], vb[c]);
+                }
+                ya[0] += dpp_mov<0x128>(ya[0]);
+                ya[1] += dpp_mov<0x128>(ya[1]);
+                ua[0] += dpp_mov<0x128>(ua[0]);
+                ua[1] += dpp_mov<0x128>(ua[1]);
+                const d2 tu = cmul(tau, ua);
+                const d2 xa = (d2){bk0a[0] - tu[0], bk0a[1] - tu[1]};
+                const double rho = sum_a8(va[0] * ya[0] + va[1] * ya[1]);
+                const double f = -0.5 * (tau[0] * tau[0] + tau[1] * tau[1]) * rho;
+                d2 wa = cmul(tau, ya);
+                wa[0] = fma(f, va[0], wa[0]);
+                wa[1] = fma(f, va[1], wa[1]);
+                asm volatile("" ::: "memory");
+                if (h == 0) {
+                    scr[a] = wa;
+                    scr[8 + a] = xa;
+                }
+                asm volatile("" ::: "memory");
+                d2 wbv[4], xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    wbv[c] = scr[4 * h + c];
+                    xb[c] = scr[8 + 4 * h + c];
+                }
+                const d2 alpha = scr[8];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d2 dn = dv[c];
+                    cfnmac(dn, va, wbv[c]);
+                    cfnmac(dn, wa, vb[c]);
+                    if (active && d_low[c] && r0 + a < n) win[id[c]] = dn;
+                }
+                d2 bn[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bn[c] = bk[c];
+                    cfnmac(bn[c], tu, vb[c]);
+                }
+                d2 n_va, n_vb[4], n_tau;
+                double beta;
+                reflector(xa, xb, alpha, n_va, n_vb, n_tau, beta);
+                const d2 ctau2 = conjd(n_tau);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const d2 zc = sum_a2(cmulc(bn[c], n_va));
+                    const d2 f2 = cmul(ctau2, zc);
+                    cfma(bn[c], (d2){-n_va[0], -n_va[1]}, f2);
+                    if (4 * h + c == 0) bn[c] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                    if (active && r0 + PB + a < n && r0 + 4 * h + c < n) win[ib[c]] = bn[c];
+                }
+                va = n_va;
+                tau = n_tau;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
+                if (active) {
+                    if (++k == k_len) {
+                        k = -1;
+                        sw += NSLOT;
+                        off = off_of(sw / NSLOT);
+                    }
+                }
+            }
+            if (pf_idx >= 0) win[pf_idx] = pf_val;
+            wg_sync();
+        }
+        // what stayed in the window goes back
+        {
+            const int base = NSLOT * g_res, off_r = off_of(g_res);
+            for (int e = tid; e < (n - base) * 16; e += NW * 64) {
+                const int j = base + (e >> 4), dd = e & 15;
+                gband[(size_t)dd * np + j] = win[dd * CWP + ((j + off_r) & (CW - 1))];
+            }
+        }
+    }
+    wg_sync();
+    for (int j = tid; j < n; j += NW * 64) {
+        Dm[j] = gband[j][0];
+        double e = 0.0;
+        if (j + 1 < n) {
+            const d2 v = gband[(size_t)np + j];
+            e = sqrt(v[0] * v[0] + v[1] * v[1]);
+        }
+        Em[j] = e;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
@@ -3108,6 +3415,18 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
     const int n = m->n_orb;
     if (chase_global(n)) {
         const int np = chase_pitch(n);
+        // Calls of a few matrices (a workgroup per CU at most): the working diagonals in a cyclic LDS window in front of the global
+        // buffer (band_chase4w_kernel; the same bits).  TBK_CHASE_WINDOW=0: off (measurements).
+        static const bool window_env = !(getenv("TBK_CHASE_WINDOW") && atoi(getenv("TBK_CHASE_WINDOW")) == 0);
+        if (window_env && std::max<int64_t>(m->call_nk, nk) <= 256) {
+            const size_t ldsw = (size_t)16 * CWP * 16 + (size_t)8 * 64 * 16 + (size_t)n * sizeof(int) + 16;
+            static std::atomic<bool> raised_w[TBK_MAX_DEVICES] = {};
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<8>), 160 * 1024, raised_w));
+            hipLaunchKernelGGL(band_chase4w_kernel<8>, dim3((unsigned)nk), dim3(512), ldsw, s, static_cast<d2*>(const_cast<void*>(d_band)),
+                               tbk_band_bytes_per_matrix(n) / sizeof(d2), n, np, d_D, d_E);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
         // 32 sweeps in flight, two steps apart, from 512 orbitals on (a sweep is n / 8 >= 64 steps long); 16 below
         static const int env_nwg = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
         // (TBK_CHASE_NW=12, round 5: twelve waves = 48 sweeps in flight for calls of a few matrices -- measured: one-k eigenval

@@ -635,6 +635,55 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
+@pytest.mark.parametrize("n", [513, 600, 777, 1030, 1300])
+def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n):
+    """Above 512 orbitals the 16 working diagonals of the second stage do not fit the LDS; calls of a few matrices keep the ~490
+    columns the 32 sweeps in flight touch in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band.hip,
+    band_chase4w_kernel; tools/two_stage_model.py: stage2_window), larger calls work in global memory (band_chase4g_kernel, also
+    ``TBK_CHASE_WINDOW=0`` -- read once per process, hence the child).  The same sweeps in another schedule: (d, e) agree bit for
+    bit, and the spectra are the matrices' (scipy's eigvalsh at _tb_model.py:1149)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import scipy.linalg as la
+
+    from tbmodels_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys
+import numpy as np
+from tbmodels_amd import _lib
+n, out = int(sys.argv[1]), sys.argv[2]
+rng = np.random.default_rng(4000 + n)
+m = rng.standard_normal((3, n, n)) + 1j * rng.standard_normal((3, n, n))
+h = np.ascontiguousarray((m + m.conj().transpose(0, 2, 1)) / 2)
+h[1] *= 1e-20
+h[2, : n // 2, n // 2 :] = 0.0
+h[2, n // 2 :, : n // 2] = 0.0
+d, e = np.empty((3, n)), np.empty((3, n))
+_lib.check(_lib.lib().tbk_tridiagonal_reduce(0, n, 3, _lib.ptr(h), _lib.TBK_REDUCE_AUTO, _lib.ptr(d), _lib.ptr(e), None))
+np.savez(out, d=d, e=e, h=h)
+"""
+    with tempfile.TemporaryDirectory() as tmp:
+        got = {}
+        for label, window in (("window", "1"), ("global", "0")):
+            out = os.path.join(tmp, label + ".npz")
+            env = dict(os.environ, TBK_CHASE_WINDOW=window, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            run = subprocess.run([sys.executable, "-c", code, str(n), out], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+            assert run.returncode == 0, run.stderr[-2000:]
+            got[label] = np.load(out)
+    assert np.array_equal(got["window"]["d"], got["global"]["d"]) and np.array_equal(got["window"]["e"], got["global"]["e"])
+    d, e, h = got["window"]["d"], got["window"]["e"], got["window"]["h"]
+    assert np.isfinite(d).all() and np.isfinite(e).all()
+    for i in range(3):
+        ref = np.linalg.eigvalsh(h[i])
+        assert np.abs(la.eigvalsh_tridiagonal(d[i], e[i, :-1]) - ref).max() <= 1e-13 * n * np.abs(ref).max(), i
+    assert _lib is not None
+
+
 def test_the_read_once_sweep_above_1024_orbitals_stays_correct():
     """``TBK_BAND_XL_SWEEP4=1`` (a measurement switch, read once per process -- hence the child process): the panels' sweeps run four
     block rows per workgroup, every tile is read once and the transposed products are added up through partial sums

@@ -168,3 +168,40 @@ def test_gram_panel_qr_returns_the_factors_of_the_sequential_one():
     full = np.zeros((50, model.B), dtype=complex)
     full[:model.B] = np.triu(r)
     assert np.abs(q @ full - y).max() < 1e-12 and np.abs(q.conj().T @ q - np.eye(50)).max() < 1e-13
+
+
+@pytest.mark.parametrize("n, slots, window", [(40, 4, 80), (100, 4, 80), (150, 4, 79), (133, 3, 64), (200, 8, 140), (97, 2, 52)])
+def test_second_stage_in_a_cyclic_window_equals_the_pipelined_chase(n, slots, window):
+    """``stage2_window``: the working diagonals of the second stage in a cyclic window of columns in front of a backing store
+    (csrc/tbk_eig_band.hip, band_chase4w_kernel: 512 columns of LDS in front of global memory, for more orbitals than the LDS
+    holds).  The model carries an occupancy tag per window column and asserts that every access finds ITS column and that a
+    column only enters a free cell; the tridiagonal equals the pipelined chase's bit for bit (the same sweeps, another
+    schedule), and its spectrum is the matrix' (scipy's eigvalsh at _tb_model.py:1149)."""
+    rng = np.random.default_rng(n)
+    m = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    h = (m + m.conj().T) / 2
+    band, _ = model.stage1_band(h)
+    d0, e0, _ = model.stage2_pipelined(band, 2, slots)
+    d1, e1, ticks = model.stage2_window(band, slots, window)
+    assert np.array_equal(d0, d1) and np.array_equal(e0, e1)
+    assert model.stage2_window.peak_columns <= window
+    assert np.abs(model.tridiag_eigvals(d1, e1) - np.linalg.eigvalsh(h)).max() < 1e-12 * n
+    assert ticks > 0
+
+
+def test_cyclic_window_of_the_kernel_s_size_holds_the_sweeps_in_flight():
+    """The kernel's parameters (32 sweep slots, 512 window columns) on a band matrix wider than the window: no access misses,
+    no column enters an occupied cell, at most 512 columns are ever held."""
+    n = 600
+    rng = np.random.default_rng(7)
+    band = np.zeros((n, model.B + 1), dtype=complex)
+    for dd in range(model.B + 1):
+        band[: n - dd, dd] = rng.standard_normal(n - dd) + (1j * rng.standard_normal(n - dd) if dd else 0)
+    d, e, _ = model.stage2_window(band, 32, 512)
+    assert model.stage2_window.peak_columns <= 512
+    hb = np.zeros((n, n), dtype=complex)
+    for dd in range(model.B + 1):
+        idx = np.arange(n - dd)
+        hb[idx, idx + dd] = band[: n - dd, dd]
+    hb = np.triu(hb) + np.triu(hb, 1).conj().T
+    assert np.abs(model.tridiag_eigvals(d, e) - np.linalg.eigvalsh(hb)).max() < 1e-12 * n

@@ -483,6 +483,150 @@ def stage2_pipelined(band, stagger, n_waves=10 ** 6):
     return L[:n, 0].real.copy(), np.abs(L[:n - 1, 1]), total
 
 
+def stage2_window(band, n_slots, window, stagger=2):
+    """The pipelined chase of stage2_pipelined with the working diagonals in a CYCLIC WINDOW of `window` columns (the kernel: LDS)
+    in front of a backing store (the kernel: global memory) -- the layout of band_chase4w_kernel for more orbitals than the
+    LDS holds columns (csrc/tbk_eig_band.hip).  Sweep s runs in slot s % n_slots; the sweeps of generation g = s // n_slots
+    see column j at window column (j + off[g]) % window with off[g + 1] = off[g] + (NE - n_slots (g + 1)), NE = n + B: the
+    top of generation g + 1 follows the bottom of generation g in the window, as it does in time.  A column enters the window
+    one tick before the generation's first sweep needs it and leaves the tick after its last sweep touched it; from the first
+    generation whose columns all fit the window on nothing leaves any more.  Asserts: every access finds ITS column in the
+    window, a column only enters a free cell, and the result equals stage2_pipelined's bit for bit.  Returns (d, e, ticks)."""
+    n = band.shape[0]
+    NE = n + B
+    G = np.zeros((NE, 2 * B), dtype=complex)  # backing store, padded columns are zero
+    G[:n, :B + 1] = band.conj()
+    win = np.zeros((window, 2 * B), dtype=complex)
+    tag = [None] * window  # (column, offset) a cell of the window holds
+
+    n_sweeps = n - 2
+    length = [(n - 1 - j + B - 1) // B for j in range(n_sweeps)]
+    n_gen = (n_sweeps + n_slots - 1) // n_slots
+    g_res = next((g for g in range(n_gen) if NE - n_slots * g <= window), n_gen)  # first generation that stays
+    # a slot whose generation LEAVES the window is taken again no sooner than gap_min ticks after it started: the columns that
+    # generation leaves must be back in the backing store before the next one fetches them
+    gap_min = 2 * n_slots + 4
+    start = []
+    for s in range(n_sweeps):
+        t0 = 0 if s == 0 else start[s - 1] + stagger
+        if s >= n_slots:
+            prev = s - n_slots
+            t0 = max(t0, start[prev] + (max(length[prev], gap_min) if prev // n_slots < g_res else length[prev]))
+        start.append(t0)
+    total = start[-1] + length[-1] if n_sweeps > 0 else 0
+    off = [0] * (n_gen + 1)
+    for g in range(1, n_gen + 1):
+        off[g] = off[g - 1] + ((NE - n_slots * g) if g <= g_res else 0)
+
+    def cell(g, j):
+        return (j + off[g]) % window
+
+    def needed(g, j):  # first tick at which generation g touches column j (its sweep 0)
+        base = n_slots * g
+        return start[base] + max(0, (j - base - 1) // B)
+
+    def last_touch(g, j):
+        base = n_slots * g
+        s_l = min(base + n_slots, n_sweeps) - 1
+        if j <= s_l:
+            return start[j]
+        return start[s_l] + (j - s_l - 1) // B
+
+    fetch_at, evict_at = {}, {}
+    for g in range(min(g_res + 1, n_gen)):
+        for j in range(n_slots * g, NE):
+            fetch_at.setdefault(needed(g, j) - 1, []).append((g, j))
+            if g < g_res:
+                evict_at.setdefault(last_touch(g, j) + 1, []).append((g, j))
+
+    def fetch(tick):
+        for g, j in fetch_at.get(tick, ()):
+            c = cell(g, j)
+            assert tag[c] is None, "tick %d: column %d of generation %d enters a cell that still holds %r" % (tick, j, g, tag[c])
+            win[c] = G[j]
+            tag[c] = (j, off[g])
+
+    class View:
+        def __init__(self, g):
+            self.g, self.reads, self.writes = g, set(), {}
+
+        def get(self, i, j):
+            assert j < NE and 0 <= i - j < 2 * B
+            c = cell(self.g, j)
+            assert tag[c] == (j, off[self.g]), "column %d of generation %d is not in the window (%r)" % (j, self.g, tag[c])
+            self.reads.add((i, j))
+            return self.writes.get((i, j), win[c, i - j])
+
+        def put(self, i, j, v):
+            if i < n and j < n:
+                c = cell(self.g, j)
+                assert tag[c] == (j, off[self.g])
+                self.writes[(i, j)] = v
+
+    def chase_tick(view, j, k, state):  # stage2_pipelined's, reading the padded cells too (the kernel does)
+        if k == 0:
+            x = np.array([view.get(j + 1 + a, j) for a in range(B)])
+            beta, v, tau = larfg(x)
+            view.put(j + 1, j, beta)
+            for a in range(1, B):
+                view.put(j + 1 + a, j, 0.0)
+        else:
+            v, tau = state
+        r0 = j + 1 + B * k
+        q0 = r0 + B
+        D = np.zeros((B, B), dtype=complex)
+        for a in range(B):
+            for b_ in range(a + 1):
+                D[a, b_] = view.get(r0 + a, r0 + b_)
+                D[b_, a] = np.conj(D[a, b_])
+        for a in range(B):
+            D[a, a] = D[a, a].real
+        y = D @ v
+        rho = np.vdot(v, y).real
+        D = D - np.conj(tau) * np.outer(v, y.conj()) - tau * np.outer(y, v.conj()) + abs(tau) ** 2 * rho * np.outer(v, v.conj())
+        for a in range(B):
+            for b_ in range(a + 1):
+                view.put(r0 + a, r0 + b_, D[a, b_])
+        Bk = np.array([[view.get(q0 + a, r0 + b_) for b_ in range(B)] for a in range(B)])
+        Bk = Bk - tau * np.outer(Bk @ v, v.conj())
+        beta, v2, tau2 = larfg(Bk[:, 0].copy())
+        z = v2.conj() @ Bk
+        Bk = Bk - np.conj(tau2) * np.outer(v2, z)
+        Bk[0, 0] = beta
+        Bk[1:, 0] = 0.0
+        for a in range(B):
+            for b_ in range(B):
+                view.put(q0 + a, r0 + b_, Bk[a, b_])
+        return v2, tau2
+
+    fetch(-1)
+    states = {}
+    peak = 0
+    for tick in range(total):
+        active = [s for s in range(n_sweeps) if start[s] <= tick < start[s] + length[s]]
+        views = []
+        for s in active:
+            view = View(s // n_slots)
+            states[s] = chase_tick(view, s, tick - start[s], states.get(s))
+            views.append(view)
+        for view in views:
+            for (i, j), val in view.writes.items():
+                win[cell(view.g, j), i - j] = val
+        fetch(tick)
+        for g, j in evict_at.get(tick, ()):
+            c = cell(g, j)
+            assert tag[c] == (j, off[g])
+            if j < n:
+                G[j] = win[c]
+            tag[c] = None
+        peak = max(peak, sum(t is not None for t in tag))
+    for c in range(window):  # what stayed
+        if tag[c] is not None and tag[c][0] < n:
+            G[tag[c][0]] = win[c]
+    stage2_window.peak_columns = peak
+    return G[:n, 0].real.copy(), np.abs(G[:n - 1, 1]), total
+
+
 def check_pipeline():
     rng = np.random.default_rng(3)
     for n in (40, 67, 100):
