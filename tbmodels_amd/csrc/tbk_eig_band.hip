@@ -550,7 +550,7 @@ band_chase4g_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
     chase4_body<NW, false, 1, true>(band, nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n, band + (size_t)n * (PB + 1));
 }
 
-// Above 512 orbitals, calls of a few matrices (round 5): the working diagonals in a CYCLIC WINDOW of 512 columns in LDS in front of
+// Above 512 orbitals (round 5): the working diagonals in a CYCLIC WINDOW of 512 columns in LDS in front of
 // the global buffer of band_chase4g_kernel.  With the diagonals in global memory a tick is two memory round trips (the loads,
 // then the wait for the stores before the barrier) around a ~1.3 us chain: 3.0 - 3.3 us against the 1.5 us of the LDS form.  But the
 // 32 sweeps in flight only ever touch ~490 consecutive columns: sweep s runs in slot s % 32, the sweeps of generation g = s / 32
@@ -3415,10 +3415,12 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
     const int n = m->n_orb;
     if (chase_global(n)) {
         const int np = chase_pitch(n);
-        // Calls of a few matrices (a workgroup per CU at most): the working diagonals in a cyclic LDS window in front of the global
-        // buffer (band_chase4w_kernel; the same bits).  TBK_CHASE_WINDOW=0: off (measurements).
+        // The working diagonals in a cyclic LDS window in front of the global buffer (band_chase4w_kernel; the same bits as the
+        // global-memory form below).  One workgroup per CU (158 KiB of LDS) and still ahead at every call size: whole eigenval of
+        // 2048 k-points 44.7 -> 41.0 us per k-point at 520 orbitals, 110.6 -> 99.6 at 768, 245.5 -> 216.1 at 1024; one k-point 15.2 ->
+        // 13.0 ms at 1024, 32.1 -> 27.2 at 1536, 53.7 -> 44.4 at 2048.  TBK_CHASE_WINDOW=0: the global-memory form (measurements).
         static const bool window_env = !(getenv("TBK_CHASE_WINDOW") && atoi(getenv("TBK_CHASE_WINDOW")) == 0);
-        if (window_env && std::max<int64_t>(m->call_nk, nk) <= 256) {
+        if (window_env) {
             const size_t ldsw = (size_t)16 * CWP * 16 + (size_t)8 * 64 * 16 + (size_t)n * sizeof(int) + 16;
             static std::atomic<bool> raised_w[TBK_MAX_DEVICES] = {};
             TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<8>), 160 * 1024, raised_w));

@@ -637,10 +637,10 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
 
 @pytest.mark.parametrize("n", [513, 600, 777, 1030, 1300])
 def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n):
-    """Above 512 orbitals the 16 working diagonals of the second stage do not fit the LDS; calls of a few matrices keep the ~490
-    columns the 32 sweeps in flight touch in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band.hip,
-    band_chase4w_kernel; tools/two_stage_model.py: stage2_window), larger calls work in global memory (band_chase4g_kernel, also
-    ``TBK_CHASE_WINDOW=0`` -- read once per process, hence the child).  The same sweeps in another schedule: (d, e) agree bit for
+    """Above 512 orbitals the 16 working diagonals of the second stage do not fit the LDS: the ~490 columns the 32 sweeps in
+    flight touch live in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band.hip, band_chase4w_kernel;
+    tools/two_stage_model.py: stage2_window).  ``TBK_CHASE_WINDOW=0`` (read once per process, hence the child) works in global
+    memory throughout (band_chase4g_kernel, the round-4 form).  The same sweeps in another schedule: (d, e) agree bit for
     bit, and the spectra are the matrices' (scipy's eigvalsh at _tb_model.py:1149)."""
     import os
     import subprocess
