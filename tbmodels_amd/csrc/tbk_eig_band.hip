@@ -563,13 +563,17 @@ band_chase4g_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
 // again no sooner than 68 ticks after it started, so that a column is back in global memory before the next generation fetches it.
 // tools/two_stage_model.py: stage2_window is this scheme with an occupancy tag per window column (every access finds ITS
 // column, a column only enters a free cell; tests/test_two_stage_model.py).  Same arithmetic per sweep as chase4_body: the same bits.
-constexpr int CW = 512, CWP = 521, CW_SLOTS = 32, CW_GAP = 2 * CW_SLOTS + 4;
-template <int NW>
+// NW waves = 4 NW sweep slots; CW window columns (>= 15 * 4 NW + 18: what the slots can hold in flight), CWP = pitch of a diagonal
+// (= 9 mod 16: bank-conflict free, as in the plain LDS form).  <8, 512, 521>: above 512 orbitals.  <4, 272, 281> (TBK_CHASE_WINDOW_SMALL,
+// measurements): 257 - 512 orbitals in 78 KiB instead of the 133 KiB of the plain LDS form.
+template <int NW, int CW, int CWP>
 __global__ void __launch_bounds__(NW * 64)
 band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np, double* __restrict__ D, double* __restrict__ E) {
-    static_assert(4 * NW == CW_SLOTS, "eight waves of four sweeps");
+    constexpr int NSLOT = 4 * NW, CW_GAP = 2 * NSLOT + 4;
+    static_assert(CW >= 15 * NSLOT + 18 && CWP >= CW + PB && CWP % 16 == 9, "window too small for the sweeps in flight / pitch");
     extern __shared__ __attribute__((aligned(16))) double bw_smem[];
-    constexpr int NSLOT = CW_SLOTS;
+    auto modw = [](int x) { return x % CW; };                 // x >= 0
+    auto wrapw = [](int x) { return x >= CW ? x - CW : x; };  // 0 <= x < 2 CW
     const size_t mat = blockIdx.x;
     const d2* band = band_all + mat * band_stride;
     d2* gband = band_all + mat * band_stride + (size_t)n * (PB + 1);  // [16][np], element (i, j) at (i - j) np + j
@@ -589,7 +593,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
     auto sweep_len = [&](int j) { return (n - 1 - j + PB - 1) / PB; };
     auto off_of = [&](int gen) {
         const int m = min(gen, g_res);
-        return (m * NE - (NSLOT / 2) * m * (m + 1)) & (CW - 1);
+        return modw(m * NE - (NSLOT / 2) * m * (m + 1));
     };
 
     for (int i = tid; i < 16 * np; i += NW * 64) gband[i] = (d2){0.0, 0.0};
@@ -643,6 +647,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
         const int wx = (PB + a) * CWP;  // first column of the block below, row a
         int sw = wave * 4 + g;
         int off = 0;  // this slot's generation offset
+        int vr0 = 0;  // window column of the slot's block position r0 (kept in [0, CW): + 8 per step)
         int k = -1, k_len = 0;
         d2 va = (d2){0.0, 0.0}, tau = va;
         d2 vb[4];
@@ -695,16 +700,16 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                     const int j_hi = min(base + 9 + PB * kk, NE);
                     const int j = j_lo + (tid >> 4), dd = tid & 15;
                     if (j < j_hi) {
-                        pf_idx = dd * CWP + ((j + off_of(g_in)) & (CW - 1));
+                        pf_idx = dd * CWP + modw(j + off_of(g_in));
                         if (j < n) pf_val = gband[(size_t)dd * np + j];
                     }
                 }
             }
             // ---- columns that leave: untouched since the last tick ----
             if (s_ev < NSLOT * g_res && s_ev < n_sweeps && sStart[s_ev] + 1 == tick) {
-                if (tid >= 384 && tid < 400) {
-                    const int dd = tid - 384;
-                    gband[(size_t)dd * np + s_ev] = win[dd * CWP + ((s_ev + off_of(s_ev / NSLOT)) & (CW - 1))];
+                if (tid >= 128 && tid < 144) {
+                    const int dd = tid - 128;
+                    gband[(size_t)dd * np + s_ev] = win[dd * CWP + modw(s_ev + off_of(s_ev / NSLOT))];
                 }
                 ++s_ev;
             }
@@ -715,9 +720,9 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                     const int j_lo = s_l + 1 + PB * ks;
                     if (j_lo >= NE) {
                         ++g_out;
-                    } else if (tid >= 256 && tid < 384) {
-                        const int j = j_lo + ((tid - 256) >> 4), dd = tid & 15;
-                        if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + ((j + off_of(g_out)) & (CW - 1))];
+                    } else if (tid < 128) {
+                        const int j = j_lo + (tid >> 4), dd = tid & 15;
+                        if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_of(g_out))];
                     }
                 }
             }
@@ -725,7 +730,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
             const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
             if (__any(starting)) {
                 const int j = starting ? sw : 0;
-                const int vj = (j + off) & (CW - 1);
+                const int vj = modw(j + off);
                 const d2 xa = win[(1 + a) * CWP + vj];
                 d2 xb[4];
 #pragma unroll
@@ -742,20 +747,20 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                     for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
                     k = 0;
                     k_len = sweep_len(sw);
+                    vr0 = wrapw(vj + 1);
                     if (h == 0 && j + 1 + a < n) win[(1 + a) * CWP + vj] = (a == 0) ? (d2){beta, 0.0} : (d2){0.0, 0.0};
                 }
             }
             const bool active = k >= 0;
             if (__any(active)) {
                 const int r0 = active ? sw + 1 + PB * k : 0;
-                const int v0 = r0 + off;
                 int id[4], ib[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    id[c] = wd[c] + ((v0 + cd[c]) & (CW - 1));
-                    ib[c] = wb[c] + ((v0 + cb[c]) & (CW - 1));
+                    id[c] = wd[c] + wrapw(vr0 + cd[c]);
+                    ib[c] = wb[c] + wrapw(vr0 + cb[c]);
                 }
-                const int ix = wx + (v0 & (CW - 1));
+                const int ix = wx + vr0;
                 d2 dv[4], bk[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -826,6 +831,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
 #pragma unroll
                 for (int c = 0; c < 4; ++c) vb[c] = n_vb[c];
                 if (active) {
+                    vr0 = wrapw(vr0 + PB);
                     if (++k == k_len) {
                         k = -1;
                         sw += NSLOT;
@@ -841,7 +847,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
             const int base = NSLOT * g_res, off_r = off_of(g_res);
             for (int e = tid; e < (n - base) * 16; e += NW * 64) {
                 const int j = base + (e >> 4), dd = e & 15;
-                gband[(size_t)dd * np + j] = win[dd * CWP + ((j + off_r) & (CW - 1))];
+                gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_r)];
             }
         }
     }
@@ -3122,7 +3128,10 @@ constexpr int BAND_LDS_CHASE_MAXN = 512;  // above: the chase keeps its 16 diago
 // and 158 registers per wave instead of 133 KiB at 512 orbitals, so its workgroups fit beside those of other kernels
 static bool chase_global(int n) {
     static const bool forced = getenv("TBK_CHASE_GLOBAL") && atoi(getenv("TBK_CHASE_GLOBAL")) != 0;
-    return n > BAND_LDS_CHASE_MAXN || (forced && !tbk_band_fused(n));
+    // TBK_CHASE_WINDOW_SMALL=1 (measurements): 257 - 512 orbitals through the windowed kernel with 16 sweep slots and 272 columns
+    // (78 KiB of LDS instead of 133: two workgroups per CU, or one beside a first-stage workgroup)
+    static const bool small_window = getenv("TBK_CHASE_WINDOW_SMALL") && atoi(getenv("TBK_CHASE_WINDOW_SMALL")) != 0;
+    return n > BAND_LDS_CHASE_MAXN || ((forced || (small_window && n > 256)) && !tbk_band_fused(n));
 }
 
 // The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 189 orbitals on (129 until round 3): up to 128 the one-stage kernel of
@@ -3421,11 +3430,20 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
         // 13.0 ms at 1024, 32.1 -> 27.2 at 1536, 53.7 -> 44.4 at 2048.  TBK_CHASE_WINDOW=0: the global-memory form (measurements).
         static const bool window_env = !(getenv("TBK_CHASE_WINDOW") && atoi(getenv("TBK_CHASE_WINDOW")) == 0);
         if (window_env) {
-            const size_t ldsw = (size_t)16 * CWP * 16 + (size_t)8 * 64 * 16 + (size_t)n * sizeof(int) + 16;
+            d2* d_b = static_cast<d2*>(const_cast<void*>(d_band));
+            const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
+            if (n <= BAND_LDS_CHASE_MAXN) {  // (TBK_CHASE_WINDOW_SMALL: measurements)
+                const size_t ldsw = (size_t)16 * 281 * 16 + (size_t)4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
+                static std::atomic<bool> raised_s[TBK_MAX_DEVICES] = {};
+                TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<4, 272, 281>), 160 * 1024, raised_s));
+                hipLaunchKernelGGL((band_chase4w_kernel<4, 272, 281>), dim3((unsigned)nk), dim3(256), ldsw, s, d_b, stride, n, np, d_D, d_E);
+                TBK_HIP(hipGetLastError());
+                return TBK_OK;
+            }
+            const size_t ldsw = (size_t)16 * 521 * 16 + (size_t)8 * 64 * 16 + (size_t)n * sizeof(int) + 16;
             static std::atomic<bool> raised_w[TBK_MAX_DEVICES] = {};
-            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<8>), 160 * 1024, raised_w));
-            hipLaunchKernelGGL(band_chase4w_kernel<8>, dim3((unsigned)nk), dim3(512), ldsw, s, static_cast<d2*>(const_cast<void*>(d_band)),
-                               tbk_band_bytes_per_matrix(n) / sizeof(d2), n, np, d_D, d_E);
+            TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<8, 512, 521>), 160 * 1024, raised_w));
+            hipLaunchKernelGGL((band_chase4w_kernel<8, 512, 521>), dim3((unsigned)nk), dim3(512), ldsw, s, d_b, stride, n, np, d_D, d_E);
             TBK_HIP(hipGetLastError());
             return TBK_OK;
         }
