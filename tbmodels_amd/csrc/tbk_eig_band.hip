@@ -690,6 +690,13 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
             {
                 const int nt = tick + 1;
                 if (g_in < last_fetch_gen && nt >= sStart[NSLOT * (g_in + 1)]) {
+                    // (the generation that led until now may have its last columns due at this very tick -- n = 1 mod 8 with 16
+                    // slots: they lie behind the matrix, i.e. they are zeros; their cells are free since the last tick)
+                    const int j_old = NSLOT * g_in + 1 + PB * (nt - t0_in);
+                    if (j_old < NE && tid < 128) {
+                        const int j = j_old + (tid >> 4), dd = tid & 15;
+                        if (j < NE) win[dd * CWP + modw(j + off_of(g_in))] = (d2){0.0, 0.0};
+                    }
                     ++g_in;
                     t0_in = sStart[NSLOT * g_in];
                 }
@@ -713,18 +720,21 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                 }
                 ++s_ev;
             }
-            if (g_out < g_res) {
+            while (g_out < g_res) {  // (at most twice per tick)
                 const int s_l = NSLOT * g_out + NSLOT - 1;
                 const int ks = tick - 1 - sStart[s_l];
-                if (ks >= 0) {
-                    const int j_lo = s_l + 1 + PB * ks;
-                    if (j_lo >= NE) {
-                        ++g_out;
-                    } else if (tid < 128) {
-                        const int j = j_lo + (tid >> 4), dd = tid & 15;
-                        if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_of(g_out))];
-                    }
+                if (ks < 0) break;
+                const int j_lo = s_l + 1 + PB * ks;
+                if (j_lo >= NE) {
+                    ++g_out;
+                    continue;
                 }
+                if (tid < 128) {
+                    const int j = j_lo + (tid >> 4), dd = tid & 15;
+                    if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_of(g_out))];
+                }
+                if (j_lo + PB < NE) break;
+                ++g_out;  // that was its last chunk: the next generation's first may be due at this very tick
             }
 
             const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
@@ -3126,13 +3136,21 @@ static int band_maxn() {
 constexpr int BAND_LDS_CHASE_MAXN = 512;  // above: the chase keeps its 16 diagonals in global memory
 // TBK_CHASE_GLOBAL=1 (measurements): the global-memory chase at every size that runs it as its own launch -- 9 KiB of LDS
 // and 158 registers per wave instead of 133 KiB at 512 orbitals, so its workgroups fit beside those of other kernels
-static bool chase_global(int n) {
+static bool chase_global_forced(int n) {
     static const bool forced = getenv("TBK_CHASE_GLOBAL") && atoi(getenv("TBK_CHASE_GLOBAL")) != 0;
-    // TBK_CHASE_WINDOW_SMALL=1 (measurements): 257 - 512 orbitals through the windowed kernel with 16 sweep slots and 272 columns
-    // (78 KiB of LDS instead of 133: two workgroups per CU, or one beside a first-stage workgroup)
-    static const bool small_window = getenv("TBK_CHASE_WINDOW_SMALL") && atoi(getenv("TBK_CHASE_WINDOW_SMALL")) != 0;
-    return n > BAND_LDS_CHASE_MAXN || ((forced || (small_window && n > 256)) && !tbk_band_fused(n));
+    return forced && !tbk_band_fused(n);
 }
+// 257 - 512 orbitals, calls of more matrices than the chip has CUs: the windowed kernel with 16 sweep slots and 272 columns -- 78 KiB
+// of LDS instead of the 133 KiB of the plain LDS form at 512 orbitals, so two of its workgroups share a CU, or one sits beside a
+// first-stage workgroup of the next chunk (76 KiB).  A matrix takes more and slower ticks (1293 x ~2.2 us instead of 1088 x 1.55 at
+// 512 orbitals), the chip holds twice as many: cfg5 16.04 -> 16.63 k k-points/s, whole eigenval of 2048 k-points 12.93 -> 11.74 us per
+// k-point at 320 orbitals, 18.82 -> 17.66 at 384, 34.57 -> 33.64 at 512; the same bits.  TBK_CHASE_WINDOW_SMALL=0: off.
+static bool chase_small_window(const tbk_model* m, int n, int64_t nk) {
+    static const bool on = !(getenv("TBK_CHASE_WINDOW_SMALL") && atoi(getenv("TBK_CHASE_WINDOW_SMALL")) == 0);
+    return on && n > 256 && n <= BAND_LDS_CHASE_MAXN && !tbk_band_fused(n) && std::max<int64_t>(m->call_nk, nk) > 256;
+}
+// does a matrix' band buffer carry the 16 working diagonals behind the compact band (by the size alone: any call may need them)
+static bool chase_has_buffer(int n) { return n > BAND_LDS_CHASE_MAXN || chase_global_forced(n) || (n > 256 && !tbk_band_fused(n)); }
 
 // The kernels handle 64 < n <= 512; the two-stage path is TAKEN from 189 orbitals on (129 until round 3): up to 128 the one-stage kernel of
 // tbk_eig_stream.hip (four waves per matrix, rows of two 64-column chunks) is faster -- 0.65 vs 0.84 us per matrix at 65
@@ -3164,7 +3182,7 @@ bool tbk_eig_band_preferred(int n) {
 // the compact band between the stages (9 complex per row) and, above 512 orbitals, the second stage's 16 working
 // diagonals behind it
 size_t tbk_band_bytes_per_matrix(int n) {
-    return ((size_t)n * (PB + 1) + (chase_global(n) ? (size_t)16 * chase_pitch(n) : 0)) * sizeof(d2);
+    return ((size_t)n * (PB + 1) + (chase_has_buffer(n) ? (size_t)16 * chase_pitch(n) : 0)) * sizeof(d2);
 }
 
 // Calls of a few matrices (Z2Pack-style lines and single k-points, _tb_model.py:1103-1108; band-structure paths of a few dozen
@@ -3422,17 +3440,19 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
 // Stage two: d_band -> d_de = d[nk][n] followed by e[nk][n]
 static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_D, double* d_E) {
     const int n = m->n_orb;
-    if (chase_global(n)) {
+    // TBK_CHASE_WINDOW=0 (measurements): no windowed kernel -- above 512 orbitals the global-memory form, the plain LDS form below
+    static const bool window_env = !(getenv("TBK_CHASE_WINDOW") && atoi(getenv("TBK_CHASE_WINDOW")) == 0);
+    const bool small_window = window_env && chase_small_window(m, n, nk);
+    if (n > BAND_LDS_CHASE_MAXN || chase_global_forced(n) || small_window) {
         const int np = chase_pitch(n);
         // The working diagonals in a cyclic LDS window in front of the global buffer (band_chase4w_kernel; the same bits as the
         // global-memory form below).  One workgroup per CU (158 KiB of LDS) and still ahead at every call size: whole eigenval of
         // 2048 k-points 44.7 -> 41.0 us per k-point at 520 orbitals, 110.6 -> 99.6 at 768, 245.5 -> 216.1 at 1024; one k-point 15.2 ->
-        // 13.0 ms at 1024, 32.1 -> 27.2 at 1536, 53.7 -> 44.4 at 2048.  TBK_CHASE_WINDOW=0: the global-memory form (measurements).
-        static const bool window_env = !(getenv("TBK_CHASE_WINDOW") && atoi(getenv("TBK_CHASE_WINDOW")) == 0);
-        if (window_env) {
+        // 13.0 ms at 1024, 32.1 -> 27.2 at 1536, 53.7 -> 44.4 at 2048.
+        if (window_env && !chase_global_forced(n)) {
             d2* d_b = static_cast<d2*>(const_cast<void*>(d_band));
             const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
-            if (n <= BAND_LDS_CHASE_MAXN) {  // (TBK_CHASE_WINDOW_SMALL: measurements)
+            if (small_window) {
                 const size_t ldsw = (size_t)16 * 281 * 16 + (size_t)4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
                 static std::atomic<bool> raised_s[TBK_MAX_DEVICES] = {};
                 TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<4, 272, 281>), 160 * 1024, raised_s));

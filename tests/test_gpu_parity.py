@@ -635,12 +635,14 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
-@pytest.mark.parametrize("n", [513, 600, 777, 1030, 1300])
-def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n):
+@pytest.mark.parametrize("n, nk", [(513, 3), (600, 3), (777, 3), (1030, 3), (1300, 3), (300, 260), (385, 260), (449, 257), (512, 257)])
+def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n, nk):
     """Above 512 orbitals the 16 working diagonals of the second stage do not fit the LDS: the ~490 columns the 32 sweeps in
     flight touch live in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band.hip, band_chase4w_kernel;
     tools/two_stage_model.py: stage2_window).  ``TBK_CHASE_WINDOW=0`` (read once per process, hence the child) works in global
-    memory throughout (band_chase4g_kernel, the round-4 form).  The same sweeps in another schedule: (d, e) agree bit for
+    memory throughout (band_chase4g_kernel, the round-4 form).  257 - 512 orbitals: calls of more than 256 matrices take the window
+    too -- 16 sweep slots and 272 columns in 78 KiB, so that two workgroups share a CU -- and with the switch off the plain LDS form
+    (band_chase4_kernel).  The same sweeps in another schedule: (d, e) agree bit for
     bit, and the spectra are the matrices' (scipy's eigvalsh at _tb_model.py:1149)."""
     import os
     import subprocess
@@ -656,23 +658,25 @@ def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n):
 import sys
 import numpy as np
 from tbmodels_amd import _lib
-n, out = int(sys.argv[1]), sys.argv[2]
+n, nk, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 rng = np.random.default_rng(4000 + n)
-m = rng.standard_normal((3, n, n)) + 1j * rng.standard_normal((3, n, n))
-h = np.ascontiguousarray((m + m.conj().transpose(0, 2, 1)) / 2)
+h = np.empty((nk, n, n), dtype=complex)
+for i in range(nk):
+    m = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    h[i] = (m + m.conj().T) / 2
 h[1] *= 1e-20
 h[2, : n // 2, n // 2 :] = 0.0
 h[2, n // 2 :, : n // 2] = 0.0
-d, e = np.empty((3, n)), np.empty((3, n))
-_lib.check(_lib.lib().tbk_tridiagonal_reduce(0, n, 3, _lib.ptr(h), _lib.TBK_REDUCE_AUTO, _lib.ptr(d), _lib.ptr(e), None))
-np.savez(out, d=d, e=e, h=h)
+d, e = np.empty((nk, n)), np.empty((nk, n))
+_lib.check(_lib.lib().tbk_tridiagonal_reduce(0, n, nk, _lib.ptr(h), _lib.TBK_REDUCE_TWO_STAGE, _lib.ptr(d), _lib.ptr(e), None))
+np.savez(out, d=d, e=e, h=h[:3])
 """
     with tempfile.TemporaryDirectory() as tmp:
         got = {}
         for label, window in (("window", "1"), ("global", "0")):
             out = os.path.join(tmp, label + ".npz")
             env = dict(os.environ, TBK_CHASE_WINDOW=window, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-            run = subprocess.run([sys.executable, "-c", code, str(n), out], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+            run = subprocess.run([sys.executable, "-c", code, str(n), str(nk), out], env=env, capture_output=True, text=True, timeout=600, cwd=root)
             assert run.returncode == 0, run.stderr[-2000:]
             got[label] = np.load(out)
     assert np.array_equal(got["window"]["d"], got["global"]["d"]) and np.array_equal(got["window"]["e"], got["global"]["e"])

@@ -205,3 +205,23 @@ def test_cyclic_window_of_the_kernel_s_size_holds_the_sweeps_in_flight():
         hb[idx, idx + dd] = band[: n - dd, dd]
     hb = np.triu(hb) + np.triu(hb, 1).conj().T
     assert np.abs(model.tridiag_eigvals(d, e) - np.linalg.eigvalsh(hb)).max() < 1e-12 * n
+
+
+@pytest.mark.parametrize("slots, window, sizes", [
+    (16, 272, list(range(258, 520))),
+    (32, 512, list(range(513, 1100)) + list(range(1100, 4097, 37)) + [2047, 2048, 2049, 3071, 3072, 3073, 4089, 4095, 4096]),
+    (4, 80, list(range(30, 200))),
+    (2, 52, list(range(30, 120))),
+])
+def test_window_trackers_of_the_kernel_find_the_columns_the_table_names(slots, window, sizes):
+    """band_chase4w_kernel does not hold a table of which column enters or leaves the window at which tick: three running
+    trackers find them (``window_plan_by_trackers`` is that code).  For every orbital count of both instantiations -- <4, 272>
+    up to 512 orbitals, <8, 512> above -- and two small parameter sets where generation boundaries coincide far more often,
+    the trackers name exactly the columns of ``stage2_window``'s table, tick by tick (round 5: at n = 1 mod 8 with 16 slots a
+    generation's last chunk and the next one's first fall on the same tick, and the first tracker missed one of them)."""
+    for n in sizes:
+        model.stage2_window(np.zeros((n, model.B + 1), dtype=complex), slots, window, plan_only=True)
+        table = model.stage2_window.plan
+        fetch, evict = model.window_plan_by_trackers(n, slots, window)
+        assert fetch == table[0], n
+        assert evict == table[1], n

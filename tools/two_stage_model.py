@@ -483,7 +483,7 @@ def stage2_pipelined(band, stagger, n_waves=10 ** 6):
     return L[:n, 0].real.copy(), np.abs(L[:n - 1, 1]), total
 
 
-def stage2_window(band, n_slots, window, stagger=2):
+def stage2_window(band, n_slots, window, stagger=2, plan_only=False):
     """The pipelined chase of stage2_pipelined with the working diagonals in a CYCLIC WINDOW of `window` columns (the kernel: LDS)
     in front of a backing store (the kernel: global memory) -- the layout of band_chase4w_kernel for more orbitals than the
     LDS holds columns (csrc/tbk_eig_band.hip).  Sweep s runs in slot s % n_slots; the sweeps of generation g = s // n_slots
@@ -599,6 +599,9 @@ def stage2_window(band, n_slots, window, stagger=2):
                 view.put(q0 + a, r0 + b_, Bk[a, b_])
         return v2, tau2
 
+    stage2_window.plan = ({t: sorted(v) for t, v in fetch_at.items()}, {t: sorted(v) for t, v in evict_at.items()})
+    if plan_only:
+        return None
     fetch(-1)
     states = {}
     peak = 0
@@ -625,6 +628,66 @@ def stage2_window(band, n_slots, window, stagger=2):
             G[tag[c][0]] = win[c]
     stage2_window.peak_columns = peak
     return G[:n, 0].real.copy(), np.abs(G[:n - 1, 1]), total
+
+
+def window_plan_by_trackers(n, n_slots, window):
+    """Which columns enter and leave the cyclic window at which tick, found the way band_chase4w_kernel finds them: three running
+    trackers (the generation whose first sweep leads, the next sweep whose own column leaves, the generation whose last sweep
+    trails) instead of a table over all columns.  Returns (fetch_at, evict_at): tick -> sorted list of (generation, column);
+    tests/test_two_stage_model.py holds it equal to the table stage2_window builds, for every orbital count the kernels see."""
+    NE = n + B
+    n_sweeps = n - 2
+    length = [(n - 1 - j + B - 1) // B for j in range(n_sweeps)]
+    n_gen = (n_sweeps + n_slots - 1) // n_slots
+    g_res = (NE - window + n_slots - 1) // n_slots if NE > window else 0
+    gap_min = 2 * n_slots + 4
+    start = []
+    for s in range(n_sweeps):
+        t0 = 0 if s == 0 else start[s - 1] + 2
+        if s >= n_slots:
+            prev = s - n_slots
+            t0 = max(t0, start[prev] + (max(length[prev], gap_min) if prev // n_slots < g_res else length[prev]))
+        start.append(t0)
+    total = start[-1] + length[-1]
+    last_fetch_gen = min(g_res, n_gen - 1)
+    fetch_at, evict_at = {}, {}
+    fetch_at[-1] = [(0, j) for j in range(min(9, NE))]
+    g_in, t0_in, s_ev, g_out = 0, 0, 0, 0
+    for tick in range(total):
+        nt = tick + 1
+        got = []
+        if g_in < last_fetch_gen and nt >= start[n_slots * (g_in + 1)]:
+            j_old = n_slots * g_in + 1 + B * (nt - t0_in)
+            got += [(g_in, j) for j in range(j_old, min(j_old + 8, NE))]
+            g_in += 1
+            t0_in = start[n_slots * g_in]
+        kk = nt - t0_in
+        if kk >= 0 and g_in <= last_fetch_gen:
+            base = n_slots * g_in
+            j_lo = base if kk == 0 else base + 1 + B * kk
+            got += [(g_in, j) for j in range(j_lo, min(base + 9 + B * kk, NE))]
+        if got:
+            fetch_at[tick] = sorted(got)
+        out = []
+        if s_ev < n_slots * g_res and s_ev < n_sweeps and start[s_ev] + 1 == tick:
+            out.append((s_ev // n_slots, s_ev))
+            s_ev += 1
+        while g_out < g_res:
+            s_l = n_slots * g_out + n_slots - 1
+            ks = tick - 1 - start[s_l]
+            if ks < 0:
+                break
+            j_lo = s_l + 1 + B * ks
+            if j_lo >= NE:
+                g_out += 1
+                continue
+            out += [(g_out, j) for j in range(j_lo, min(j_lo + 8, NE))]
+            if j_lo + B < NE:
+                break
+            g_out += 1
+        if out:
+            evict_at[tick] = sorted(out)
+    return fetch_at, evict_at
 
 
 def check_pipeline():
