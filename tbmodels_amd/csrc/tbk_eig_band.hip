@@ -533,10 +533,12 @@ __device__ inline void chase4_body(const d2* __restrict__ band, const double* __
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
-band_chase4_kernel(const d2* __restrict__ band_all, int n, int np, int stagger, double* __restrict__ D, double* __restrict__ E) {
+band_chase4_kernel(const d2* __restrict__ band_all, size_t band_stride, int n, int np, int stagger, double* __restrict__ D,
+                   double* __restrict__ E) {
+    // (band_stride complex numbers per matrix: the compact band, and from 257 orbitals on the working diagonals of the windowed kernel behind it)
     extern __shared__ __attribute__((aligned(16))) double bc_smem[];
     const size_t mat = blockIdx.x;
-    chase4_body<NW, false>(band_all + mat * (size_t)n * (PB + 1), nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
+    chase4_body<NW, false>(band_all + mat * band_stride, nullptr, bc_smem, n, np, stagger, D + mat * (size_t)n, E + mat * (size_t)n);
 }
 
 // above 512 orbitals: the 16 working diagonals in global memory, behind the compact band of the same matrix
@@ -3500,7 +3502,7 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
 #define TBK_CHASE4(NWV, SLOT)                                                                                             \
     do {                                                                                                                  \
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4_kernel<NWV>), 160 * 1024, raised4[SLOT]));   \
-        hipLaunchKernelGGL(band_chase4_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds4, s, static_cast<const d2*>(d_band), n, np, stagger, d_D, d_E); \
+        hipLaunchKernelGGL(band_chase4_kernel<NWV>, dim3((unsigned)nk), dim3(NWV * 64), lds4, s, static_cast<const d2*>(d_band), tbk_band_bytes_per_matrix(n) / sizeof(d2), n, np, stagger, d_D, d_E); \
     } while (0)
         if (nw4 <= 2)
             TBK_CHASE4(2, 0);
