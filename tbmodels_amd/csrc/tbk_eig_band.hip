@@ -3142,14 +3142,17 @@ static bool chase_global_forced(int n) {
     static const bool forced = getenv("TBK_CHASE_GLOBAL") && atoi(getenv("TBK_CHASE_GLOBAL")) != 0;
     return forced && !tbk_band_fused(n);
 }
-// 257 - 512 orbitals, calls of more matrices than the chip has CUs: the windowed kernel with 16 sweep slots and 272 columns -- 78 KiB
+// 257 - 768 orbitals, calls of more matrices than the chip has CUs: the windowed kernel with 16 sweep slots and 272 columns -- 78 KiB
 // of LDS instead of the 133 KiB of the plain LDS form at 512 orbitals, so two of its workgroups share a CU, or one sits beside a
 // first-stage workgroup of the next chunk (76 KiB).  A matrix takes more and slower ticks (1293 x ~2.2 us instead of 1088 x 1.55 at
 // 512 orbitals), the chip holds twice as many: cfg5 16.04 -> 16.63 k k-points/s, whole eigenval of 2048 k-points 12.93 -> 11.74 us per
 // k-point at 320 orbitals, 18.82 -> 17.66 at 384, 34.57 -> 33.64 at 512; the same bits.  TBK_CHASE_WINDOW_SMALL=0: off.
 static bool chase_small_window(const tbk_model* m, int n, int64_t nk) {
     static const bool on = !(getenv("TBK_CHASE_WINDOW_SMALL") && atoi(getenv("TBK_CHASE_WINDOW_SMALL")) == 0);
-    return on && n > 256 && n <= BAND_LDS_CHASE_MAXN && !tbk_band_fused(n) && std::max<int64_t>(m->call_nk, nk) > 256;
+    // Up to 768 orbitals (TBK_CHASE_WINDOW_SMALL_MAXN, measurements): above 512 against the 32-slot window -- whole eigenval of 2048
+    // k-points 41.1 -> 39.1 us per k-point at 520 orbitals, 64.8 -> 62.9 at 640, 100.1 -> 97.4 at 768, 206.2 -> 215.6 at 1000.
+    static const int maxn = getenv("TBK_CHASE_WINDOW_SMALL_MAXN") ? atoi(getenv("TBK_CHASE_WINDOW_SMALL_MAXN")) : 768;
+    return on && n > 256 && n <= maxn && !tbk_band_fused(n) && std::max<int64_t>(m->call_nk, nk) > 256;
 }
 // does a matrix' band buffer carry the 16 working diagonals behind the compact band (by the size alone: any call may need them)
 static bool chase_has_buffer(int n) { return n > BAND_LDS_CHASE_MAXN || chase_global_forced(n) || (n > 256 && !tbk_band_fused(n)); }

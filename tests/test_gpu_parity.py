@@ -635,14 +635,14 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
     _close(big[idx], np.array(oracle.eigenval(r_vec, hop, k[idx])))
 
 
-@pytest.mark.parametrize("n, nk", [(513, 3), (600, 3), (777, 3), (1030, 3), (1300, 3), (300, 260), (385, 260), (449, 257), (512, 257)])
+@pytest.mark.parametrize("n, nk", [(513, 3), (600, 3), (777, 3), (1030, 3), (1300, 3), (300, 260), (385, 260), (449, 257), (512, 257), (600, 260), (768, 257)])
 def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n, nk):
     """Above 512 orbitals the 16 working diagonals of the second stage do not fit the LDS: the ~490 columns the 32 sweeps in
     flight touch live in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band.hip, band_chase4w_kernel;
     tools/two_stage_model.py: stage2_window).  ``TBK_CHASE_WINDOW=0`` (read once per process, hence the child) works in global
-    memory throughout (band_chase4g_kernel, the round-4 form).  257 - 512 orbitals: calls of more than 256 matrices take the window
-    too -- 16 sweep slots and 272 columns in 78 KiB, so that two workgroups share a CU -- and with the switch off the plain LDS form
-    (band_chase4_kernel).  The same sweeps in another schedule: (d, e) agree bit for
+    memory throughout (band_chase4g_kernel, the round-4 form).  257 - 768 orbitals: calls of more than 256 matrices take a window
+    of 16 sweep slots and 272 columns in 78 KiB, so that two workgroups share a CU; with the switch off the plain LDS form up to
+    512 orbitals (band_chase4_kernel).  The same sweeps in another schedule: (d, e) agree bit for
     bit, and the spectra are the matrices' (scipy's eigvalsh at _tb_model.py:1149)."""
     import os
     import subprocess
