@@ -13,7 +13,7 @@ import os
 import sys
 
 NAMES = ("band_xl_sweep_kernel", "band_xl_sweep4_kernel", "band_xl_xsum_kernel", "band_xl_serial_kernel", "band_xl_update_kernel",
-         "band_chase4g_kernel", "tridiag_bisect_kernel", "band_extract_from_kernel", "band_deposit_kernel")
+         "band_chase4g_kernel", "band_chase4w_kernel", "tridiag_bisect_kernel", "band_extract_from_kernel", "band_deposit_kernel")
 
 
 def short(name):
