@@ -680,10 +680,15 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                     if (4 * h + c != 0) o_vb[c] = cmul(xb[c], scale);
             }
         };
-        // (uniform) trackers of the columns that enter and leave
-        int g_in = 0, t0_in = 0;       // generation whose first sweep leads, its first tick
-        int s_ev = 0;                  // next sweep whose own column leaves (generations that leave only)
-        int g_out = 0;                 // generation whose last sweep trails
+        // (uniform) trackers of the columns that enter and leave; what they need of the schedule is read when it changes, not per tick
+        constexpr int NEVER = 0x7fffffff;
+        int g_in = 0, t0_in = 0, off_in = 0;   // generation whose first sweep leads, its first tick, its offset
+        int t_in_next = last_fetch_gen > 0 ? sStart[NSLOT] : NEVER;  // first tick of the generation that leads next
+        int s_ev = 0, off_ev = 0;              // next sweep whose own column leaves (generations that leave only)
+        int t_ev = g_res > 0 ? sStart[0] + 1 : NEVER;
+        int g_out = 0, off_out = 0;            // generation whose last sweep trails
+        int t_sl = g_res > 0 ? sStart[NSLOT - 1] : NEVER;  // first tick of that sweep
+        int my_start = sw < n_sweeps ? sStart[sw] : NEVER;  // first tick of this slot's next sweep
 
         for (int tick = 0; tick < total_ticks; ++tick) {
             // ---- columns that enter for tick + 1: fetched now, stored to the window at the end of this tick ----
@@ -691,55 +696,64 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
             d2 pf_val = (d2){0.0, 0.0};
             {
                 const int nt = tick + 1;
-                if (g_in < last_fetch_gen && nt >= sStart[NSLOT * (g_in + 1)]) {
+                if (nt >= t_in_next) {
                     // (the generation that led until now may have its last columns due at this very tick -- n = 1 mod 8 with 16
                     // slots: they lie behind the matrix, i.e. they are zeros; their cells are free since the last tick)
                     const int j_old = NSLOT * g_in + 1 + PB * (nt - t0_in);
                     if (j_old < NE && tid < 128) {
                         const int j = j_old + (tid >> 4), dd = tid & 15;
-                        if (j < NE) win[dd * CWP + modw(j + off_of(g_in))] = (d2){0.0, 0.0};
+                        if (j < NE) win[dd * CWP + modw(j + off_in)] = (d2){0.0, 0.0};
                     }
                     ++g_in;
-                    t0_in = sStart[NSLOT * g_in];
+                    t0_in = t_in_next;
+                    off_in = off_of(g_in);
+                    t_in_next = g_in < last_fetch_gen ? sStart[NSLOT * (g_in + 1)] : NEVER;
                 }
                 const int kk = nt - t0_in;
-                if (kk >= 0 && g_in <= last_fetch_gen) {
+                if (kk >= 0) {
                     const int base = NSLOT * g_in;
                     const int j_lo = kk == 0 ? base : base + 1 + PB * kk;
                     const int j_hi = min(base + 9 + PB * kk, NE);
                     const int j = j_lo + (tid >> 4), dd = tid & 15;
                     if (j < j_hi) {
-                        pf_idx = dd * CWP + modw(j + off_of(g_in));
+                        pf_idx = dd * CWP + modw(j + off_in);
                         if (j < n) pf_val = gband[(size_t)dd * np + j];
                     }
                 }
             }
             // ---- columns that leave: untouched since the last tick ----
-            if (s_ev < NSLOT * g_res && s_ev < n_sweeps && sStart[s_ev] + 1 == tick) {
+            if (tick == t_ev) {
                 if (tid >= 128 && tid < 144) {
                     const int dd = tid - 128;
-                    gband[(size_t)dd * np + s_ev] = win[dd * CWP + modw(s_ev + off_of(s_ev / NSLOT))];
+                    gband[(size_t)dd * np + s_ev] = win[dd * CWP + modw(s_ev + off_ev)];
                 }
                 ++s_ev;
+                if (s_ev < NSLOT * g_res) {
+                    t_ev = sStart[s_ev] + 1;
+                    if (s_ev % NSLOT == 0) off_ev = off_of(s_ev / NSLOT);
+                } else {
+                    t_ev = NEVER;
+                }
             }
             while (g_out < g_res) {  // (at most twice per tick)
-                const int s_l = NSLOT * g_out + NSLOT - 1;
-                const int ks = tick - 1 - sStart[s_l];
+                const int ks = tick - 1 - t_sl;
                 if (ks < 0) break;
-                const int j_lo = s_l + 1 + PB * ks;
-                if (j_lo >= NE) {
-                    ++g_out;
-                    continue;
+                const int j_lo = NSLOT * g_out + NSLOT + PB * ks;
+                bool through = j_lo >= NE;
+                if (!through) {
+                    if (tid < 128) {
+                        const int j = j_lo + (tid >> 4), dd = tid & 15;
+                        if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_out)];
+                    }
+                    if (j_lo + PB < NE) break;
+                    // (that was its last chunk: the next generation's first may be due at this very tick)
                 }
-                if (tid < 128) {
-                    const int j = j_lo + (tid >> 4), dd = tid & 15;
-                    if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_of(g_out))];
-                }
-                if (j_lo + PB < NE) break;
-                ++g_out;  // that was its last chunk: the next generation's first may be due at this very tick
+                ++g_out;
+                off_out = off_of(g_out);
+                t_sl = g_out < g_res ? sStart[NSLOT * g_out + NSLOT - 1] : NEVER;
             }
 
-            const bool starting = k < 0 && sw < n_sweeps && tick == sStart[min(sw, n_sweeps - 1)];
+            const bool starting = k < 0 && tick == my_start;
             if (__any(starting)) {
                 const int j = starting ? sw : 0;
                 const int vj = modw(j + off);
@@ -848,6 +862,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                         k = -1;
                         sw += NSLOT;
                         off = off_of(sw / NSLOT);
+                        my_start = sw < n_sweeps ? sStart[sw] : NEVER;
                     }
                 }
             }
