@@ -56,6 +56,8 @@ __device__ unsigned long long tbk_band_clock[32];
 //   TBK_ABLATE_OPERANDS  every visit reads the partner's [V | W] / Vn operand blocks of ONE fixed block (always cached)
 //   TBK_ABLATE_BARRIER   no workgroup barrier per step of the pass
 //   TBK_ABLATE_STORES    the updated tiles are never stored (an upper bound for ANY scheme that defers the update)
+//   TBK_ABLATE_WIN_IO    band_chase4w_kernel without the global loads / stores of the columns that enter and leave the window
+//   TBK_ABLATE_WIN_FORCE the 32-slot window kernel from 257 orbitals on at every call size (against the plain LDS form at 512)
 //   TBK_ABLATE_STORES_ALT  ... stored on every second panel only: what "the rank-16 update every second panel" saves in
 //                        stores, before any of its costs (a K = 32 update, the corrections of the products)
 constexpr int PB = 8;    // panel height = band half-width
@@ -717,16 +719,22 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                     const int j = j_lo + (tid >> 4), dd = tid & 15;
                     if (j < j_hi) {
                         pf_idx = dd * CWP + modw(j + off_in);
-                        if (j < n) pf_val = gband[(size_t)dd * np + j];
+#if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_LOADS)
+                        // (no `j < n ? ... : 0`: the buffer's columns n .. n + 7 ARE zeros (np >= n + 8, nothing is ever written back there),
+                        // and a select would want the loaded value at once -- the whole memory latency at the head of every tick: 12 %)
+                        pf_val = gband[(size_t)dd * np + j];
+#endif
                     }
                 }
             }
             // ---- columns that leave: untouched since the last tick ----
             if (tick == t_ev) {
+#if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_STORES)
                 if (tid >= 128 && tid < 144) {
                     const int dd = tid - 128;
                     gband[(size_t)dd * np + s_ev] = win[dd * CWP + modw(s_ev + off_ev)];
                 }
+#endif
                 ++s_ev;
                 if (s_ev < NSLOT * g_res) {
                     t_ev = sStart[s_ev] + 1;
@@ -741,10 +749,12 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                 const int j_lo = NSLOT * g_out + NSLOT + PB * ks;
                 bool through = j_lo >= NE;
                 if (!through) {
+#if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_STORES)
                     if (tid < 128) {
                         const int j = j_lo + (tid >> 4), dd = tid & 15;
                         if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_out)];
                     }
+#endif
                     if (j_lo + PB < NE) break;
                     // (that was its last chunk: the next generation's first may be due at this very tick)
                 }
@@ -3463,7 +3473,12 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
     // TBK_CHASE_WINDOW=0 (measurements): no windowed kernel -- above 512 orbitals the global-memory form, the plain LDS form below
     static const bool window_env = !(getenv("TBK_CHASE_WINDOW") && atoi(getenv("TBK_CHASE_WINDOW")) == 0);
     const bool small_window = window_env && chase_small_window(m, n, nk);
-    if (n > BAND_LDS_CHASE_MAXN || chase_global_forced(n) || small_window) {
+#ifdef TBK_ABLATE_WIN_FORCE  // (timing: the 32-slot window from 257 orbitals on, at every call size)
+    const bool win_force = n > 256 && !tbk_band_fused(n);
+#else
+    const bool win_force = false;
+#endif
+    if (n > BAND_LDS_CHASE_MAXN || chase_global_forced(n) || small_window || win_force) {
         const int np = chase_pitch(n);
         // The working diagonals in a cyclic LDS window in front of the global buffer (band_chase4w_kernel; the same bits as the
         // global-memory form below).  One workgroup per CU (158 KiB of LDS) and still ahead at every call size: whole eigenval of
@@ -3472,7 +3487,7 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
         if (window_env && !chase_global_forced(n)) {
             d2* d_b = static_cast<d2*>(const_cast<void*>(d_band));
             const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
-            if (small_window) {
+            if (small_window && !win_force) {
                 const size_t ldsw = (size_t)16 * 281 * 16 + (size_t)4 * 64 * 16 + (size_t)n * sizeof(int) + 16;
                 static std::atomic<bool> raised_s[TBK_MAX_DEVICES] = {};
                 TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_chase4w_kernel<4, 272, 281>), 160 * 1024, raised_s));
