@@ -624,7 +624,10 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
     }
     wg_sync();
     if (n_sweeps > 0) {
-        const int total_ticks = sStart[n_sweeps - 1] + sweep_len(n_sweeps - 1);
+        // (what the trackers read of the schedule goes through readfirstlane: uniform by construction, and only so does the compiler
+        // keep them and everything derived from them in scalar registers -- the tracker arithmetic of every tick on the scalar unit)
+        auto sched = [&](int s) { return __builtin_amdgcn_readfirstlane(sStart[s]); };
+        const int total_ticks = sched(n_sweeps - 1) + sweep_len(n_sweeps - 1);
         const int n_gen = (n_sweeps + NSLOT - 1) / NSLOT;
         const int last_fetch_gen = min(g_res, n_gen - 1);
         // the columns generation 0 needs at tick 0
@@ -684,12 +687,15 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
         };
         // (uniform) trackers of the columns that enter and leave; what they need of the schedule is read when it changes, not per tick
         constexpr int NEVER = 0x7fffffff;
+        const int io_c = tid >> 4, io_dd = tid & 15;  // this thread's column of a chunk and diagonal, when it moves an element
+        const int io_row = io_dd * CWP;
+        const d2* io_g = gband + (size_t)io_dd * np;
         int g_in = 0, t0_in = 0, off_in = 0;   // generation whose first sweep leads, its first tick, its offset
-        int t_in_next = last_fetch_gen > 0 ? sStart[NSLOT] : NEVER;  // first tick of the generation that leads next
+        int t_in_next = last_fetch_gen > 0 ? sched(NSLOT) : NEVER;  // first tick of the generation that leads next
         int s_ev = 0, off_ev = 0;              // next sweep whose own column leaves (generations that leave only)
-        int t_ev = g_res > 0 ? sStart[0] + 1 : NEVER;
+        int t_ev = g_res > 0 ? sched(0) + 1 : NEVER;
         int g_out = 0, off_out = 0;            // generation whose last sweep trails
-        int t_sl = g_res > 0 ? sStart[NSLOT - 1] : NEVER;  // first tick of that sweep
+        int t_sl = g_res > 0 ? sched(NSLOT - 1) : NEVER;  // first tick of that sweep
         int my_start = sw < n_sweeps ? sStart[sw] : NEVER;  // first tick of this slot's next sweep
 
         for (int tick = 0; tick < total_ticks; ++tick) {
@@ -703,26 +709,26 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                     // slots: they lie behind the matrix, i.e. they are zeros; their cells are free since the last tick)
                     const int j_old = NSLOT * g_in + 1 + PB * (nt - t0_in);
                     if (j_old < NE && tid < 128) {
-                        const int j = j_old + (tid >> 4), dd = tid & 15;
-                        if (j < NE) win[dd * CWP + modw(j + off_in)] = (d2){0.0, 0.0};
+                        const int j = j_old + io_c;
+                        if (j < NE) win[io_row + wrapw(modw(j_old + off_in) + io_c)] = (d2){0.0, 0.0};
                     }
                     ++g_in;
                     t0_in = t_in_next;
                     off_in = off_of(g_in);
-                    t_in_next = g_in < last_fetch_gen ? sStart[NSLOT * (g_in + 1)] : NEVER;
+                    t_in_next = g_in < last_fetch_gen ? sched(NSLOT * (g_in + 1)) : NEVER;
                 }
                 const int kk = nt - t0_in;
                 if (kk >= 0) {
                     const int base = NSLOT * g_in;
                     const int j_lo = kk == 0 ? base : base + 1 + PB * kk;
                     const int j_hi = min(base + 9 + PB * kk, NE);
-                    const int j = j_lo + (tid >> 4), dd = tid & 15;
+                    const int j = j_lo + io_c;
                     if (j < j_hi) {
-                        pf_idx = dd * CWP + modw(j + off_in);
+                        pf_idx = io_row + wrapw(modw(j_lo + off_in) + io_c);
 #if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_LOADS)
                         // (no `j < n ? ... : 0`: the buffer's columns n .. n + 7 ARE zeros (np >= n + 8, nothing is ever written back there),
                         // and a select would want the loaded value at once -- the whole memory latency at the head of every tick: 12 %)
-                        pf_val = gband[(size_t)dd * np + j];
+                        pf_val = io_g[j];
 #endif
                     }
                 }
@@ -737,7 +743,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
 #endif
                 ++s_ev;
                 if (s_ev < NSLOT * g_res) {
-                    t_ev = sStart[s_ev] + 1;
+                    t_ev = sched(s_ev) + 1;
                     if (s_ev % NSLOT == 0) off_ev = off_of(s_ev / NSLOT);
                 } else {
                     t_ev = NEVER;
@@ -751,8 +757,8 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                 if (!through) {
 #if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_STORES)
                     if (tid < 128) {
-                        const int j = j_lo + (tid >> 4), dd = tid & 15;
-                        if (j < n) gband[(size_t)dd * np + j] = win[dd * CWP + modw(j + off_out)];
+                        const int j = j_lo + io_c;
+                        if (j < n) const_cast<d2*>(io_g)[j] = win[io_row + wrapw(modw(j_lo + off_out) + io_c)];
                     }
 #endif
                     if (j_lo + PB < NE) break;
@@ -760,7 +766,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
                 }
                 ++g_out;
                 off_out = off_of(g_out);
-                t_sl = g_out < g_res ? sStart[NSLOT * g_out + NSLOT - 1] : NEVER;
+                t_sl = g_out < g_res ? sched(NSLOT * g_out + NSLOT - 1) : NEVER;
             }
 
             const bool starting = k < 0 && tick == my_start;
