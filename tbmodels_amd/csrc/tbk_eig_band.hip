@@ -577,7 +577,12 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
     static_assert(CW >= 15 * NSLOT + 18 && CWP >= CW + PB && CWP % 16 == 9, "window too small for the sweeps in flight / pitch");
     extern __shared__ __attribute__((aligned(16))) double bw_smem[];
     auto modw = [](int x) { return x % CW; };                 // x >= 0
-    auto wrapw = [](int x) { return x >= CW ? x - CW : x; };  // 0 <= x < 2 CW
+    auto wrapw = [](int x) {  // 0 <= x < 2 CW
+        if constexpr ((CW & (CW - 1)) == 0)
+            return x & (CW - 1);  // (one instruction instead of compare + subtract + select: nine addresses per tick and sweep)
+        else
+            return x >= CW ? x - CW : x;
+    };
     const size_t mat = blockIdx.x;
     const d2* band = band_all + mat * band_stride;
     d2* gband = band_all + mat * band_stride + (size_t)n * (PB + 1);  // [16][np], element (i, j) at (i - j) np + j
@@ -689,7 +694,10 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
         constexpr int NEVER = 0x7fffffff;
         const int io_c = tid >> 4, io_dd = tid & 15;  // this thread's column of a chunk and diagonal, when it moves an element
         const int io_row = io_dd * CWP;
-        const d2* io_g = gband + (size_t)io_dd * np;
+        // (uniform base + 32-bit byte offset: scalar-base addressing, two vector instructions per address instead of 64-bit arithmetic;
+        // a matrix' diagonals are < 4 GiB)
+        const unsigned io_goff = (unsigned)io_dd * (unsigned)np * 16u;
+        auto g_at = [&](unsigned byte_off) -> d2& { return *reinterpret_cast<d2*>(reinterpret_cast<char*>(gband) + byte_off); };
         int g_in = 0, t0_in = 0, off_in = 0;   // generation whose first sweep leads, its first tick, its offset
         int t_in_next = last_fetch_gen > 0 ? sched(NSLOT) : NEVER;  // first tick of the generation that leads next
         int s_ev = 0, off_ev = 0;              // next sweep whose own column leaves (generations that leave only)
@@ -728,7 +736,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
 #if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_LOADS)
                         // (no `j < n ? ... : 0`: the buffer's columns n .. n + 7 ARE zeros (np >= n + 8, nothing is ever written back there),
                         // and a select would want the loaded value at once -- the whole memory latency at the head of every tick: 12 %)
-                        pf_val = io_g[j];
+                        pf_val = g_at(io_goff + (unsigned)j * 16u);
 #endif
                     }
                 }
@@ -736,10 +744,8 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
             // ---- columns that leave: untouched since the last tick ----
             if (tick == t_ev) {
 #if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_STORES)
-                if (tid >= 128 && tid < 144) {
-                    const int dd = tid - 128;
-                    gband[(size_t)dd * np + s_ev] = win[dd * CWP + modw(s_ev + off_ev)];
-                }
+                if (tid >= 128 && tid < 144)  // (io_dd = tid - 128 there)
+                    g_at(io_goff + (unsigned)s_ev * 16u) = win[io_row + modw(s_ev + off_ev)];
 #endif
                 ++s_ev;
                 if (s_ev < NSLOT * g_res) {
@@ -758,7 +764,7 @@ band_chase4w_kernel(d2* __restrict__ band_all, size_t band_stride, int n, int np
 #if !defined(TBK_ABLATE_WIN_IO) && !defined(TBK_ABLATE_WIN_STORES)
                     if (tid < 128) {
                         const int j = j_lo + io_c;
-                        if (j < n) const_cast<d2*>(io_g)[j] = win[io_row + wrapw(modw(j_lo + off_out) + io_c)];
+                        if (j < n) g_at(io_goff + (unsigned)j * 16u) = win[io_row + wrapw(modw(j_lo + off_out) + io_c)];
                     }
 #endif
                     if (j_lo + PB < NE) break;
