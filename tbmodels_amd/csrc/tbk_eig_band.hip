@@ -3338,9 +3338,14 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     static const bool y_lds_env = !(getenv("TBK_BAND_XL_YLDS") && atoi(getenv("TBK_BAND_XL_YLDS")) == 0);
     const bool y_lds = y_lds_env && n <= BAND_ONE_WG_MAXN;
     const size_t y_bytes = (size_t)npad * PB * sizeof(d2);
+    // up to 256 orbitals the rows fill four waves only: a workgroup of four (TBK_BAND_XL_SERIAL4=0: eight, measurements) meets faster
+    static const bool serial4_env = !(getenv("TBK_BAND_XL_SERIAL4") && atoi(getenv("TBK_BAND_XL_SERIAL4")) == 0);
+    const bool four_waves = serial4_env && y_lds && n <= 256;
     if (y_lds) {
         static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
         TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_xl_serial_kernel<NTS, true>), 132 * 1024, raised));
+        static std::atomic<bool> raised4[TBK_MAX_DEVICES] = {};
+        TBK_HIP(tbk_raise_lds_limit(reinterpret_cast<const void*>(&band_xl_serial_kernel<256, true>), 132 * 1024, raised4));
     }
     // A batch above 1024 orbitals goes in GROUPS of matrices on streams of their own: the serial phases of a panel occupy one
     // workgroup per matrix (a latency chain on a quarter of the CUs at 64 matrices) while the sweep is bound by HBM, and the second
@@ -3359,8 +3364,12 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
         int cur = 0;
         for (int p = 0; p <= p_end; ++p) {
             if (y_lds)
-                hipLaunchKernelGGL((band_xl_serial_kernel<NTS, true>), dim3((unsigned)nkg), dim3(NTS), y_bytes, st, b[cur], n, vw, vn, xy, tt, p,
-                                   bd, stride);
+                if (four_waves)
+                    hipLaunchKernelGGL((band_xl_serial_kernel<256, true>), dim3((unsigned)nkg), dim3(256), y_bytes, st, b[cur], n, vw, vn, xy, tt, p,
+                                       bd, stride);
+                else
+                    hipLaunchKernelGGL((band_xl_serial_kernel<NTS, true>), dim3((unsigned)nkg), dim3(NTS), y_bytes, st, b[cur], n, vw, vn, xy, tt, p,
+                                       bd, stride);
             else
                 hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nkg), dim3(NTS), 0, st, b[cur], n, vw, vn, xy, tt, p, bd,
                                    stride);
