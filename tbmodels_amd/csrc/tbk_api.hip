@@ -1096,7 +1096,8 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
     {
         const size_t k_bytes = (size_t)nk * m->dim * sizeof(double), h_bytes = (size_t)nk * nn2 * sizeof(double);
         const size_t p_bytes = convention == 1 ? (size_t)m->n_orb * m->dim * sizeof(double) : 0;
-        if (m->h_stage != nullptr && k_bytes + p_bytes + h_bytes <= m->h_stage_bytes) {
+        const size_t h_off = (k_bytes + p_bytes + 63) / 64 * 64;  // (16-byte stores of H: keep the block aligned)
+        if (m->h_stage != nullptr && h_off + h_bytes <= m->h_stage_bytes) {
             // small result (one k-point: 64 KiB of H at 64 orbitals): [k | pos | H] through the pinned buffer.  The chunked
             // download below -- a blocking copy into pageable memory -- takes 290 us per call for results of 25 - 64 KiB
             // in a loop of one-k calls (tools/trace_single_k.py), this path 50 - 95 us whatever the size
@@ -1130,13 +1131,22 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
                     d_pos = m->ws_pos.as<double>();
                 }
             }
-            const int rc_inline = tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, m->ws_out.as<double>());
+            // Round 6: up to 1 MiB of H the kernels store straight into the pinned buffer (a host allocation is
+            // device-addressable; the stores collect in the L2 and leave with the system-scope release of ev_sync) -- no
+            // copy kernel and no dependent boundary in front of it: one-k hamilton 84 -> 68 us at 64 orbitals, 124 -> 112
+            // at 256 (sparse).  4 MiB (512 orbitals) written that way take longer than the copy (scattered 16-byte stores
+            // across PCIe: 1.69 -> 1.81 ms), so a bigger H still takes the copy; downloading it in two or four pieces, each
+            // copied on to the caller's array while the next crosses PCIe, was measured and is within the noise of the
+            // 1.3 - 1.4 ms kernel in front of it (1586 / 1661 / 1704 and 1568 / 1613 / 1563 us for 1 / 2 / 4 pieces).
+            const bool direct = h_bytes <= (size_t(1) << 20);
+            double* d_out = direct ? reinterpret_cast<double*>(st + h_off) : m->ws_out.as<double>();
+            const int rc_inline = tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, d_out);
             m->h_k_inline = nullptr;
             m->d_pos_inline = nullptr;
             TBK_CHECK(rc_inline);
-            TBK_HIP(hipMemcpyAsync(st + k_bytes + p_bytes, m->ws_out.ptr, h_bytes, hipMemcpyDeviceToHost, m->stream));
+            if (!direct) TBK_HIP(hipMemcpyAsync(st + h_off, m->ws_out.ptr, h_bytes, hipMemcpyDeviceToHost, m->stream));
             TBK_CHECK(wait_main_stream(m));
-            std::memcpy(H_out, st + k_bytes + p_bytes, h_bytes);
+            std::memcpy(H_out, st + h_off, h_bytes);
             return TBK_OK;
         }
     }
@@ -1184,10 +1194,11 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
     const size_t k_bytes = (size_t)nk * m->dim * sizeof(double), e_bytes = (size_t)nk * m->n_orb * sizeof(double);
     TBK_CHECK(m->ws_k.reserve(k_bytes));
     TBK_CHECK(m->ws_out.reserve(e_bytes));
-    if (m->h_stage != nullptr && k_bytes + e_bytes + 16 <= m->h_stage_bytes) {
+    const size_t e_off = (k_bytes + 63) / 64 * 64;
+    if (m->h_stage != nullptr && e_off + e_bytes + 16 <= m->h_stage_bytes) {
         // small call: [k | E | flags] through the pinned buffer, everything enqueued, one synchronisation
         char* st = static_cast<char*>(m->h_stage);
-        int* flag = reinterpret_cast<int*>(st + k_bytes + e_bytes);
+        int* flag = reinterpret_cast<int*>(st + e_off + e_bytes);
         // (one k-point of a dense model on the matrix-vector path: k travels in the kernel arguments, see tbk_hamilton --
         // only the chunk pipeline reads it from there: the rocSOLVER branch fills its phase rows from ws_k, which a call
         // that skipped the upload would leave stale)
@@ -1198,13 +1209,14 @@ extern "C" int tbk_eigenval(tbk_model* m, const double* k, int64_t nk, double* E
             std::memcpy(st, k, k_bytes);
             TBK_HIP(hipMemcpyAsync(m->ws_k.ptr, st, k_bytes, hipMemcpyHostToDevice, m->stream));
         }
+        // (the eigenvalues stored straight into the pinned buffer, like H in tbk_hamilton: measured, no gain -- 180.2 vs 180.0 us)
         const int rc_inline = eigenval_device_impl(m, m->ws_k.as<double>(), k, nk, m->ws_out.as<double>());
         m->h_k_inline = nullptr;
         TBK_CHECK(rc_inline);
-        TBK_HIP(hipMemcpyAsync(st + k_bytes, m->ws_out.ptr, e_bytes, hipMemcpyDeviceToHost, m->stream));
+        TBK_HIP(hipMemcpyAsync(st + e_off, m->ws_out.ptr, e_bytes, hipMemcpyDeviceToHost, m->stream));
         TBK_HIP(hipMemcpyAsync(flag, m->ws_flag.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
         TBK_CHECK(wait_main_stream(m));
-        std::memcpy(E_out, st + k_bytes, e_bytes);
+        std::memcpy(E_out, st + e_off, e_bytes);
         if (flag[0] != 0 || flag[1] != 0) return tbk_eigenval_check(m);  // (rare) the ordinary path reports and resets
         return TBK_OK;
     }

@@ -342,60 +342,113 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 
 // Batches of at most 32 k-points (Z2Pack-style callers evaluate one k-point per call): the 128-row MFMA tile would
 // spend most of its work on padding (127/128 for one k-point), so this is a plain matrix-vector product on the vector
-// unit -- one thread per packed element, up to 32 accumulator pairs, K split over blockIdx.y like the split-K launch above and finished by
-// the same hk_finish_kernel.  Bound by reading Bt once (272 MB at N_orb = 64, N_R = 4096: ~55 us).
+// unit, bound by reading Bt ONCE (272 MB at N_orb = 64, N_R = 4096; 8.6 GB at N_orb = 512, N_R = 2048).
+//
+// Round 6: a streaming kernel built from independent WAVES.  A row of Bt is `2 ncol_pad` doubles = ncol_pad / 64 blocks of
+// 128 doubles; a wave owns one block (16 B per lane: one global_load_dwordx4 reads 1 KiB of the row -- 8-byte loads reach
+// 0.54 - 0.70 of the 16-byte rate on gfx950, MI355X_MICROARCH.md) and a slice of whole lattice vectors (two K rows each), keeps
+// two batches of GEMV_U non-temporal loads in flight (row addresses in scalar registers, the lane as the offset), and needs
+// nothing from the other waves of its workgroup: no barrier anywhere, consecutive waves take consecutive blocks of the same
+// slice (a workgroup reads 4 KiB of every row).  The phase rows of the slice are made by the wave itself into a wave-private
+// strip of LDS, AFTER its first two batches have been issued (same arithmetic as tbk_phase.hip; the loads of the lattice
+// vectors share the counter of the stream, so the strip is made once, not in the loop); k.p models and slices too long for
+// the strip get finished rows (A != nullptr) instead.  A lane holds two `re` or two `im` values of neighbouring elements (Bt
+// is [tile][re | im][16]): one exchange with lane ^ 8 turns them into the (re, im) pairs of P[slice][k][e], which
+// hk_finish_kernel / hk_finish_wide_kernel add in slice order.  gemv_plan() cuts the slices so that the launch is either ONE
+// round of exactly two workgroups per CU (the dynamic LDS size is the occupancy limiter: a CU's share of the bytes is what
+// bounds the kernel, so a CU with a third workgroup would finish 1.5x late) or many rounds of workgroups of ~1 MB.
+constexpr int GEMV_U = 8;  // rows per batch of loads; two batches in flight
+
 template <int NKV, bool INLINE_PHASES>
-__global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int rows_per_slice) {
-    extern __shared__ __attribute__((aligned(16))) double s_rows[];  // INLINE_PHASES: [rows_per_slice][NKV]
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int64_t kk0 = (int64_t)blockIdx.y * rows_per_slice;
-    const int64_t kk1 = min(kk0 + rows_per_slice, a.k2);
+__global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double s_rows[];  // [4 waves][strip_doubles]: phase rows [row][NKV] of the wave's slice
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nblk = a.ncol_pad >> 6;
+    const int task = (int)blockIdx.x * 4 + wave;
+    const int sl = task / nblk, cb = task - sl * nblk;
+    if (sl >= a.splits) return;  // (whole waves: nothing below synchronises the workgroup)
+    const int64_t n_pairs = a.k2 >> 1;  // slices are cut between lattice vectors: a (cos, sin) pair of rows stays together
+    const int64_t kk0 = 2 * (sl * n_pairs / a.splits);
+    const int n_rows = (int)(2 * ((sl + 1) * n_pairs / a.splits) - kk0);
     const int64_t kbase = (int64_t)blockIdx.z * NKV;  // small models: groups of NKV k-points over blockIdx.z
     const int nk_here = (int)min((int64_t)NKV, a.nk - kbase);
-    if (INLINE_PHASES) {
-        // the slice's phase rows, made here instead of by a phase_rows_kernel launch of their own (one dependent
-        // launch less: ~10 us of a 90 us single-k hamilton() call); same arithmetic as tbk_phase.hip
-        const int cells = (int)(kk1 - kk0) * NKV;
-        for (int idx = threadIdx.x; idx < cells; idx += 256) {
-            const int row = idx / NKV, q = idx % NKV;
-            const int64_t kk = kk0 + row, r = kk >> 1;
-            double v = 0.0;
-            if (q < nk_here && r < a.n_r) {
-                double dot = 0.0;
-                for (int d = 0; d < a.dim; ++d) dot = fma(hk_kcomp(a, kbase + q, d), (double)a.R[r * a.dim + d], dot);
-                double sn, cs;
-                sincospi(2.0 * dot, &sn, &cs);
-                v = (kk & 1) ? sn : cs;
-            }
-            s_rows[idx] = v;
-        }
-        __syncthreads();
-    }
-    if (e >= a.ncol_pad) return;
-    const int64_t ldb = (int64_t)a.ncol_pad * 2;
-    const double* bre = a.Bt + (size_t)(e >> 4) * 32 + (e & 15);  // Bt[kk][tile][re | im][16]
+    const int64_t ld2 = a.ncol_pad;  // row stride of Bt in 16-byte units
+    // (wave-uniform row pointers + the lane as a 32-bit offset: the loads take their row address from scalar registers)
+    const d2* rows = reinterpret_cast<const d2*>(a.Bt) + kk0 * ld2 + cb * 64;
+    double* strip = s_rows + wave * strip_doubles;
+
+    d2 buf0[GEMV_U], buf1[GEMV_U];
     double acc[NKV][2];
 #pragma unroll
     for (int q = 0; q < NKV; ++q) acc[q][0] = acc[q][1] = 0.0;
-#pragma unroll 4
-    for (int64_t kk = kk0; kk < kk1; ++kk) {
-        const double br = bre[kk * ldb], bi = bre[kk * ldb + 16];
-        // uniform: phase row kk, k-points 0 .. NKV-1
-        const double* arow = INLINE_PHASES ? s_rows + (kk - kk0) * NKV : a.A + kk * a.nk_pad + kbase;
+
+    // a batch of GEMV_U rows; rows past the slice's end re-read its last row (a cache hit) and are skipped by consume().  No
+    // branch around a batch: behind a merge of control flow the compiler's wait counts assume the SHORTER queue, and the
+    // first use of one batch would wait for the whole of the next
+    auto fetch = [&](d2 (&buf)[GEMV_U], int base) {
 #pragma unroll
-        for (int q = 0; q < NKV; ++q) {
-            const double aq = arow[q];
-            acc[q][0] = fma(aq, br, acc[q][0]);
-            acc[q][1] = fma(aq, bi, acc[q][1]);
+        for (int u = 0; u < GEMV_U; ++u) {
+            const int r = min(base + u, n_rows - 1);
+            buf[u] = __builtin_nontemporal_load(rows + (int64_t)r * ld2 + lane);
         }
+    };
+    auto consume = [&](const d2 (&buf)[GEMV_U], int row) {
+        // uniform: phase row `row`, k-points 0 .. NKV-1
+        const double* arow = INLINE_PHASES ? strip + row * NKV : a.A + (kk0 + row) * a.nk_pad + kbase;
+        const int64_t lda = INLINE_PHASES ? NKV : a.nk_pad;
+#pragma unroll
+        for (int u = 0; u < GEMV_U; ++u) {
+            if (!INLINE_PHASES && row + u >= n_rows) break;  // (the strip holds zeros past the slice's end; finished rows end with A)
+#pragma unroll
+            for (int q = 0; q < NKV; ++q) {
+                const double aq = arow[u * lda + q];
+                acc[q][0] = fma(aq, buf[u][0], acc[q][0]);
+                acc[q][1] = fma(aq, buf[u][1], acc[q][1]);
+            }
+        }
+    };
+    fetch(buf0, 0);
+    fetch(buf1, GEMV_U);
+    if (INLINE_PHASES) {
+        // n_rows / 2 lattice vectors x NKV k-points, cos and sin of each; zeros up to the next multiple of 16 rows
+        for (int idx = lane; idx < ((n_rows + 15) >> 4) * 8 * NKV; idx += 64) {
+            const int rr = idx / NKV, q = idx % NKV;
+            const int64_t r = (kk0 >> 1) + rr;
+            double sn = 0.0, cs = 0.0;
+            if (q < nk_here && r < a.n_r && 2 * rr < n_rows) {
+                double dot = 0.0;
+                for (int d = 0; d < a.dim; ++d) dot = fma(hk_kcomp(a, kbase + q, d), (double)a.R[r * a.dim + d], dot);
+                sincospi(2.0 * dot, &sn, &cs);
+            }
+            strip[(2 * rr) * NKV + q] = cs;
+            strip[(2 * rr + 1) * NKV + q] = sn;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave writes and reads the strip: its LDS operations execute in order
     }
-    // (a predicate per k-point, not a `break`: leaving the unrolled loop early made the accumulator index dynamic, and
-    // hipcc then kept all 2 NKV accumulators of the 16- and 32-point instantiations in scratch memory: 272 / 528 B per thread)
+    for (int row = 0; row < n_rows; row += 2 * GEMV_U) {
+        // (scheduling fences: left alone, the compiler sinks both batches of loads below both batches of FMAs, and the queue
+        // runs empty once per trip)
+        consume(buf0, row);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(buf0, row + 2 * GEMV_U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(buf1, row + GEMV_U);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(buf1, row + 3 * GEMV_U);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // lanes l and l ^ 8 hold (re, re') and (im, im') of elements e0, e0 + 1: after the exchange lane l writes element e0,
+    // lane l ^ 8 element e0 + 1.  (A predicate per k-point, not a `break`: leaving the unrolled loop early made the
+    // accumulator index dynamic and the accumulators of the 16- and 32-point instantiations went to scratch memory.)
+    const bool hi = (lane & 8) != 0;
+    const int e = cb * 64 + (lane >> 4) * 16 + (lane & 7) * 2 + (hi ? 1 : 0);
 #pragma unroll
     for (int q = 0; q < NKV; ++q) {
+        const double got = __shfl_xor(hi ? acc[q][0] : acc[q][1], 8, 64);
         if (q < nk_here) {
-            double* part = a.P + (((size_t)blockIdx.y * a.p_rows + kbase + q) * a.ncol_pad + e) * 2;
-            *reinterpret_cast<d2*>(part) = (d2){acc[q][0], acc[q][1]};
+            double* part = a.P + (((size_t)sl * a.p_rows + kbase + q) * a.ncol_pad + e) * 2;
+            *reinterpret_cast<d2*>(part) = hi ? (d2){got, acc[q][1]} : (d2){acc[q][0], got};
         }
     }
 }
@@ -486,29 +539,36 @@ __global__ void __launch_bounds__(256) hk_finish_tiles_kernel(const HkArgs a) {
 }
 
 template <int MODE, int CONV>
-hipError_t launch_gemv(const HkArgs& a, int rows_per_slice, hipStream_t s) {
-    const dim3 grid((unsigned)((a.ncol_pad + 255) / 256), (unsigned)a.splits, (unsigned)((a.nk + 31) / 32));
-#define TBK_GEMV(N)                                                                                              \
-    do {                                                                                                         \
-        if (a.A == nullptr)                                                                                      \
-            hipLaunchKernelGGL((hk_gemv_kernel<N, true>), grid, dim3(256), (size_t)rows_per_slice * N * sizeof(double), s, a, \
-                               rows_per_slice);                                                                  \
-        else                                                                                                     \
-            hipLaunchKernelGGL((hk_gemv_kernel<N, false>), grid, dim3(256), 0, s, a, rows_per_slice);            \
+hipError_t launch_gemv(tbk_model* m, const HkArgs& a, size_t lds, hipStream_t s) {
+    const int tasks = (a.ncol_pad >> 6) * a.splits;  // waves: (block of 64 packed elements) x (K slice)
+    const dim3 grid((unsigned)((tasks + 3) / 4), 1, (unsigned)((a.nk + 31) / 32));
+    static std::atomic<bool> raised[2][6][TBK_MAX_DEVICES] = {};
+#define TBK_GEMV(N, SLOT)                                                                                               \
+    do {                                                                                                                \
+        if (a.A == nullptr) {                                                                                           \
+            hipError_t e1 = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_gemv_kernel<N, true>), 160 * 1024, raised[0][SLOT]); \
+            if (e1 != hipSuccess) return e1;                                                                            \
+            hipLaunchKernelGGL((hk_gemv_kernel<N, true>), grid, dim3(256), lds, s, a, (int)(lds / 32));                                  \
+        } else {                                                                                                        \
+            hipError_t e1 = tbk_raise_lds_limit(reinterpret_cast<const void*>(&hk_gemv_kernel<N, false>), 160 * 1024, raised[1][SLOT]); \
+            if (e1 != hipSuccess) return e1;                                                                            \
+            hipLaunchKernelGGL((hk_gemv_kernel<N, false>), grid, dim3(256), lds, s, a, (int)(lds / 32));                                 \
+        }                                                                                                               \
     } while (0)
     if (a.nk <= 1)
-        TBK_GEMV(1);
+        TBK_GEMV(1, 0);
     else if (a.nk <= 2)
-        TBK_GEMV(2);
+        TBK_GEMV(2, 1);
     else if (a.nk <= 4)
-        TBK_GEMV(4);
+        TBK_GEMV(4, 2);
     else if (a.nk <= 8)
-        TBK_GEMV(8);
+        TBK_GEMV(8, 3);
     else if (a.nk <= 16)
-        TBK_GEMV(16);
+        TBK_GEMV(16, 4);
     else
-        TBK_GEMV(32);
+        TBK_GEMV(32, 5);
 #undef TBK_GEMV
+    (void)m;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t threads = a.nk * a.ncol_pad;
@@ -604,15 +664,30 @@ int launch(tbk_model* m, const HkArgs& a0, int grid) {
     return TBK_OK;
 }
 
-// K slices of the matrix-vector path: ~1024 workgroups of 256 packed elements x one K slice each
-void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, int* rows_out) {
-    const int col_blocks = (m->ncol_pad + 255) / 256;
+// K slices of the matrix-vector path: (blocks of 64 packed elements) x (K slices) independent waves, four to a workgroup.
+// The kernel is bound by the bytes a CU pulls, so the workgroups must come out EVEN over the CUs: an operand of up to ~1.5 MB
+// per workgroup slot goes in ONE round of at most two workgroups per CU (`*lds_out` = half a CU's LDS keeps a third one away);
+// a bigger one in workgroups of ~1 MB (256 rows per wave), many rounds, the ragged end a few per cent.  The partial sums
+// (one row of P per slice and k-point) stay below 256 MB.
+void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, size_t* lds_out) {
+    const int nblk = m->ncol_pad / 64;
+    const int64_t n_pairs = m->k2 / 2;
     const size_t per_split = (size_t)nk * m->ncol_pad * 2 * sizeof(double);
-    int slices = std::max(1, std::min(1024 / col_blocks, (int)(m->k2 / 32)));
-    slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices, (size_t(64) << 20) / per_split));
-    const int rows_per_slice = (int)((m->k2 + slices - 1) / slices);
-    *slices_out = (int)((m->k2 + rows_per_slice - 1) / rows_per_slice);
-    *rows_out = rows_per_slice;
+    const int64_t cap = std::max<int64_t>(1, (int64_t)((size_t(256) << 20) / per_split));
+    const int64_t wave_slots = (int64_t)m->n_cu * 8;  // two workgroups per CU
+    int64_t slices = wave_slots / nblk;               // one round: nblk * slices <= slots
+    size_t lds = 80 * 1024;
+    const int64_t rows_one_round = slices > 0 ? (m->k2 + slices - 1) / slices : m->k2 + 1;
+    if (slices < 1 || nblk * slices * 10 < wave_slots * 9 || rows_one_round > 384 || slices > cap) {
+        // many rounds: workgroups of ~1 MB, at least eight per CU while a slice keeps 32 rows
+        slices = std::max<int64_t>(m->k2 / 256, std::min<int64_t>(((int64_t)m->n_cu * 32 + nblk - 1) / nblk, n_pairs / 16));
+        slices = std::max<int64_t>(1, std::min(cap, slices));
+        lds = 16 * 1024;
+    }
+    slices = std::max<int64_t>(1, std::min(slices, n_pairs / 8));  // at least 16 rows per slice
+    if (nblk * slices * 2 <= wave_slots) lds = 16 * 1024;  // (a small model: nothing to balance)
+    *slices_out = (int)slices;
+    *lds_out = lds;
 }
 
 }  // namespace
@@ -621,11 +696,15 @@ void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, int* rows_out) {
 // skips tbk_launch_phase and passes d_A = nullptr.
 bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk) {
     if (!tbk_hk_gemv_path(m, nk) || m->kdotp || m->d_R == nullptr) return false;
-    int slices, rows;
-    gemv_plan(m, nk, &slices, &rows);
+    // the phase rows of a wave's slice for its (up to 32) k-points must fit its strip of the workgroup's LDS
+    int slices;
+    size_t lds;
+    gemv_plan(m, nk, &slices, &lds);
+    const int64_t n_pairs = m->k2 / 2;
+    const int64_t rows_max = 2 * ((n_pairs + slices - 1) / slices);
     int nkv = 1;
     while (nkv < std::min<int64_t>(nk, 32)) nkv *= 2;
-    return (size_t)rows * nkv * sizeof(double) <= (size_t(32) << 10);
+    return (rows_max + 15) / 16 * 16 * nkv <= (int64_t)(lds / 32);
 }
 
 // The matrix-vector path: up to 32 k-points of any model, and up to 4096 k-points (in groups of 32) of a SMALL model --
@@ -682,8 +761,9 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     a.pos_raw = nullptr;
     for (int d = 0; d < TBK_MAX_DIM; ++d) a.k_val[d] = 0.0;
     if (tbk_hk_gemv_path(m, nk)) {
-        int slices, rows_per_slice;
-        gemv_plan(m, nk, &slices, &rows_per_slice);
+        int slices;
+        size_t lds;
+        gemv_plan(m, nk, &slices, &lds);
         const size_t per_split = (size_t)nk * a.ncol_pad * 2 * sizeof(double);
         if (m->h_k_inline != nullptr && nk == 1 && d_A == nullptr && tbk_hk_inline_phases(m, 1)) {
             a.k_inline = 1;  // (tbk_hamilton / tbk_eigenval on host buffers, one k-point: no upload of k)
@@ -698,11 +778,11 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
         a.p_rows = nk;
         StageTimer t(m, TBK_T_HK);
         if (mode == HK_TRI) {
-            TBK_HIP((launch_gemv<HK_TRI, 2>(a, rows_per_slice, m->stream)));
+            TBK_HIP((launch_gemv<HK_TRI, 2>(m, a, lds, m->stream)));
         } else if (convention == 1) {
-            TBK_HIP((launch_gemv<HK_FULL, 1>(a, rows_per_slice, m->stream)));
+            TBK_HIP((launch_gemv<HK_FULL, 1>(m, a, lds, m->stream)));
         } else {
-            TBK_HIP((launch_gemv<HK_FULL, 2>(a, rows_per_slice, m->stream)));
+            TBK_HIP((launch_gemv<HK_FULL, 2>(m, a, lds, m->stream)));
         }
         return TBK_OK;
     }
