@@ -277,6 +277,27 @@ def trace_identity_error(arrays, k_slab, eig_all, n_rows=4096):
     return float(np.abs(eig_all[rows].sum(axis=1) - 2.0 * (phase @ traces).real).max())
 
 
+def second_moment_error(lib, model, n_orb, k_slab, eig_all, n_rows, chunk_bytes=256 << 20):
+    """The second moment of every sampled spectrum against H(k) itself: sum_i E_i(k)^2 = ||H(k)||_F^2, with H(k) from the
+    H(k) kernels (tbk_hamilton on host buffers; their parity with the oracle is pinned separately), on `n_rows` rows drawn
+    from the whole slab.  Where the trace identity holds the eigensolver to the first moment only, this holds it to H on
+    every row.  Returned as an equivalent eigenvalue error: max_k |sum E^2 - ||H||_F^2| / (2 sum_i |E_i|) -- a uniform
+    error of that size on every eigenvalue would produce the difference (compare with the 1e-10 bar)."""
+    nk = len(k_slab)
+    rows = np.sort(np.random.default_rng(2).choice(nk, min(nk, n_rows), replace=False))
+    k_sel = np.ascontiguousarray(k_slab[rows])
+    per = max(1, int(chunk_bytes // (16 * n_orb * n_orb)))
+    frob = np.empty(len(rows))
+    ham = np.empty((min(per, len(rows)), n_orb, n_orb), dtype=np.complex128)
+    for lo in range(0, len(rows), per):
+        n = min(per, len(rows) - lo)
+        _lib.check(lib.tbk_hamilton(model, _lib.ptr(k_sel[lo:lo + n]), n, 2, None, _lib.ptr(ham)))
+        flat = ham[:n].view(np.float64).reshape(n, -1)
+        frob[lo:lo + n] = np.einsum("ij,ij->i", flat, flat)
+    e_sel = eig_all[rows]
+    return float((np.abs((e_sel * e_sel).sum(axis=1) - frob) / (2.0 * np.abs(e_sel).sum(axis=1))).max())
+
+
 def eig_roofline_entry(n_orb, matrices, eig_ms, steps):
     """The reduction to tridiagonal form: (16/3) n^3 flops per matrix (eigensolve, values only) over the
     HIP-event time of the reduction stage on its own stream."""
@@ -377,12 +398,28 @@ def hk_roofline_entry(arrays, n_orb, n_r, dim, stage_ms, stage_n, k_total, confi
     return entry
 
 
-def single_k_latency(lib, model, k_slab, n_orb, calls=128, warm=8):
-    """Wall-clock of ONE-k-point calls on host buffers -- what Z2Pack-style callers do (_tb_model.py:1103-1108)."""
+def staged_operand_bytes(arrays):
+    """Bytes of the staged hopping operand one H(k) evaluation has to read at least once: the dense
+    Bt[K][ncol_pad] of (re, im) pairs, K = 2 N_R rounded up to 16 rows, ncol = N (N + 1) / 2 rounded up to 64; for sparse
+    hoppings the 16-byte records (value + packed offsets) of the element-major CSR."""
+    n_orb = arrays["n_orb"]
+    if arrays["kind"] == "dense":
+        k_rows = (2 * len(arrays["R"]) + 15) // 16 * 16
+        ncol_pad = (n_orb * (n_orb + 1) // 2 + 63) // 64 * 64
+        return 16.0 * k_rows * ncol_pad
+    return 16.0 * len(arrays["val"])
+
+
+def single_k_latency(lib, model, k_slab, n_orb, calls=128, warm=8, arrays=None):
+    """Wall-clock of ONE-k-point calls on host buffers -- what Z2Pack-style callers do (_tb_model.py:1103-1108) -- and, with
+    `arrays`, the roofline of the H(k) kernels of such a call: HIP-event time of the "hk" stage of 8 further calls (for a
+    dense model hk_gemv_kernel + its finish kernel: one read of the staged operand + one write of H) against 8 TB/s."""
     one_h = np.empty((1, n_orb, n_orb), dtype=np.complex128)
     one_e = np.empty((1, n_orb))
     single = {}
     nk = len(k_slab)
+    # (stage timing off for the wall-clock: with it every call records and reads back HIP events, ~10 us per call)
+    _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 0))
     for name, call in (("hamilton", lambda q: lib.tbk_hamilton(model, _lib.ptr(k_slab[q:q + 1]), 1, 2, None, _lib.ptr(one_h))),
                        ("eigenval", lambda q: lib.tbk_eigenval(model, _lib.ptr(k_slab[q:q + 1]), 1, _lib.ptr(one_e)))):
         for q in range(warm):
@@ -391,6 +428,27 @@ def single_k_latency(lib, model, k_slab, n_orb, calls=128, warm=8):
         for q in range(warm, warm + calls):
             _lib.check(call(q % nk))
         single[name] = round((time.perf_counter() - t1) / calls * 1e6, 1)
+    if arrays is not None:
+        ms = (ctypes.c_double * _lib.TBK_T_COUNT)()
+        launches = (ctypes.c_int64 * _lib.TBK_T_COUNT)()
+        _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 1))
+        _lib.check(lib.tbk_get_timing(model, None, None, 1))
+        timed = 8
+        for q in range(timed):
+            _lib.check(lib.tbk_hamilton(model, _lib.ptr(k_slab[q % nk:q % nk + 1]), 1, 2, None, _lib.ptr(one_h)))
+        _lib.check(lib.tbk_get_timing(model, ms, launches, 1))
+        hk_us = ms[_lib.STAGE_NAMES.index("hk")] / timed * 1e3
+        nbytes = staged_operand_bytes(arrays) + 16.0 * n_orb * n_orb
+        rate = nbytes / (hk_us * 1e-6) / 1e12 if hk_us > 0 else 0.0
+        single["roofline"] = {
+            "kernel": "hk_gemv_kernel + hk_finish_wide_kernel" if arrays["kind"] == "dense" else "hk_csr_lds_kernel",
+            "bound": "hbm", "kernel_us": round(hk_us, 2), "bytes": nbytes, "TB/s": round(rate, 3), "peak": 8.0,
+            "frac": round(rate / 8.0, 4),
+            "note": "HIP events around the H(k) stage of a one-k hamilton call (all its kernels and the gaps between them); "
+                    "bytes = one read of the staged operand + one write of the full H; kernel traces: profiles/*_single_k_*.csv",
+        }
+    _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 1))  # (the callers measure with stage timing on)
+    _lib.check(lib.tbk_get_timing(model, None, None, 1))
     return single
 
 
@@ -463,10 +521,16 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         stage_n = {stage_name: launches[i] for i, stage_name in enumerate(_lib.STAGE_NAMES)}
         eig = np.empty((nk, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig), d_e, eig.nbytes))
+        moment_err = None
+        if n_orb > 64:
+            # sum E^2 = ||H(k)||_F^2 on 4096 rows (512 at 512 orbitals: 4 MiB of H per row) -- the eigensolver held to H itself
+            moment_rows = 4096 if n_orb <= 256 else 512
+            moment_err = second_moment_error(lib, model, n_orb, k, eig, moment_rows)
+            _lib.check(lib.tbk_get_timing(model, None, None, 1))
         single = None
         if os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
             # (a one-k call at 512 orbitals takes ~10 ms: fewer of them)
-            single = single_k_latency(lib, model, k, n_orb, calls=32 if n_orb > 128 else 128, warm=4 if n_orb > 128 else 8)
+            single = single_k_latency(lib, model, k, n_orb, calls=32 if n_orb > 128 else 128, warm=4 if n_orb > 128 else 8, arrays=arrays)
             _lib.check(lib.tbk_get_timing(model, None, None, 1))
     finally:
         lib.tbk_device_free(device, d_k)
@@ -509,11 +573,55 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         "oracle_sample": "%d rows (the first %d k-points of the workload%s)"
                          % (oracle_rows, oracle_rows, ": the rows of cpu_baseline_all_cores" if oracle_rows > sample else ""),
         "max_trace_identity_err_4096_rows": trace_err,
+        "max_second_moment_err": moment_err,
+        "second_moment_note": None if moment_err is None else
+                              "max |sum E^2 - ||H(k)||_F^2| / (2 sum |E|) over %d rows of the workload, H(k) from tbk_hamilton"
+                              % (4096 if n_orb <= 256 else 512),
         "model_build_and_staging_s": round(build_s, 2),
     }
-    if not (parity <= 1e-10 and trace_err <= 1e-10):
+    if not (parity <= 1e-10 and trace_err <= 1e-10 and (moment_err is None or moment_err <= 1e-10)):
         raise SystemExit("parity failure in %s: %r" % (name, entry))
     return entry
+
+
+def _sig(x, digits=4):
+    """`x` rounded to `digits` significant digits (None stays None): the summary has to stay short."""
+    if x is None:
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def make_summary(result):
+    """The figures of every config in <= 1.5 KB, to be the LAST key of the JSON line: the driver's record keeps the final
+    2000 characters of the output, and the full line is ~15 KB.  Per config: value, ms_per_step,
+    roofline.frac of its H(k) kernel, eig_roofline.frac in the pipeline and standalone, one-k latencies with the H(k)
+    fraction of 8 TB/s of such a call, cpu_baseline.value, max_abs_err_vs_oracle (+ the second-moment check)."""
+    def entry(src):
+        if not isinstance(src, dict) or "value" not in src:
+            return {"error": str((src or {}).get("error", "missing"))[:60]} if isinstance(src, dict) else None
+        eig = src.get("eig_roofline") or {}
+        single = src.get("single_k_us") or (src.get("host_api") or {}).get("single_k_us") or {}
+        return {
+            "v": _sig(src.get("value"), 6), "ms": _sig(src.get("ms_per_step")),
+            "hk": _sig((src.get("roofline") or {}).get("frac")),
+            "eig": _sig(eig.get("frac")), "eig_sa": _sig((eig.get("standalone") or {}).get("frac")),
+            "k1": [single.get("hamilton"), single.get("eigenval"), _sig((single.get("roofline") or {}).get("frac"))],
+            "cpu": _sig((src.get("cpu_baseline") or {}).get("value")),
+            "err": _sig(src.get("max_abs_err_vs_oracle"), 2), "m2": _sig(src.get("max_second_moment_err"), 2),
+        }
+    main_name = (result.get("config") or {}).get("workload", "cfg2")[:4]
+    out = {main_name: entry(result)}
+    for name, src in sorted((result.get("configs") or {}).items()):
+        out[name] = entry(src)
+    host = result.get("host_api") or {}
+    out["host"] = _sig(host.get("value"), 6)
+    out["host_h_GBs"] = _sig((host.get("hamilton") or {}).get("GB/s"))
+    out["construct"] = _sig((result.get("construct_only") or {}).get("value"), 6)
+    out["cpu_all"] = _sig((result.get("cpu_baseline_all_cores") or {}).get("value"))
+    out["keys"] = ("v=k-points/s ms=ms_per_step hk=roofline.frac eig=eig_roofline.frac eig_sa=.standalone.frac "
+                   "k1=[one-k hamilton us,eigenval us,H(k) frac of 8TB/s] cpu=cpu_baseline k/s err=max_abs_err_vs_oracle "
+                   "m2=second moment; host=host_api.value")
+    return out
 
 
 def strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays, steps=3, warmup=1, mesh=100):
@@ -889,7 +997,7 @@ def main():
         dt_list = time.perf_counter() - t1
         del as_list
         # Z2Pack-style callers evaluate ONE k-point per call (_tb_model.py:1103-1108): wall-clock of such calls
-        single = single_k_latency(lib, model, k_slab, n_orb, calls=32 if n_orb > 128 else 128, warm=4 if n_orb > 128 else 8)
+        single = single_k_latency(lib, model, k_slab, n_orb, calls=32 if n_orb > 128 else 128, warm=4 if n_orb > 128 else 8, arrays=arrays)
         host_api = {
             "value": round(nk_gpu / dt_call, 1), "unit": "k-points/s", "ms_per_call": round(dt_call * 1e3, 3),
             "single_k_us": single,
@@ -1012,6 +1120,8 @@ def main():
             "metric": "k-points/sec (H(k)+eig) at N_orb=%d, N_R=%d" % (n_orb, n_r) if not args.construct_only
                       else "k-points/sec (H(k) construction only) at N_orb=%d, N_R=%d" % (n_orb, n_r),
             "value": round(value, 1),
+            # the same call on HOST buffers (H2D of k and D2H of the eigenvalues inside: SURVEY 8(d) "Evidence"); N = 1 only
+            "value_host_buffers": host_api["value"] if host_api else None,
             "unit": "k-points/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -1063,6 +1173,7 @@ def main():
             lambda: strong_scaling_leg(lib, device, model, comm, group, world, rank, n_orb, arrays,
                                        mesh=int(os.environ.get("TBK_BENCH_STRONG_MESH", "100"))))
     if rank == 0 and result is not None:
+        result["summary"] = make_summary(result)  # LAST key: what survives in a record that keeps the end of the line
         print(json.dumps(result), flush=True)
     if strong_failed:  # the main line stands and says "strong_scaling": "failed"; the exit status below reports it too
         sys.stderr.write("[bench] the cfg4 strong-scaling leg failed on rank %d: see configs in the JSON line\n" % rank)

@@ -102,7 +102,9 @@ int tbk_model_set_option(tbk_model* m, int option, int64_t value);
 int tbk_model_info(const tbk_model* m, int* device, int* dim, int* n_orb, int64_t* n_r,
                    int* is_sparse, int64_t* staged_bytes);
 /* Event counters of a handle since its creation (which path the eigenvalue calls took). */
-enum { TBK_CNT_EIGENVAL_CALLS = 0, TBK_CNT_FOLDED_CALLS = 1, TBK_CNT_FOLDED_KPOINTS = 2, TBK_CNT_COUNT = 3 };
+enum { TBK_CNT_EIGENVAL_CALLS = 0, TBK_CNT_FOLDED_CALLS = 1, TBK_CNT_FOLDED_KPOINTS = 2,
+       TBK_CNT_LIBRARY_CALLS = 3, /* eigenvalue calls handed to rocSOLVER (on request, or above the own kernels' range) */
+       TBK_CNT_COUNT = 4 };
 int tbk_model_counter(tbk_model* m, int counter, int64_t* value);
 
 /* ---- the hot path, host buffers (what Model.hamilton / Model.eigenval call) -------------- */

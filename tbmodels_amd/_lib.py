@@ -25,7 +25,7 @@ TBK_ERR_NO_CONVERGENCE = 5
 TBK_EIG_AUTO, TBK_EIG_WAVE, TBK_EIG_ROCSOLVER = 0, 1, 2
 TBK_OPT_EIGENSOLVER, TBK_OPT_K_CHUNK, TBK_OPT_TIMING, TBK_OPT_FOLD = 1, 2, 3, 4
 TBK_REDUCE_AUTO, TBK_REDUCE_ONE_STAGE, TBK_REDUCE_TWO_STAGE = 0, 1, 2
-TBK_CNT_EIGENVAL_CALLS, TBK_CNT_FOLDED_CALLS, TBK_CNT_FOLDED_KPOINTS = 0, 1, 2
+TBK_CNT_EIGENVAL_CALLS, TBK_CNT_FOLDED_CALLS, TBK_CNT_FOLDED_KPOINTS, TBK_CNT_LIBRARY_CALLS = 0, 1, 2, 3
 TBK_T_PHASE, TBK_T_HK, TBK_T_EIG, TBK_T_QL, TBK_T_COUNT = 0, 1, 2, 3, 4
 STAGE_NAMES = ("phase", "hk", "eig", "ql")
 

@@ -985,6 +985,7 @@ static int eigenval_device_solve(tbk_model* m, const double* d_k, const double* 
     // elements
     chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, (int64_t(1) << 29) / std::max<int64_t>(1, (int64_t)m->n_orb * m->n_orb)));
     // rocSOLVER path: TBK_EIG_ROCSOLVER, or n_orb above the own solvers' range
+    m->counters[TBK_CNT_LIBRARY_CALLS] += 1;
     for (int64_t c0 = 0; c0 < nk; c0 += chunk) {
         const int64_t nkc = std::min(chunk, nk - c0);
         const int64_t nk_pad = phase_ld(nkc);

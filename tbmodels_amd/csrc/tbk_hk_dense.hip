@@ -669,11 +669,22 @@ int launch(tbk_model* m, const HkArgs& a0, int grid) {
 // per workgroup slot goes in ONE round of at most two workgroups per CU (`*lds_out` = half a CU's LDS keeps a third one away);
 // a bigger one in workgroups of ~1 MB (256 rows per wave), many rounds, the ragged end a few per cent.  The partial sums
 // (one row of P per slice and k-point) stay below 256 MB.
+int gemv_nkv(int64_t nk) {  // the kernel instantiation's k-points per wave
+    int nkv = 1;
+    while (nkv < std::min<int64_t>(nk, 32)) nkv *= 2;
+    return nkv;
+}
+int64_t gemv_strip_rows(const tbk_model* m, int64_t slices) {  // rows of the longest slice, rounded up to whole trips of the loop
+    const int64_t n_pairs = m->k2 / 2;
+    return (2 * ((n_pairs + slices - 1) / slices) + 15) / 16 * 16;
+}
+
 void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, size_t* lds_out) {
     const int nblk = m->ncol_pad / 64;
     const int64_t n_pairs = m->k2 / 2;
     const size_t per_split = (size_t)nk * m->ncol_pad * 2 * sizeof(double);
     const int64_t cap = std::max<int64_t>(1, (int64_t)((size_t(256) << 20) / per_split));
+    // (one-k hamilton at N_orb = 64, N_R = 4096 with 1 / 2 / 3 / 4 / 5 workgroups per CU: 69.4 / 65.2 / 66.5 / 67.9 / 69.2 us)
     const int64_t wave_slots = (int64_t)m->n_cu * 8;  // two workgroups per CU
     int64_t slices = wave_slots / nblk;               // one round: nblk * slices <= slots
     size_t lds = 80 * 1024;
@@ -686,6 +697,12 @@ void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, size_t* lds_out)
     }
     slices = std::max<int64_t>(1, std::min(slices, n_pairs / 8));  // at least 16 rows per slice
     if (nblk * slices * 2 <= wave_slots) lds = 16 * 1024;  // (a small model: nothing to balance)
+    if (lds < 64 * 1024) {
+        // no occupancy limiter: as much LDS as the phase strips of four waves take (up to 64 KiB), so that e.g. groups of 32
+        // k-points of a small model still make their own rows (the 1000-point silicon mesh: no phase_rows_kernel launch)
+        const size_t need = (size_t)4 * gemv_strip_rows(m, slices) * gemv_nkv(nk) * sizeof(double);
+        if (need <= size_t(64) * 1024) lds = std::max(lds, need);
+    }
     *slices_out = (int)slices;
     *lds_out = lds;
 }
@@ -700,11 +717,7 @@ bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk) {
     int slices;
     size_t lds;
     gemv_plan(m, nk, &slices, &lds);
-    const int64_t n_pairs = m->k2 / 2;
-    const int64_t rows_max = 2 * ((n_pairs + slices - 1) / slices);
-    int nkv = 1;
-    while (nkv < std::min<int64_t>(nk, 32)) nkv *= 2;
-    return (rows_max + 15) / 16 * 16 * nkv <= (int64_t)(lds / 32);
+    return gemv_strip_rows(m, slices) * gemv_nkv(nk) <= (int64_t)(lds / 32);
 }
 
 // The matrix-vector path: up to 32 k-points of any model, and up to 4096 k-points (in groups of 32) of a SMALL model --

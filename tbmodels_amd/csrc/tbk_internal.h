@@ -176,7 +176,7 @@ struct tbk_model {
     std::vector<int32_t> h_R;  // host copy of the lattice vectors [n_r][dim]
     tbk_fold_plan_t fold[TBK_MAX_DIM];
     bool fold_enabled = true;
-    int64_t counters[TBK_CNT_COUNT] = {0, 0, 0};  // tbk_model_counter
+    int64_t counters[TBK_CNT_COUNT] = {0, 0, 0, 0};  // tbk_model_counter
 
     // --- options ---
     int eigensolver = TBK_EIG_AUTO;

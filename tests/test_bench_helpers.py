@@ -258,3 +258,40 @@ def test_strong_scaling_watchdog_prints_the_line_and_exits_non_zero(tmp_path):
         record = json.loads(lines[0])
         assert record["strong_scaling"] == verdict and record["value"] == 1.0
         assert "error" in record["configs"]["cfg4"] and record["configs"]["cfg4"]["n_gpus"] == 2
+
+
+def test_summary_is_compact_and_carries_every_config():
+    """``summary`` is the LAST key of the JSON line and at most 1.5 KB: the driver's record keeps the final 2000 characters of
+    the output, and every config's value / roofline fractions / one-k latencies must survive there."""
+    import json
+
+    import bench
+
+    def config(value, with_standalone=True):
+        eig = {"frac": 0.2072}
+        if with_standalone:
+            eig["standalone"] = {"frac": 0.21841234}
+        return {"value": value, "ms_per_step": 292.6123, "roofline": {"frac": 0.19134}, "eig_roofline": eig,
+                "single_k_us": {"hamilton": 135.2, "eigenval": 1848.0, "roofline": {"frac": 0.671234}},
+                "cpu_baseline": {"value": 16.6123}, "max_abs_err_vs_oracle": 3.9968028886505635e-14,
+                "max_second_moment_err": 1.2345678e-15}
+
+    result = dict(config(955117.3), config={"workload": "cfg2: dense N_orb=64 N_R=4096, 100000 random k-points per GPU"},
+                  configs={name: config(v) for name, v in (("cfg1", 1.39e7), ("cfg3", 170899.0), ("cfg4", 9253450.0), ("cfg5", 16665.7))},
+                  host_api={"value": 922642.1, "single_k_us": {"hamilton": 66.0, "eigenval": 180.0}, "hamilton": {"GB/s": 49.06}},
+                  construct_only={"value": 1047310.0}, cpu_baseline_all_cores={"value": 452.1})
+    del result["single_k_us"]  # the main line carries its one-k figures under host_api
+    result["configs"]["cfg4"] = {"error": "RuntimeError: " + "x" * 300, "n_gpus": 8}  # a failed leg must not blow the budget
+    summary = bench.make_summary(result)
+    text = json.dumps(summary)
+    assert len(text) <= 1536, len(text)
+    assert list(summary)[:5] == ["cfg2", "cfg1", "cfg3", "cfg4", "cfg5"]
+    assert summary["cfg2"]["v"] == 955117.0 and summary["cfg2"]["k1"] == [66.0, 180.0, None]
+    assert summary["cfg3"] == {"v": 170899.0, "ms": 292.6, "hk": 0.1913, "eig": 0.2072, "eig_sa": 0.2184, "k1": [135.2, 1848.0, 0.6712],
+                               "cpu": 16.61, "err": 4e-14, "m2": 1.2e-15}
+    assert "error" in summary["cfg4"] and len(summary["cfg4"]["error"]) <= 60
+    assert summary["host"] == 922642.0 and summary["host_h_GBs"] == 49.06 and summary["construct"] == 1047310.0 and summary["cpu_all"] == 452.1
+    assert "keys" in summary
+    # a multi-rank line has no host_api / construct_only / other configs: still a valid summary
+    bare = bench.make_summary({"value": 7.5e6, "ms_per_step": 105.0, "config": {"workload": "cfg2: ..."}, "configs": None})
+    assert bare["cfg2"]["v"] == 7.5e6 and bare["host"] is None and len(json.dumps(bare)) < 700

@@ -104,6 +104,11 @@ def test_config3_sparse_shape_full_50k():
     assert eig.shape == (50_000, 256) and np.isfinite(eig).all()
     assert np.all(np.diff(eig, axis=1) >= 0)
     assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    # the second moment: sum_i E_i^2 = ||H(k)||_F^2 with H(k) from the sparse H(k) kernel (pinned to the oracle separately) on
+    # 4096 rows from the whole list -- holds the eigensolver to H itself where the trace only sees the first moment
+    import bench
+
+    assert bench.second_moment_error(_lib.lib(), model._staged(), 256, k, eig, 4096) < 1e-10
     dense_hop = syn.csr_to_dense(256, r_ptr, row, col, val)
     idx = np.sort(np.random.default_rng(5).choice(len(k), 48, replace=False))
     ref = np.array(oracle.eigenval(r_vec, dense_hop, k[idx]))
@@ -136,8 +141,8 @@ def test_config5_large_orbital_shape_reduced_R():
 
 def test_config5_large_orbital_shape_full():
     """Config 5 at full size: dense N_orb=512, N_R=2048 (8.6 GB of hoppings), 10 000 random k-points, staged straight
-    through the C ABI (the host model class would copy the 8.6 GB twice).  Trace identity on every row, 8 rows against
-    the oracle, and a second run must give the same bits (race detector for the N=512 reduction pipeline)."""
+    through the C ABI (the host model class would copy the 8.6 GB twice).  Trace identity on every row, the second moment on 512 rows, 32 rows
+    against the oracle, and a second run must give the same bits (race detector for the N=512 reduction pipeline)."""
     import ctypes
 
     n_orb, n_r, n_k = 512, 2048, 10_000
@@ -152,7 +157,11 @@ def test_config5_large_orbital_shape_full():
         assert np.isfinite(eig).all() and np.all(np.diff(eig, axis=1) >= 0)
         traces = np.einsum("rii->r", hop)
         assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
-        idx = np.array([0, 1111, 2222, 3333, 5000, 6667, 8888, n_k - 1])
+        import bench
+
+        assert bench.second_moment_error(lib, handle, n_orb, k, eig, 512) < 1e-10  # sum E^2 = ||H(k)||_F^2 on 512 rows
+        idx = np.unique(np.concatenate([[0, 1111, 2222, 3333, 5000, 6667, 8888, n_k - 1],
+                                        np.random.default_rng(8).choice(n_k, 24, replace=False)]))  # 32 rows (~20 s of oracle)
         ref = np.array(oracle.eigenval(r_vec, hop, k[idx]))
         assert np.abs(eig[idx] - ref).max() < 1e-10
         again = np.empty_like(eig)

@@ -493,9 +493,10 @@ def test_non_finite_k_is_value_error(silicon, kdotp_golden):
 @pytest.mark.parametrize("n_orb,solver", [(40, "rocsolver"), (64, "rocsolver"), (1030, "auto")])
 def test_one_k_calls_on_the_library_solver_branch_follow_k(n_orb, solver):
     """ONE k-point per call (the Z2Pack call shape, `_tb_model.py:1103-1108`) on the branch that hands the matrices to
-    rocSOLVER (on request, or above the own kernels' range): the k-point of the CURRENT call must reach H(k) -- the chunk
-    pipeline takes it from the kernel arguments and skips the upload, this branch reads the uploaded copy (it
-    was evaluated at the previous call's k)."""
+    rocSOLVER on request: the k-point of the CURRENT call must reach H(k) -- the chunk pipeline takes it from the kernel
+    arguments and skips the upload, this branch reads the uploaded copy (it was evaluated at the previous call's
+    k).  (1030, "auto") takes the OWN launch chain since round 5 (own range: up to 4096 orbitals) -- the same call sequence
+    on the other side of the switch; AUTO falling through to rocSOLVER is the child-process test below.)"""
     from tbmodels_amd import _lib
 
     r_vec, hop, pos = syn.dense_model_arrays(n_orb, 3, syn.MODEL_SEED + 700 + n_orb)
@@ -509,6 +510,57 @@ def test_one_k_calls_on_the_library_solver_branch_follow_k(n_orb, solver):
         one = model.eigenval(ks[i])
         assert one.shape == (n_orb,)
         _close(one, ref[i])
+
+
+def test_auto_falls_through_to_the_library_solver_above_the_own_range():
+    """AUTO above the own kernels' range is rocSOLVER (`tbk_api.hip: eigenval_device_solve`; the reference has no size limit,
+    `_tb_model.py:1149-1150`).  The own range ends at 4096 orbitals, too big for a test -- ``TBK_BAND_XL=0`` (read once per
+    process, hence the child) ends it at 1024, so that a 1030-orbital model with the DEFAULT solver option really reaches the
+    library: a 3-point batch, one-k calls each after a call at another k (the stale-k fix of ADVICE r4 on THIS branch), and a
+    NaN hopping -> ValueError through `flag_nonfinite_kernel` behind the library call."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import numpy as np
+import tbmodels_amd
+from tbmodels_amd import _lib, synthetic as syn
+from oracle import tbk_oracle as oracle
+n_orb = 1030
+r_vec, hop, pos = syn.dense_model_arrays(n_orb, 3, syn.MODEL_SEED + 700 + n_orb)
+model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+ks = syn.random_kpoints(3, seed=900 + n_orb)
+import ctypes
+def library_calls(mdl):
+    value = ctypes.c_int64(0)
+    _lib.check(_lib.lib().tbk_model_counter(mdl._staged(), _lib.TBK_CNT_LIBRARY_CALLS, ctypes.byref(value)))
+    return value.value
+batch = model.eigenval_array(ks)
+ref = np.array(oracle.eigenval(r_vec, hop, ks))
+assert np.abs(batch - ref).max() < 1e-10, np.abs(batch - ref).max()
+for i in (2, 0, 1, 1):
+    one = model.eigenval(ks[i])
+    assert one.shape == (n_orb,) and np.abs(one - ref[i]).max() < 1e-10, (i, np.abs(one - ref[i]).max())
+assert library_calls(model) == 5, library_calls(model)  # every one of these calls went to rocSOLVER
+broken = hop.copy()
+broken[1, 0, n_orb - 1] = np.nan
+bad = tbmodels_amd.Model.from_packed(r_vec, broken, pos=pos)
+for arg in (ks, ks[1]):
+    try:
+        bad.eigenval(arg)
+    except ValueError as exc:
+        assert "infs or NaNs" in str(exc), exc
+    else:
+        raise AssertionError("NaN hopping went through")
+assert library_calls(bad) == 2
+assert np.abs(model.eigenval(ks[2]) - ref[2]).max() < 1e-10
+print("CHILD OK")
+"""
+    env = dict(os.environ, TBK_BAND_XL="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert run.returncode == 0 and "CHILD OK" in run.stdout, (run.stdout[-1000:], run.stderr[-2000:])
 
 
 @pytest.mark.parametrize("n_orb,n_k", [(8, 5), (8, 6000), (40, 3), (64, 50000), (100, 4), (300, 2)])
