@@ -13,7 +13,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtbk.so")
+# (TBK_LIBTBK: another build of the same library -- tools/ and one test load `libtbk_experiments.so`, the build whose
+# measurement switches read the environment (`make -C tbmodels_amd/csrc EXPERIMENTS=1`); the product never sets it)
+LIB_PATH = os.environ.get("TBK_LIBTBK") or os.path.join(_HERE, "libtbk.so")
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "libtbk_experiments.so")
 
 TBK_OK = 0
 TBK_ERR_ARGUMENT = 1

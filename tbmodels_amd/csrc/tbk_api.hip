@@ -27,7 +27,11 @@ void tbk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tbk_last_error(void) { return g_err; }
+#ifdef TBK_EXPERIMENTS
+extern "C" const char* tbk_version(void) { return "tbk 0.1 (gfx950) +experiments"; }  // (`make EXPERIMENTS=1`: tbk_exp_env reads the environment)
+#else
 extern "C" const char* tbk_version(void) { return "tbk 0.1 (gfx950)"; }
+#endif
 
 extern "C" int tbk_device_count(int* count) {
     TBK_ARG(count != nullptr, "count is NULL");
@@ -180,7 +184,7 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
 
     {
         // TBK_MAIN_PRIORITY=1 (measurements): the main stream -- the H(k) kernels -- at the highest priority
-        static const bool main_hi = getenv("TBK_MAIN_PRIORITY") != nullptr && atoi(getenv("TBK_MAIN_PRIORITY")) != 0;
+        static const bool main_hi = tbk_exp_env("TBK_MAIN_PRIORITY") != nullptr && atoi(tbk_exp_env("TBK_MAIN_PRIORITY")) != 0;
         int lo = 0, hi = 0;
         if (main_hi && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
             TBK_TRY(TBK_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi)));
@@ -207,7 +211,7 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     // one H(k) (up to 1024 orbitals: 16 MiB) with its k-point and positions, or a few hundred eigenvalue rows
     m->h_stage_bytes = std::max<size_t>(size_t(320) << 10,
                                         n_orb <= 1024 ? (size_t)n_orb * n_orb * 16 + (size_t)n_orb * dim * 8 + (size_t(64) << 10) : 0);
-    static const int stage_mode = getenv("TBK_STAGE_MODE") ? atoi(getenv("TBK_STAGE_MODE")) : 1;  // 0 off, 1 non-coherent, 2 coherent
+    static const int stage_mode = tbk_exp_env("TBK_STAGE_MODE") ? atoi(tbk_exp_env("TBK_STAGE_MODE")) : 1;  // 0 off, 1 non-coherent, 2 coherent
     if (stage_mode == 0 || hipHostMalloc(&m->h_stage, m->h_stage_bytes, stage_mode == 1 ? hipHostMallocNonCoherent : hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         m->h_stage = nullptr;  // no pinned memory: every call takes the pageable path
@@ -615,7 +619,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     const int64_t n_chunks = (int64_t)sched.size();
     const int64_t max_chunk = *std::max_element(sched.begin(), sched.end());
     // a property of the call, not of its chunking: TBK_OPT_K_CHUNK must not change the results
-    static const int64_t per_orbital = getenv("TBK_SMALL_CALL_PER_ORBITAL") ? atoll(getenv("TBK_SMALL_CALL_PER_ORBITAL")) : 768;
+    static const int64_t per_orbital = tbk_exp_env("TBK_SMALL_CALL_PER_ORBITAL") ? atoll(tbk_exp_env("TBK_SMALL_CALL_PER_ORBITAL")) : 768;
     const bool small_call = nk <= std::max<int64_t>(TBK_SMALL_CALL, per_orbital * (int64_t)m->n_orb);
     TBK_CHECK(m->ws_H.reserve((size_t)max_chunk * nn2 * sizeof(double)));
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b)
@@ -628,8 +632,8 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     // orbitals) -- that reduction is a chain of short phases which leaves the matrix pipe idle four fifths of the time, and
     // the sparse H(k) is an HBM-write kernel.  Default: one after the other (the round-3 order); TBK_H_OVERLAP_BIG=1 turns
     // the overlap (and the 84 KiB hk_lds_floor below) on for measurements.
-    static const bool overlap_on = getenv("TBK_H_OVERLAP") == nullptr || atoi(getenv("TBK_H_OVERLAP")) != 0;
-    static const bool overlap_big = getenv("TBK_H_OVERLAP_BIG") != nullptr && atoi(getenv("TBK_H_OVERLAP_BIG")) != 0;
+    static const bool overlap_on = tbk_exp_env("TBK_H_OVERLAP") == nullptr || atoi(tbk_exp_env("TBK_H_OVERLAP")) != 0;
+    static const bool overlap_big = tbk_exp_env("TBK_H_OVERLAP_BIG") != nullptr && atoi(tbk_exp_env("TBK_H_OVERLAP_BIG")) != 0;
     const bool h_overlap = n_chunks > 2 && overlap_on &&
                            ((builder != nullptr && tbk_eig_small_supported(m->n_orb)) ||
                             (overlap_big && builder == nullptr && !tbk_eig_small_supported(m->n_orb) && tbk_eig_two_stage(m)));
@@ -639,7 +643,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         ~LdsFloor() { m->hk_lds_floor = 0; }
     } lds_floor_guard{m};
     if (h_overlap && builder == nullptr) {
-        static const int floor_kib = getenv("TBK_H_OVERLAP_LDS") ? atoi(getenv("TBK_H_OVERLAP_LDS")) : 84;
+        static const int floor_kib = tbk_exp_env("TBK_H_OVERLAP_LDS") ? atoi(tbk_exp_env("TBK_H_OVERLAP_LDS")) : 84;
         m->hk_lds_floor = (size_t)floor_kib * 1024;
     }
     if (h_overlap) {
@@ -702,7 +706,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
         if (c >= 1) {  // tridiagonal stage of the previous chunk, alongside this chunk's reduction
             // TBK_CHASE_EARLY=1 (measurements): ... alongside this chunk's H(k) already -- it starts as soon as its own
             // reduction is done
-            static const bool early = getenv("TBK_CHASE_EARLY") && atoi(getenv("TBK_CHASE_EARLY")) != 0;
+            static const bool early = tbk_exp_env("TBK_CHASE_EARLY") && atoi(tbk_exp_env("TBK_CHASE_EARLY")) != 0;
             if (!(early && two_stage)) TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_hk[b], 0));
             // (d, e) of the previous chunk: implied by ev_hk unless H(c) was built beside that reduction
             if (h_overlap || (early && two_stage)) TBK_HIP(hipStreamWaitEvent(m->stream_ql, m->ev_tri[b ^ 1], 0));

@@ -960,6 +960,9 @@ struct Frag {  // a 16 x 16 complex operand block in A/B-operand layout: lane l 
 #ifndef TBK_PASS_SPLIT
 #define TBK_PASS_SPLIT 1  // 0: the left-over blocks of a pass' last round on one wave each, the others idle
 #endif
+#ifndef TBK_QR_ONE_WAVE
+#define TBK_QR_ONE_WAVE 0  // 1: the recurrence of the Gram-form panel QR (one row per thread) on wave 0 alone, its coefficients through LDS
+#endif
 template <int NT, int ROWS, bool VN_LDS, int PHASE = 0>
 __global__ void __launch_bounds__(NT, NT <= 256 ? TBK_BAND_WAVES_PER_SIMD : 1)  // two waves per SIMD: 4 x 128, 2 x 256 or 1 x 512 threads per CU
 band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2* __restrict__ VNall, d2* __restrict__ band_all,
@@ -1720,6 +1723,109 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                 d2 top[PB];
 #pragma unroll
                 for (int c = 0; c < PB; ++c) top[c] = (c >= c0 && c < m) ? sTop[c * PB + t8] : (d2){0.0, 0.0};
+#if TBK_QR_ONE_WAVE
+                // Round 6: the recurrence on wave 0 ALONE -- its coefficients (f per column in the T area,
+                // which is dead until the T block below; scale and beta in the row buffer; the round's end and the mask of live
+                // reflectors in the totals area) wait in LDS behind one more meeting, then every wave applies the reflectors to
+                // its rows.  The other three waves' SIMDs are free for the co-resident workgroup meanwhile.  Same operations on
+                // the same values as the every-wave form: the same bits.
+                d2* const sF = sT;
+                int* const sCtl = reinterpret_cast<int*>(sTot);
+                int c1 = last;
+                unsigned has_mask = 0;
+                if (wave == 0) {
+                    d2 g_next = sG[min(c0, PB - 1) * PB + t8];
+                    bool stopped = false;
+                    static_for<0, PB>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (c >= c0 && c < last && !stopped) {  // uniform
+                            const d2 g_row = g_next;
+                            g_next = sG[min(c + 1, PB - 1) * PB + t8];
+                            d2 g = g_row;
+                            static_for<0, c>([&](auto ic) {
+                                constexpr int i = decltype(ic)::value;
+                                cfnmacj_bc<c>(g, top[i], top[i]);
+                            });
+                            const double gcc = lane_value<c>(g[0]);
+                            const double Gcc = lane_value<c>(g_row[0]);
+                            if (c > c0 && !(gcc >= GRAM_THRESH * Gcc)) {
+                                stopped = true;
+                                c1 = c;
+                            } else {
+                                const d2 alpha = (d2){lane_value<c>(top[c][0]), lane_value<c>(top[c][1])};
+                                const d2 rowv = top[c];
+                                const double sigma = gcc - (alpha[0] * alpha[0] + alpha[1] * alpha[1]);
+                                if (!(gcc == 0.0 || (sigma == 0.0 && alpha[1] == 0.0))) {  // uniform
+                                    double root, rroot;
+                                    fast_sqrt_rsqrt(gcc, root, rroot);
+                                    const double beta = -copysign(root, alpha[0]);
+                                    const double rbeta = -copysign(rroot, alpha[0]);
+                                    const d2 tau_c = (d2){(beta - alpha[0]) * rbeta, -alpha[1] * rbeta};
+                                    if (tid == 0) sTau[c] = tau_c;
+                                    const double qr_ = alpha[0] - beta, qi_ = alpha[1];
+                                    const double qn = fast_rcp(qr_ * qr_ + qi_ * qi_);
+                                    const d2 scale = (d2){qr_ * qn, -qi_ * qn};
+                                    d2 tz = g;
+                                    cfnmac(tz, rowv, alpha);
+                                    d2 z = cmulc(tz, scale);
+                                    z[0] += rowv[0];
+                                    z[1] += rowv[1];
+                                    d2 f = cmul(conjd(tau_c), z);
+                                    if (t8 <= c) f = (d2){0.0, 0.0};
+                                    top[c] = t8 > c ? (d2){rowv[0] - f[0], rowv[1] - f[1]} : (t8 == c ? (d2){beta, 0.0} : (d2){0.0, 0.0});
+                                    static_for<c + 1, PB>([&](auto ic) {
+                                        constexpr int i = decltype(ic)::value;
+                                        d2 vt = (d2){0.0, 0.0};
+                                        cfma_bc<c>(vt, scale, top[i]);
+                                        cfma(top[i], (d2){-vt[0], -vt[1]}, f);
+                                    });
+                                    sF[c * PB + t8] = f;  // (the eight 16-lane rows of the wave write the same values)
+                                    sRow[c] = scale;
+                                    sRow[PB + c] = (d2){beta, 0.0};
+                                    has_mask |= 1u << c;
+                                }
+                            }
+                        }
+                    });
+                    if (lane == 0) {
+                        sCtl[0] = c1;
+                        sCtl[1] = (int)has_mask;
+                    }
+                }
+                lds_fence();
+                __syncthreads();
+                c1 = __builtin_amdgcn_readfirstlane(sCtl[0]);
+                has_mask = (unsigned)__builtin_amdgcn_readfirstlane(sCtl[1]);
+                static_for<0, PB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if (c >= c0 && c < c1 && (has_mask >> c & 1u)) {  // uniform
+                        const d2 f = sF[c * PB + t8];
+                        const d2 scale = sRow[c];
+                        const double beta = sRow[PB + c][0];
+#pragma unroll
+                        for (int rr = 0; rr < ROWS; ++rr) {
+                            const bool below = qr_row[rr] && row_of(rr) >= s + c;
+                            const bool head = row_of(rr) == s + c;
+                            d2 v = cmul(y[rr][c], scale);
+                            v = below ? (head ? (d2){1.0, 0.0} : v) : (d2){0.0, 0.0};
+                            vn[rr][c] = v;
+                            static_for<c + 1, PB>([&](auto cpc) {
+                                constexpr int cp = decltype(cpc)::value;
+                                cfnma_bc<cp>(y[rr][cp], v, f);
+                            });
+                            if (below) y[rr][c] = head ? (d2){beta, 0.0} : (d2){0.0, 0.0};
+                        }
+                    }
+                });
+                TBK_CLK(14);
+                c0 = c1;
+                // (another round, or the T block's Gram matrix: both write areas read above -- the meeting below the loop /
+                // the one here orders them)
+                if (c0 < last) {
+                    lds_fence();
+                    __syncthreads();
+                }
+#else
                 d2 g_next = sG[min(c0, PB - 1) * PB + t8];
                 bool stopped = false;
                 int c1 = last;
@@ -1793,6 +1899,7 @@ band_reduce_kernel(double* __restrict__ Hall, int n, d2* __restrict__ VWall, d2*
                     lds_fence();
                     __syncthreads();
                 }
+#endif
             }
             // (sTop = the S area and sG = the partial-sum area are written again by the T block's Gram matrix below)
             lds_fence();
@@ -3141,7 +3248,7 @@ static size_t xl_partial_doubles(int n) {
     return (nbk + 3) / 4 * nbk * 256;
 }
 static bool xl_sweep4() {
-    static const bool on = getenv("TBK_BAND_XL_SWEEP4") && atoi(getenv("TBK_BAND_XL_SWEEP4")) != 0;
+    static const bool on = tbk_exp_env("TBK_BAND_XL_SWEEP4") && atoi(tbk_exp_env("TBK_BAND_XL_SWEEP4")) != 0;
     return on;
 }
 size_t tbk_band_xl_buffer_per_matrix(int n) {
@@ -3156,7 +3263,7 @@ size_t tbk_band_scratch_per_matrix(int n) {
 static int chase_pitch(int n) {
     // TBK_CHASE_PITCH=r (measurements): pitch = r mod 16.  Bank model of the four-sweeps-per-wave layout (DESIGN_LOG R4.2): 148 LDS
     // cycles per tick at 9, 138 at 3 or 11 -- reads of two sweeps that share a 16-lane group collide at every pitch
-    static const int want = getenv("TBK_CHASE_PITCH") ? (atoi(getenv("TBK_CHASE_PITCH")) & 15) | 1 : 9;
+    static const int want = tbk_exp_env("TBK_CHASE_PITCH") ? (atoi(tbk_exp_env("TBK_CHASE_PITCH")) & 15) | 1 : 9;
     int np = n + PB;
     while (np % 16 != want) ++np;
     return np;
@@ -3176,7 +3283,7 @@ constexpr int BAND_LDS_CHASE_MAXN = 512;  // above: the chase keeps its 16 diago
 // TBK_CHASE_GLOBAL=1 (measurements): the global-memory chase at every size that runs it as its own launch -- 9 KiB of LDS
 // and 158 registers per wave instead of 133 KiB at 512 orbitals, so its workgroups fit beside those of other kernels
 static bool chase_global_forced(int n) {
-    static const bool forced = getenv("TBK_CHASE_GLOBAL") && atoi(getenv("TBK_CHASE_GLOBAL")) != 0;
+    static const bool forced = tbk_exp_env("TBK_CHASE_GLOBAL") && atoi(tbk_exp_env("TBK_CHASE_GLOBAL")) != 0;
     return forced && !tbk_band_fused(n);
 }
 // 257 - 768 orbitals, calls of more matrices than the chip has CUs: the windowed kernel with 16 sweep slots and 272 columns -- 78 KiB
@@ -3185,10 +3292,10 @@ static bool chase_global_forced(int n) {
 // 512 orbitals), the chip holds twice as many: cfg5 16.04 -> 16.63 k k-points/s, whole eigenval of 2048 k-points 12.93 -> 11.74 us per
 // k-point at 320 orbitals, 18.82 -> 17.66 at 384, 34.57 -> 33.64 at 512; the same bits.  TBK_CHASE_WINDOW_SMALL=0: off.
 static bool chase_small_window(const tbk_model* m, int n, int64_t nk) {
-    static const bool on = !(getenv("TBK_CHASE_WINDOW_SMALL") && atoi(getenv("TBK_CHASE_WINDOW_SMALL")) == 0);
+    static const bool on = !(tbk_exp_env("TBK_CHASE_WINDOW_SMALL") && atoi(tbk_exp_env("TBK_CHASE_WINDOW_SMALL")) == 0);
     // Up to 768 orbitals (TBK_CHASE_WINDOW_SMALL_MAXN, measurements): above 512 against the 32-slot window -- whole eigenval of 2048
     // k-points 41.1 -> 39.1 us per k-point at 520 orbitals, 64.8 -> 62.9 at 640, 100.1 -> 97.4 at 768, 206.2 -> 215.6 at 1000.
-    static const int maxn = getenv("TBK_CHASE_WINDOW_SMALL_MAXN") ? atoi(getenv("TBK_CHASE_WINDOW_SMALL_MAXN")) : 768;
+    static const int maxn = tbk_exp_env("TBK_CHASE_WINDOW_SMALL_MAXN") ? atoi(tbk_exp_env("TBK_CHASE_WINDOW_SMALL_MAXN")) : 768;
     return on && n > 256 && n <= maxn && !tbk_band_fused(n) && std::max<int64_t>(m->call_nk, nk) > 256;
 }
 // does a matrix' band buffer carry the 16 working diagonals behind the compact band (by the size alone: any call may need them)
@@ -3204,7 +3311,7 @@ static bool chase_has_buffer(int n) { return n > BAND_LDS_CHASE_MAXN || chase_gl
 // workgroup per CU there, and the separate launch fills the gaps of the next chunk's first stage).  TBK_BAND_FUSE=0 / 1
 // forces one (measurements).
 bool tbk_band_fused(int n) {
-    static const int forced = getenv("TBK_BAND_FUSE") ? atoi(getenv("TBK_BAND_FUSE")) : -1;
+    static const int forced = tbk_exp_env("TBK_BAND_FUSE") ? atoi(tbk_exp_env("TBK_BAND_FUSE")) : -1;
     if (band_xl(n)) return false;  // (the launch chain ends in the band's way out; the second stage is a launch of its own)
     return forced >= 0 ? forced != 0 : n <= 256;
 }
@@ -3217,7 +3324,7 @@ bool tbk_eig_band_preferred(int n) {
     // 14.9 vs 14.4 at 192.  Round 4, after the trims of both stages, whole eigenval per k-point, one-stage vs two-stage:
     // 2.85 vs 3.16 us at 168, 3.36 vs 3.34 at 176, 3.70 vs 3.70 at 184, 3.88 vs 3.78 at 188 -- 177 .. 192 orbitals pad to
     // the same twelve blocks of 16, so the two-stage path takes over where the one-stage time reaches that: from 185)
-    static const int from = getenv("TBK_BAND_FROM") ? atoi(getenv("TBK_BAND_FROM")) : 185;  // measurements only
+    static const int from = tbk_exp_env("TBK_BAND_FROM") ? atoi(tbk_exp_env("TBK_BAND_FROM")) : 185;  // measurements only
     return n >= from && n <= BAND_MAXN;
 }
 
@@ -3233,7 +3340,7 @@ size_t tbk_band_bytes_per_matrix(int n) {
 // sums of the members differ from one workgroup's in the last bit).  TBK_BAND_SPLIT=0: off (measurements).
 bool tbk_band_split(const tbk_model* m, int64_t nk) {
     static const bool on = !(getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 0);
-    static const int64_t forced_limit = getenv("TBK_BAND_SPLIT_MAX") ? atoll(getenv("TBK_BAND_SPLIT_MAX")) : 0;
+    static const int64_t forced_limit = tbk_exp_env("TBK_BAND_SPLIT_MAX") ? atoll(tbk_exp_env("TBK_BAND_SPLIT_MAX")) : 0;
     const int n = m->n_orb;
     if (!on || n <= 128 || n > BAND_ONE_WG_MAXN || band_xl(n)) return false;
     // as long as every member workgroup of every matrix finds a CU of its own: n_cu / members matrices (on 256 CUs: 64 up to
@@ -3286,7 +3393,7 @@ static int launch_split(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t
 static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_D, double* d_E);
 static int xl_groups(int n, int64_t nk) {
     // TBK_BAND_XL_GROUPS=g (1 - 4; measurements): default 2
-    static const int groups_env = getenv("TBK_BAND_XL_GROUPS") ? std::min(4, std::max(1, atoi(getenv("TBK_BAND_XL_GROUPS")))) : 2;
+    static const int groups_env = tbk_exp_env("TBK_BAND_XL_GROUPS") ? std::min(4, std::max(1, atoi(tbk_exp_env("TBK_BAND_XL_GROUPS")))) : 2;
     return (band_xl(n) && nk >= 4 * groups_env) ? groups_env : 1;
 }
 bool tbk_band_xl_grouped(int n, int64_t nk) { return xl_groups(n, nk) > 1; }
@@ -3304,7 +3411,7 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     constexpr int NTS = 512, NTP = 256;
     // TBK_BAND_XL_SWEEPS=2 (measurements): the update sweep and the product sweep as two launches on ONE matrix buffer (the first
     // form of the chain: every tile crosses HBM four times per panel)
-    static const bool two_sweeps = getenv("TBK_BAND_XL_SWEEPS") && atoi(getenv("TBK_BAND_XL_SWEEPS")) == 2;
+    static const bool two_sweeps = tbk_exp_env("TBK_BAND_XL_SWEEPS") && atoi(tbk_exp_env("TBK_BAND_XL_SWEEPS")) == 2;
     if (two_sweeps) {
         for (int p = 0; p <= p_end; ++p) {
             hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p,
@@ -3335,11 +3442,11 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     double* buf[2] = {d_H, m->ws_xl.as<double>()};
     double* d_P = m->ws_xl.as<double>() + (size_t)nk * n * n * 2;
     // up to 1024 orbitals (calls of a few matrices): the panel's rows in LDS (TBK_BAND_XL_YLDS=0: in global memory, as above 1024)
-    static const bool y_lds_env = !(getenv("TBK_BAND_XL_YLDS") && atoi(getenv("TBK_BAND_XL_YLDS")) == 0);
+    static const bool y_lds_env = !(tbk_exp_env("TBK_BAND_XL_YLDS") && atoi(tbk_exp_env("TBK_BAND_XL_YLDS")) == 0);
     const bool y_lds = y_lds_env && n <= BAND_ONE_WG_MAXN;
     const size_t y_bytes = (size_t)npad * PB * sizeof(d2);
     // up to 256 orbitals the rows fill four waves only: a workgroup of four (TBK_BAND_XL_SERIAL4=0: eight, measurements) meets faster
-    static const bool serial4_env = !(getenv("TBK_BAND_XL_SERIAL4") && atoi(getenv("TBK_BAND_XL_SERIAL4")) == 0);
+    static const bool serial4_env = !(tbk_exp_env("TBK_BAND_XL_SERIAL4") && atoi(tbk_exp_env("TBK_BAND_XL_SERIAL4")) == 0);
     const bool four_waves = serial4_env && y_lds && n <= 256;
     if (y_lds) {
         static std::atomic<bool> raised[TBK_MAX_DEVICES] = {};
@@ -3353,7 +3460,7 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     // changes (same launches, same order, same bits).
     const int groups = xl_groups(n, nk);
     // TBK_BAND_XL_WALK=1 (measurements): the pairing walk of band_xl_sweep_kernel
-    static const int walk_flag = (getenv("TBK_BAND_XL_WALK") && atoi(getenv("TBK_BAND_XL_WALK")) != 0) ? 2 : 0;
+    static const int walk_flag = (tbk_exp_env("TBK_BAND_XL_WALK") && atoi(tbk_exp_env("TBK_BAND_XL_WALK")) != 0) ? 2 : 0;
     auto chain = [&](hipStream_t st, int64_t k0, int64_t nkg) {
         double* b[2] = {buf[0] + (size_t)k0 * n * n * 2, buf[1] + (size_t)k0 * n * n * 2};
         d2* vw = d_VW + (size_t)k0 * nbk * 256;
@@ -3433,8 +3540,8 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // a CU to itself anyway, so it gets EIGHT waves and one row per thread -- twice the waves on the tile pass, half the
     // rows per thread in the thread-per-row phases.  By the size of the CALL (TBK_OPT_K_CHUNK must not change a result:
     // the partial sums of eight waves differ from those of four in the last bit).  TBK_BAND_WIDE=0: off (measurements).
-    static const bool wide_env = !(getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 0);
-    static const bool wide_all = getenv("TBK_BAND_WIDE") && atoi(getenv("TBK_BAND_WIDE")) == 2;  // (measurements: every call size)
+    static const bool wide_env = !(tbk_exp_env("TBK_BAND_WIDE") && atoi(tbk_exp_env("TBK_BAND_WIDE")) == 0);
+    static const bool wide_all = tbk_exp_env("TBK_BAND_WIDE") && atoi(tbk_exp_env("TBK_BAND_WIDE")) == 2;  // (measurements: every call size)
     const bool wide = wide_env && n <= 512 && (wide_all || std::max<int64_t>(m->call_nk, nk) <= 128);
     const int nw = (n > 512 || wide) ? 8 : 4;
     const int rows_per_thread = (n > 512 || (n > 256 && !wide)) ? 2 : 1;  // (the instantiation chosen below)
@@ -3469,7 +3576,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // TBK_BAND_NARROW=1 (measurement, round 4): TWO waves per matrix and two rows per thread up to 256 orbitals -- four matrices
     // per CU instead of two, the per-wave overhead of the serial phases (reductions, scalar chains) paid half as often per
     // matrix; 38 KiB of LDS, second stage in its own launch
-    static const bool narrow_env = getenv("TBK_BAND_NARROW") && atoi(getenv("TBK_BAND_NARROW")) != 0;
+    static const bool narrow_env = tbk_exp_env("TBK_BAND_NARROW") && atoi(tbk_exp_env("TBK_BAND_NARROW")) != 0;
     if (narrow_env && !wide && n <= 256 && d_de_fused == nullptr) {
         lds = band_xv_bytes(npad, false, 2, 2) + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
         TBK_REDUCE(128, 2, false, 5);
@@ -3524,7 +3631,7 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
             return TBK_OK;
         }
         // 32 sweeps in flight, two steps apart, from 512 orbitals on (a sweep is n / 8 >= 64 steps long); 16 below
-        static const int env_nwg = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
+        static const int env_nwg = tbk_exp_env("TBK_CHASE_NW") ? atoi(tbk_exp_env("TBK_CHASE_NW")) : 0;
         // (TBK_CHASE_NW=12, round 5: twelve waves = 48 sweeps in flight for calls of a few matrices -- measured: one-k eigenval
         // 13.88 -> 14.09 ms at 768 orbitals, 24.90 -> 25.17 at 1024, the same bits: the ticks' global-memory round trips, not the
         // 32 slots, bound it.  Eight stay.)
@@ -3546,8 +3653,8 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
         // Consecutive sweeps run `stagger` chase steps apart: 2 is the closest that keeps the steps of one tick on
         // disjoint cells (tools/two_stage_model.py: check_pipeline).  Waves per workgroup: enough sweeps in flight to
         // fill that pipeline (a sweep is ~n / 8 steps long).  TBK_CHASE_NW / TBK_CHASE_STAGGER: measurements only.
-        static const int env_nw = getenv("TBK_CHASE_NW") ? atoi(getenv("TBK_CHASE_NW")) : 0;
-        static const int env_stagger = getenv("TBK_CHASE_STAGGER") ? atoi(getenv("TBK_CHASE_STAGGER")) : 0;
+        static const int env_nw = tbk_exp_env("TBK_CHASE_NW") ? atoi(tbk_exp_env("TBK_CHASE_NW")) : 0;
+        static const int env_stagger = tbk_exp_env("TBK_CHASE_STAGGER") ? atoi(tbk_exp_env("TBK_CHASE_STAGGER")) : 0;
         const int stagger = env_stagger >= 2 ? env_stagger : 2;
         // four sweeps per wave: a sweep is ~n / 8 steps long and sweeps start two ticks apart
         const int nw4 = env_nw ? env_nw : (n <= 128 ? 2 : n <= 256 ? 4 : 8);

@@ -500,6 +500,19 @@ herm_tridiag4_kernel(double* H, int n, double* __restrict__ D, double* __restric
     for (int b = 0; b < NB; ++b) bc_slot[b] = min(NW * (16 * b + (lane & 15)) + q, NR - 1);
 
     for (int j = 0; j < n_steps; ++j) {
+#ifdef TBK_ABLATE_CASCADE
+        // TIMING ONLY (results wrong by construction): what repacking the live rows could buy at most.  From step 16 of a
+        // 64-row matrix on, 48 of the 64 lanes hold live rows: a cascade 64 -> 48 would keep four matrices on three waves.  Here
+        // every fourth matrix simply stops at step 16 -- perfect packing, no repacking cost.  =2: the same at step 8 (56 rows:
+        // one matrix in eight) on top.
+        // (workgroup b runs on XCD b % 8 and, to begin with, on CU (b / 8) % 32 of it: the matrices that stop are picked by a
+        // hash of b -- `b % 4 == 3` put them all on two XCDs, whose early finish bought nothing)
+        const unsigned pick = (blockIdx.x * 2654435761u) >> 20;
+        if (NR == 64 && j >= 16 && (pick & 3) == 3) break;
+        if (TBK_ABLATE_CASCADE == 2 && NR == 64 && j >= 8 && (pick & 7) == 6) break;
+        if (TBK_ABLATE_CASCADE == 3 && NR == 64 && j >= 16) break;  // (calibration: EVERY matrix stops at step 16 / at step 1)
+        if (TBK_ABLATE_CASCADE == 4 && NR == 64 && j >= 1) break;
+#endif
         wg_sync();  // B1: sx, ssc describe the reflector of column j
         const d2 vme = (lane < NR) ? sx[j & 1][lane] : (d2){0.0, 0.0};
         const HhScalars sc = ssc;
@@ -1010,14 +1023,14 @@ static int launch_tridiag_33_64(hipStream_t s, double* d_H, int n, int64_t nk, d
     // Calls of a few matrices (all of them resident at once: what counts is one matrix' latency, not issue slots) keep the
     // whole reduction in ONE launch of the four-wave kernel: a single 64 x 64 matrix 99 -> 78 us.  By the size of the CALL,
     // not of this chunk: TBK_OPT_K_CHUNK must not change results, and the forms differ in the last bit.
-    static const bool split_env = !(getenv("TBK_SMALL_SPLIT") && atoi(getenv("TBK_SMALL_SPLIT")) == 0);
+    static const bool split_env = !(tbk_exp_env("TBK_SMALL_SPLIT") && atoi(tbk_exp_env("TBK_SMALL_SPLIT")) == 0);
     const bool split_on = split_env && std::max(call_nk, nk) > 512;
     const int n_steps = split_on ? n - 32 : n - 1;
     // TWO waves per matrix at every size when the kernel only does the first n - 32 steps (round 3; TBK_SMALL_NW2=0:
     // four): those are the steps with the most FMAs per reduction / barrier / scalar chain, and halving the copies of
     // that overhead buys more than the lower occupancy costs (178 registers at 64 rows: two waves per SIMD) -- cfg2
     // 951 -> 963 k, cfg4 8.84 -> 9.26 M k-points/s.  For the WHOLE reduction it was a wash (4.07 vs 4.14 ms, round 2).
-    static const bool two_env = !(getenv("TBK_SMALL_NW2") && atoi(getenv("TBK_SMALL_NW2")) == 0);
+    static const bool two_env = !(tbk_exp_env("TBK_SMALL_NW2") && atoi(tbk_exp_env("TBK_SMALL_NW2")) == 0);
     const bool two_waves = split_on && two_env;
 #define TBK_T4(NRV, NWV) \
     hipLaunchKernelGGL((herm_tridiag4_kernel<NRV, NWV>), grid, dim3(NWV * 64), 0, s, d_H, n, d_D, d_Eo, n_steps, h_stride, ldd, off)

@@ -811,7 +811,7 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
     // 1.42 with eight waves and a panel of 8); above that panel / workgroup variants are within 2 % of each other
     // Round 3: the kernel stops after the first n - 64 steps and the register-resident kernels finish the trailing 64 x 64
     // block (tbk_launch_tridiag_tail64); TBK_STREAM_SPLIT=0: the whole reduction here (measurements).
-    static const bool split_on = !(getenv("TBK_STREAM_SPLIT") && atoi(getenv("TBK_STREAM_SPLIT")) == 0);
+    static const bool split_on = !(tbk_exp_env("TBK_STREAM_SPLIT") && atoi(tbk_exp_env("TBK_STREAM_SPLIT")) == 0);
     // above 128 orbitals: this kernel goes down to the trailing 128 x 128 block, the eight-wave register kernel to
     // 64 x 64 (TBK_REG128=0: this kernel down to 64)
     const bool via128 = split_on && n > 128 && tbk_eig_reg128_supported(128);
@@ -847,7 +847,7 @@ int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t n
     const int64_t call_nk = std::max(m->call_nk, nk);
     int lpe = call_nk <= 32 ? 16 : call_nk <= 512 ? 4 : 1;
     unsigned threads, parts = 1;
-    static const int lpe_env = getenv("TBK_BISECT_LPE") ? atoi(getenv("TBK_BISECT_LPE")) : 0;  // (measurements: 1, 4 or 16 above 64 orbitals)
+    static const int lpe_env = tbk_exp_env("TBK_BISECT_LPE") ? atoi(tbk_exp_env("TBK_BISECT_LPE")) : 0;  // (measurements: 1, 4 or 16 above 64 orbitals)
     if (n > 64) {
         // Above 64 orbitals (round 5): 16 or 4 lanes per eigenvalue at every size, over as many workgroups as that takes (until
         // round 4 the lanes had to fit ONE workgroup: 4 at 256 orbitals, 2 at 512 -- 31 sweeps where one lane with its secant steps

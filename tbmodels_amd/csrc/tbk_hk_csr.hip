@@ -255,11 +255,11 @@ template <int MODE, int CONV, int KT>
 hipError_t launch_lds(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_pad, const double* d_k,
                       const double* d_pos, double* d_H) {
     const size_t lds = (size_t)std::max<int64_t>(m->n_r, 1) * (KT * 2 + 2) * sizeof(double);
-    static const bool sched_on = !(getenv("TBK_CSR_SCHED") && atoi(getenv("TBK_CSR_SCHED")) == 0);  // 0: measurements
+    static const bool sched_on = !(tbk_exp_env("TBK_CSR_SCHED") && atoi(tbk_exp_env("TBK_CSR_SCHED")) == 0);  // 0: measurements
     const bool sched = sched_on && m->sched_kt == KT && m->d_sptr != nullptr;
     static std::atomic<bool> raised[2][TBK_MAX_DEVICES] = {};
     // slices of 4 x 1024 packed elements (measured: 1 -> 18.5, 2 -> 17.0, 3 -> 16.6, 4 -> 16.1, 6 -> 18.3, 8 -> 19.8 ms per 50 000 k-points at cfg3) (TBK_CSR_SLICE_ROUNDS: measurements); one slice = the whole triangle for small models
-    static const int slice_rounds = getenv("TBK_CSR_SLICE_ROUNDS") ? std::max(1, atoi(getenv("TBK_CSR_SLICE_ROUNDS"))) : 4;
+    static const int slice_rounds = tbk_exp_env("TBK_CSR_SLICE_ROUNDS") ? std::max(1, atoi(tbk_exp_env("TBK_CSR_SLICE_ROUNDS"))) : 4;
     const int64_t n_tiles = (nk + KT - 1) / KT;
     const bool flat = n_tiles < 8;  // one-k calls and short lines: see the kernel
     const int tiles_per_xcd = flat ? 0 : (int)((n_tiles + 7) / 8);
@@ -296,7 +296,7 @@ hipError_t launch_lds_mode(tbk_model* m, const double* d_A, int64_t nk, int64_t 
 int tbk_csr_tile_kpoints(int64_t n_r) {
     const int64_t budget = 80 * 1024 / (int64_t)sizeof(double);
     // TBK_CSR_KT16=1 (measurement, round 4): tiles of 16 k-points -- twice the FMAs per record decode, ONE workgroup per CU
-    static const bool kt16 = getenv("TBK_CSR_KT16") && atoi(getenv("TBK_CSR_KT16")) != 0;
+    static const bool kt16 = tbk_exp_env("TBK_CSR_KT16") && atoi(tbk_exp_env("TBK_CSR_KT16")) != 0;
     if (kt16 && n_r > 0 && n_r * 34 <= 2 * budget - 1024) return 16;
     if (n_r <= 0 || n_r * 4 > budget) return 0;
     if (n_r * 18 <= budget) return 8;

@@ -589,7 +589,7 @@ constexpr int TAIL_MAX_ROUNDS = 12;
 
 static int tail_split_rounds() {
     static const int rounds = [] {
-        const char* v = getenv("TBK_HK_TAIL_SPLIT");  // measurements only: "0" switches it off, N sets the limit
+        const char* v = tbk_exp_env("TBK_HK_TAIL_SPLIT");  // measurements only: "0" switches it off, N sets the limit
         return v ? atoi(v) : TAIL_MAX_ROUNDS;
     }();
     return rounds;
@@ -690,8 +690,8 @@ void gemv_plan(const tbk_model* m, int64_t nk, int* slices_out, size_t* lds_out)
     size_t lds = 80 * 1024;
     const int64_t rows_one_round = slices > 0 ? (m->k2 + slices - 1) / slices : m->k2 + 1;
     if (slices < 1 || nblk * slices * 10 < wave_slots * 9 || rows_one_round > 384 || slices > cap) {
-        // many rounds: workgroups of ~1 MB, at least eight per CU while a slice keeps 32 rows
-        slices = std::max<int64_t>(m->k2 / 256, std::min<int64_t>(((int64_t)m->n_cu * 32 + nblk - 1) / nblk, n_pairs / 16));
+        // many rounds: workgroups of ~1 MB, at least eight per CU while a slice keeps 16 rows
+        slices = std::max<int64_t>(m->k2 / 256, std::min<int64_t>(((int64_t)m->n_cu * 32 + nblk - 1) / nblk, n_pairs / 8));
         slices = std::max<int64_t>(1, std::min(cap, slices));
         lds = 16 * 1024;
     }
@@ -752,7 +752,7 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
     int grid;
     if (a.mt_count >= 32) {  // below that a plain round-robin over the XCDs balances better
         a.xcd_rows = 4;
-        if (const char* v = getenv("TBK_HK_XCD_ROWS")) a.xcd_rows = std::max(1, atoi(v));  // measurements only
+        if (const char* v = tbk_exp_env("TBK_HK_XCD_ROWS")) a.xcd_rows = std::max(1, atoi(v));  // measurements only
         const int max_rows = (a.mt_count + 7) / 8;
         grid = max_rows * a.nt_count * 8;
     } else {

@@ -5,6 +5,7 @@
 #include <rocblas/rocblas.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <functional>
@@ -63,6 +64,20 @@ void tbk_set_error(const char* fmt, ...);
             return TBK_ERR_ARGUMENT;                                                              \
         }                                                                                         \
     } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Environment switches.  The DEFAULT library reads only the switches a test uses as an independent cross-check of the product
+// path (plain getenv in the sources: TBK_BAND, TBK_BAND_SPLIT, TBK_BAND_XL, TBK_BAND_XL_FROM, TBK_CHASE_WINDOW, TBK_REG128,
+// TBK_REG128_NW2, TBK_GATHER_BLOCK_ROWS -- the table in DESIGN.md section 6).  Every measurement switch of a variant that was
+// built, measured and dropped goes through tbk_exp_env(), which is a constant NULL unless the library is built with
+// `make EXPERIMENTS=1` (-DTBK_EXPERIMENTS): a user cannot flip a product-path branch by accident, and the dead branches
+// fold away at compile time.
+// ------------------------------------------------------------------------------------------------
+#ifdef TBK_EXPERIMENTS
+inline const char* tbk_exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* tbk_exp_env(const char*) { return nullptr; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // dynamic LDS above the 64 KiB default: hipFuncSetAttribute acts on the CURRENT device's copy of the

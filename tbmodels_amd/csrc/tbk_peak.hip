@@ -121,7 +121,7 @@ int tbk_run_mfma_f64_peak(double* tflops) {
     TBK_HIP(hipGetDevice(&dev));
     TBK_HIP(hipGetDeviceProperties(&prop, dev));
     const int iters = 100000;  // ~20 ms per launch: long enough for the clock to settle
-    const bool verbose = getenv("TBK_VERBOSE") != nullptr;
+    const bool verbose = tbk_exp_env("TBK_VERBOSE") != nullptr;
     double* d_out = nullptr;
     TBK_HIP(hipMalloc((void**)&d_out, (size_t)prop.multiProcessorCount * 4 * 256 * sizeof(double)));
     hipEvent_t e0, e1;

@@ -741,7 +741,8 @@ np.savez(out, d=d, e=e, h=h[:3])
 
 
 def test_the_read_once_sweep_above_1024_orbitals_stays_correct():
-    """``TBK_BAND_XL_SWEEP4=1`` (a measurement switch, read once per process -- hence the child process): the panels' sweeps run four
+    """``TBK_BAND_XL_SWEEP4=1`` (a measurement switch of the EXPERIMENTS build of the library, `libtbk_experiments.so` -- the default
+    library does not read it; read once per process, hence the child process): the panels' sweeps run four
     block rows per workgroup, every tile is read once and the transposed products are added up through partial sums
     (csrc/tbk_eig_band.hip, band_xl_sweep4_kernel + band_xl_xsum_kernel; DESIGN_LOG.md R5.12: built, not faster, off by default).
     Same function as the one-row sweep: the spectra are those of the matrices (scipy's eigvalsh at _tb_model.py:1149), two runs
@@ -750,11 +751,16 @@ def test_the_read_once_sweep_above_1024_orbitals_stays_correct():
     import subprocess
     import sys
 
+    from tbmodels_amd import _lib
+
+    if not os.path.exists(_lib.EXPERIMENTS_LIB_PATH):
+        pytest.skip("the read-once sweep is a dropped variant: only in the experiments build (make -C tbmodels_amd/csrc EXPERIMENTS=1)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = """
 import numpy as np, scipy.linalg as la
 from tbmodels_amd import _lib
 lib = _lib.lib()
+assert b"+experiments" in lib.tbk_version()
 n, nk = 1040, 9
 rng = np.random.default_rng(78)
 m = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
@@ -775,7 +781,8 @@ for i in (0, 5, 6, 8):
     assert np.abs(got - ref).max() <= 1e-13 * n * np.abs(ref).max(), i
 print("ok")
 """
-    env = dict(os.environ, TBK_BAND_XL_SWEEP4="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, TBK_BAND_XL_SWEEP4="1", TBK_LIBTBK=_lib.EXPERIMENTS_LIB_PATH,
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stderr[-2000:]
 

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
+#define TBK_EXPERIMENTS 1  // (this driver flips the measurement switches: tbk_exp_env reads the environment)
 #include "../tbmodels_amd/csrc/tbk_eig_band.hip"
 
 void tbk_set_error(const char*, ...) {}
