@@ -193,8 +193,7 @@ static int create_common(int device, int dim, int n_orb, int64_t n_r, const int3
     }
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_eig, hipStreamNonBlocking)));
     TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&m->stream_ql, hipStreamNonBlocking)));
-    for (hipStream_t& st : m->stream_xl) TBK_TRY(TBK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)));
-    for (hipEvent_t& e : m->ev_xl) TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)));
+    // (stream_xl / ev_xl: created by launch_band_xl when a batch above 1024 orbitals first goes in groups)
     for (int b = 0; b < 2; ++b) {
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_hk[b], hipEventDisableTiming)));
         TBK_TRY(TBK_HIP(hipEventCreateWithFlags(&m->ev_tri[b], hipEventDisableTiming)));
@@ -656,6 +655,7 @@ static int eigenval_wave_pipeline(tbk_model* m, const double* d_k, int64_t nk, d
     if (two_stage) {
         TBK_CHECK(m->ws_band.reserve((size_t)max_chunk * tbk_band_scratch_per_matrix(m->n_orb)));
         for (int b = 0; b < 2; ++b) TBK_CHECK(m->ws_bandmat[b].reserve((size_t)max_chunk * tbk_band_bytes_per_matrix(m->n_orb)));
+        TBK_CHECK(tbk_band_xl_reserve(m, max_chunk));
     }
     if (n_chunks == 1) {
         // one chunk has nothing to overlap: everything in order on the main stream, no cross-stream events (they
@@ -1313,9 +1313,11 @@ extern "C" int tbk_reduce_standalone(int device, int n_orb, int64_t nk, int reps
             TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n_orb)));
             TBK_CHECK(m->ws_bandmat[0].reserve((size_t)nk * tbk_band_bytes_per_matrix(n_orb)));
         }
-        // what: 0 = the reduction as the pipeline runs it, 1 = first stage alone, 2 = second stage alone (two-stage sizes only)
+        // what: 0 = the reduction as the pipeline runs it, 1 = first stage alone, 2 = second stage alone (two-stage sizes only).
+        // The second stage has no input of its own: every repetition of `what == 2` chases the band the LAST repetition of
+        // `what == 1` left in ws_bandmat[0] (the chase reads it and writes only (d, e): the same work every time).
         for (int what = 0; what < (band ? 3 : 1); ++what) {
-            float best = 0.0f, sum = 0.0f;
+            float sum = 0.0f;
             for (int r = 0; r <= reps; ++r) {  // (repetition 0 warms up)
                 if (what != 2)
                     TBK_HIP(hipMemcpyAsync(m->ws_H.ptr, pristine.ptr, (size_t)nk * mat_bytes, hipMemcpyDeviceToDevice, m->stream));
@@ -1334,12 +1336,8 @@ extern "C" int tbk_reduce_standalone(int device, int n_orb, int64_t nk, int reps
                 TBK_HIP(hipEventSynchronize(ev[1]));
                 float ms = 0.0f;
                 TBK_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
-                if (r > 0) {
-                    sum += ms;
-                    best = (r == 1 || ms < best) ? ms : best;
-                }
+                if (r > 0) sum += ms;
             }
-            (void)best;
             us_per_matrix[what] = (double)sum / reps * 1e3 / (double)nk;
         }
         return TBK_OK;

@@ -275,16 +275,20 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
         nk = 0;
     }
     if (host_status != 0) local = host_status;
+    const auto soft_nccl = [&](ncclResult_t r, const char* what) {
+        if (r != ncclSuccess && local == TBK_OK) {
+            tbk_set_error("%s failed: %s (tbk_eigenval_device_gather)", what, ncclGetErrorString(r));
+            local = TBK_ERR_DEVICE;
+        }
+    };
     const int64_t n = m->n_orb;
     const int64_t slab = per * n;                       // doubles per rank
     const int64_t B = tbk_gather_block_rows(per, (int)n);
     const int64_t n_blocks = per > 0 ? (per + B - 1) / B : 0;
     double* mine = d_all + (size_t)c->rank * slab;
-    const bool compute = local == TBK_OK && nk > 0;
-    // rows this rank does not compute are zero (short or empty slab, or a rank that arrives with a failure)
-    const int64_t first_idle = compute ? nk : 0;
-    if (per > first_idle)
-        soft(hipMemsetAsync(mine + (size_t)first_idle * n, 0, (size_t)(per - first_idle) * n * sizeof(double), m->stream), "hipMemsetAsync");
+    // the landing area FIRST: whether this rank computes at all is decided behind the last thing that can fail in front of
+    // the solve (a rank whose fallback allocation failed used to run the whole pipeline into rows its own
+    // all-gathers were landing on)
     double* landing = c->d_stage;
     if ((size_t)c->world * (size_t)B * n * sizeof(double) > c->stage_bytes) {
         // (tbk_comm_prepare_gather was skipped or asked for another shape)
@@ -292,21 +296,28 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
         landing = c->d_stage;
         if (rc_prepare != TBK_OK) {
             if (local == TBK_OK) local = rc_prepare;
-            // no landing area: the result itself takes the pieces ([world][per][n] holds [world][B][n]); the status word says
-            // that nothing of this rank's copy is to be used
+            // no landing area: the head of the result takes the pieces ([world][per][n] holds [world][B][n]) IN PLACE -- this rank
+            // sends from its own piece of that area, the one aliasing NCCL defines; what it sends is meaningless and nothing
+            // of its copy is placed: the status word says so to everybody
             landing = d_all;
         }
     }
+    const bool compute = local == TBK_OK && nk > 0;
+    // rows this rank does not compute are zero (short or empty slab, or a rank that arrives with a failure)
+    const int64_t first_idle = compute ? nk : 0;
+    if (per > first_idle && landing != d_all)
+        soft(hipMemsetAsync(mine + (size_t)first_idle * n, 0, (size_t)(per - first_idle) * n * sizeof(double), m->stream), "hipMemsetAsync");
     int64_t next_block = 0;
     const bool ranged = m->timing;
     auto send_blocks = [&](int64_t rows_done) -> int {  // every block that ends at or before rows_done
         while (next_block < n_blocks && std::min(per, (next_block + 1) * B) <= rows_done) {
             const int64_t b0 = next_block * B, rows = std::min(per, b0 + B) - b0;
             const int64_t count = rows * n;
+            const double* piece = landing == d_all ? d_all + (size_t)c->rank * count : mine + (size_t)b0 * n;
             if (ranged) tbk_range_push("tbk:allgather_eigenvalues(block)");
-            const ncclResult_t r = ncclAllGather(mine + (size_t)b0 * n, landing, (size_t)count, ncclDouble, c->comm, c->stream);
+            const ncclResult_t r = ncclAllGather(piece, landing, (size_t)count, ncclDouble, c->comm, c->stream);
             if (ranged) tbk_range_pop();
-            TBK_NCCL(r);
+            soft_nccl(r, "ncclAllGather");  // (never a return from here: the peers are in the same sequence of collectives)
             if (landing == d_all) {
                 // (this rank has no landing area and reports a failure: its rows are not placed)
             } else if (((count | slab | (b0 * n)) & 1) == 0) {  // 16-byte copies when every piece starts on an even double
@@ -315,11 +326,11 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
                 hipLaunchKernelGGL(gather_place_kernel, dim3(gx, (unsigned)c->world), dim3(256), 0, c->stream,
                                    reinterpret_cast<const double2*>(landing), reinterpret_cast<double2*>(d_all), pairs, slab / 2,
                                    b0 * n / 2);
-                TBK_HIP(hipGetLastError());
+                soft(hipGetLastError(), "gather_place_kernel");
             } else {
                 for (int r2 = 0; r2 < c->world; ++r2)
-                    TBK_HIP(hipMemcpyAsync(d_all + (size_t)r2 * slab + (size_t)b0 * n, landing + (size_t)r2 * count,
-                                           (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                    soft(hipMemcpyAsync(d_all + (size_t)r2 * slab + (size_t)b0 * n, landing + (size_t)r2 * count,
+                                        (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
             }
             ++next_block;
         }
@@ -339,15 +350,16 @@ extern "C" int tbk_eigenval_device_gather(tbk_comm* c, tbk_model* m, const doubl
     // the way: the peers are waiting in the same sequence of collectives -- goes behind the main stream
     soft(hipEventRecord(c->tail, m->stream), "hipEventRecord");
     soft(hipStreamWaitEvent(c->stream, c->tail, 0), "hipStreamWaitEvent");
-    const int rc2 = send_blocks(per);
-    const int status = local != TBK_OK ? local : (rc != TBK_OK ? rc : rc2);
+    (void)send_blocks(per);
+    const int status = local != TBK_OK ? local : rc;
+    // (soft, all of it: this rank must enter the status all-gather whatever happened to it -- the peers are waiting there)
     hipLaunchKernelGGL(status_word_kernel, dim3(1), dim3(1), 0, c->stream, m->ws_flag.as<int>(), status, c->d_status);
-    TBK_HIP(hipGetLastError());
-    TBK_NCCL(ncclAllGather(c->d_status, c->d_status + 1, 1, ncclDouble, c->comm, c->stream));
-    TBK_HIP(hipMemcpyAsync(d_status_all, c->d_status + 1, (size_t)c->world * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    soft(hipGetLastError(), "status_word_kernel");
+    soft_nccl(ncclAllGather(c->d_status, c->d_status + 1, 1, ncclDouble, c->comm, c->stream), "ncclAllGather (status)");
+    soft(hipMemcpyAsync(d_status_all, c->d_status + 1, (size_t)c->world * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
     // the next call on the model's streams must not overwrite rows a gather is still reading
-    TBK_HIP(hipEventRecord(c->done[0], c->stream));
-    TBK_HIP(hipStreamWaitEvent(m->stream, c->done[0], 0));
-    if (local != TBK_OK && host_status == 0) return local;
-    return rc != TBK_OK ? rc : rc2;
+    soft(hipEventRecord(c->done[0], c->stream), "hipEventRecord");
+    soft(hipStreamWaitEvent(m->stream, c->done[0], 0), "hipStreamWaitEvent");
+    if (local != TBK_OK && local != host_status) return local;
+    return rc;
 }

@@ -3254,6 +3254,16 @@ static bool xl_sweep4() {
 size_t tbk_band_xl_buffer_per_matrix(int n) {
     return band_xl(n) ? (size_t)n * n * sizeof(d2) + (xl_sweep4() ? xl_partial_doubles(n) * sizeof(double) : 0) : 0;
 }
+bool tbk_band_split(const tbk_model* m, int64_t nk);
+// The chain's second matrix buffer for calls / chunks of up to max_nk matrices, reserved where the callers reserve ws_band and
+// ws_bandmat -- in front of the pipeline, not inside a launch (a grow there is a free + malloc, i.e. a device synchronisation
+// between the chunks of a call whose later chunk is the larger one).  Calls of a few matrices take the chain at
+// every size (tbk_band_split): up to 96 matrices x 16 n^2 bytes, 1.6 GB at 1024 orbitals.
+int tbk_band_xl_reserve(tbk_model* m, int64_t max_nk) {
+    const int n = m->n_orb;
+    if (!(band_xl(n) || tbk_band_split(m, max_nk))) return TBK_OK;
+    return m->ws_xl.reserve((size_t)max_nk * ((size_t)n * n * sizeof(d2) + (xl_sweep4() ? xl_partial_doubles(n) * sizeof(double) : 0)));
+}
 // (+ for the launch chain of band_xl_*: X / the panel's rows [npad][8] and T of the panel)
 size_t tbk_band_scratch_per_matrix(int n) {
     const size_t nbk = (size_t)((n + TS - 1) / TS);
@@ -3505,20 +3515,34 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     if (groups == 1) {
         TBK_CHECK(chain(s, 0, nk));
     } else {
+        // the side streams and their events exist from the first batch that uses them (not for every model: the temporary
+        // models of tbk_tridiagonal_reduce / tbk_reduce_standalone and every small model never get here)
+        for (int g = 1; g < groups; ++g)
+            if (m->stream_xl[g - 1] == nullptr) TBK_HIP(hipStreamCreateWithFlags(&m->stream_xl[g - 1], hipStreamNonBlocking));
+        for (int g = 0; g < groups; ++g)
+            if (m->ev_xl[g] == nullptr) TBK_HIP(hipEventCreateWithFlags(&m->ev_xl[g], hipEventDisableTiming));
         TBK_HIP(hipEventRecord(m->ev_xl[0], s));
         const int64_t per = (nk + groups - 1) / groups;
         for (int g = 1; g < groups; ++g) TBK_HIP(hipStreamWaitEvent(m->stream_xl[g - 1], m->ev_xl[0], 0));
         // (the host enqueues group after group; the streams run side by side from the first launch on)
+        // A failing group does not end the function: `s` first waits for every side stream that has work -- the caller's stream
+        // must not go on to reuse ws_H / ws_xl / ws_band under kernels still running there
+        int rc = TBK_OK;
         for (int g = 0; g < groups; ++g) {
             const int64_t k0 = g * per, nkg = std::min(per, nk - k0);
             if (nkg <= 0) break;
             hipStream_t st = g == 0 ? s : m->stream_xl[g - 1];
-            TBK_CHECK(chain(st, k0, nkg));
+            if (rc == TBK_OK) rc = chain(st, k0, nkg);
             if (g > 0) {
-                TBK_HIP(hipEventRecord(m->ev_xl[g], st));
-                TBK_HIP(hipStreamWaitEvent(s, m->ev_xl[g], 0));
+                hipError_t e = hipEventRecord(m->ev_xl[g], st);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s, m->ev_xl[g], 0);
+                if (e != hipSuccess && rc == TBK_OK) {
+                    tbk_set_error("joining a side stream of the launch chain failed: %s", hipGetErrorString(e));
+                    rc = TBK_ERR_DEVICE;
+                }
             }
         }
+        if (rc != TBK_OK) return rc;
     }
     TBK_HIP(hipGetLastError());
     return TBK_OK;

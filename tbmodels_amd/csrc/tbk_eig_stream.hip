@@ -774,7 +774,8 @@ hipError_t launch_stream(hipStream_t s, unsigned nk, double* d_H, int n, double*
 }  // namespace
 
 // sizes the own solvers of this file and of tbk_eig_band.hip cover between them: the one-stage kernel here up to 512
-// orbitals, the two-stage reduction up to 1024 (round 4; rocSOLVER above)
+// orbitals, the two-stage reduction up to band_maxn() = 4096 (round 5: the launch chain of band_xl_* above 1024; with
+// TBK_BAND_XL=0 the range ends at 1024 again); rocSOLVER above
 bool tbk_eig_stream_supported(int n) { return n > 64 && (n <= ST_MAXN || tbk_eig_band_supported(n)); }
 
 // two-stage reduction (tbk_eig_band.hip) unless TBK_BAND=0 asks for the one-stage kernel of this file
@@ -797,6 +798,7 @@ int tbk_launch_tridiag_stream(tbk_model* m, hipStream_t s, double* d_H, int64_t 
     }
     if (method == TBK_REDUCE_TWO_STAGE || (method == TBK_REDUCE_AUTO && tbk_eig_two_stage(m))) {  // both stages in order on this stream (single-chunk calls, tbk_tridiagonal_reduce)
         TBK_CHECK(m->ws_band.reserve((size_t)nk * tbk_band_scratch_per_matrix(n)));
+        TBK_CHECK(tbk_band_xl_reserve(m, nk));
         if (tbk_band_fused(n) && !tbk_band_split(m, nk)) return tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, nullptr, d_de);
         TBK_CHECK(m->ws_bandmat[0].reserve((size_t)nk * tbk_band_bytes_per_matrix(n)));
         if (tbk_band_xl_grouped(n, nk)) return tbk_launch_band_reduce(m, s, d_H, nk, m->ws_band.ptr, m->ws_bandmat[0].ptr, d_de);

@@ -311,6 +311,7 @@ bool tbk_hk_inline_phases(const tbk_model* m, int64_t nk);  // tbk_hk_dense.hip
 bool tbk_hk_gemv_path(const tbk_model* m, int64_t nk);
 int tbk_launch_bisect(tbk_model* m, hipStream_t s, const double* d_de, int64_t nk, double* d_E);
 size_t tbk_eig_scratch_per_k(const tbk_model* m);
+int tbk_band_xl_reserve(tbk_model* m, int64_t max_nk);  // tbk_eig_band.hip: ws_xl for chunks of up to max_nk matrices
 
 // tbk_eig_band.hip: two-stage reduction (dense -> band on the matrix pipe, band -> tridiagonal in LDS)
 bool tbk_eig_band_supported(int n);
@@ -318,7 +319,7 @@ bool tbk_eig_band_preferred(int n);
 size_t tbk_band_scratch_per_matrix(int n);
 size_t tbk_band_bytes_per_matrix(int n);
 size_t tbk_band_xl_buffer_per_matrix(int n);  // the second matrix buffer of the launch chain above 1024 orbitals
-bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this model (64 < n_orb <= 512, not TBK_BAND=0)
+bool tbk_eig_two_stage(const tbk_model* m);  // the band path applies to this model (64 < n_orb <= band_maxn() = 4096 -- 1024 with TBK_BAND_XL=0 --, not TBK_BAND=0)
 // d_de_fused != NULL: every workgroup runs the second stage for its matrix too and writes (d, e); d_band is not used
 int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk, void* d_vw, void* d_band,
                            double* d_de_fused = nullptr);

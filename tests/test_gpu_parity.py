@@ -885,18 +885,32 @@ def test_tridiagonal_reduce_on_caller_supplied_matrices(n):
 @pytest.mark.parametrize("n", [3000, 4096])
 def test_largest_sizes_of_the_own_path(n):
     """The launch chain above 1024 orbitals at the top of its validated range (the structured-matrix test stops at 2050: LAPACK
-    on the host needs ~10 - 30 s per matrix here): a random and a graded Hermitian matrix through ``eigenval`` against
-    numpy.linalg.eigvalsh, two k-points (the bisection's eigenvalues span three / four workgroups per matrix)."""
+    on the host needs ~10 - 30 s per matrix here): a random Hermitian matrix through ``eigenval`` against numpy.linalg.eigvalsh,
+    and two STRUCTURED matrices whose spectra are known without LAPACK -- a graded and a clustered diagonal D (16 decades; 64
+    values repeated 64 times) turned dense by two Householder similarities, M = H2 H1 D H1 H2 (O(n^2) to build, spectrum = D up
+    to the rounding of that) -- each at two k-points (the bisection's eigenvalues span three / four workgroups per matrix).
+    Tolerance n eps-like, as for the (d, e) tests: 1e-13 n max|lambda| (it was 1e-12 n, ~4e-7 absolute at 4096)."""
     rng = np.random.default_rng(7000 + n)
     rand = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
     rand = (rand + rand.conj().T) / 2
-    graded = rand * np.outer(10.0 ** -np.arange(n) / (n // 8), np.ones(n))
-    cases = [("random", rand)] + ([("graded", (graded + graded.conj().T) / 2)] if n < 4000 else [])  # (host LAPACK: ~15 s per 4096 matrix)
-    for name, mat in cases:
+
+    def reflected(diag):
+        mat = np.diag(diag).astype(complex)
+        for _ in range(2):
+            u = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            u /= np.linalg.norm(u)
+            mu = mat @ u
+            mat = mat - 2.0 * np.outer(u, u.conj() @ mat) - 2.0 * np.outer(mu, u.conj()) + 4.0 * (u.conj() @ mu) * np.outer(u, u.conj())
+        return (mat + mat.conj().T) / 2
+
+    graded = np.sort(10.0 ** (-16.0 * np.arange(n) / n) * np.where(np.arange(n) % 2, -1.0, 1.0))
+    clustered = np.sort(np.repeat(np.linspace(-3.0, 5.0, 64), (n + 63) // 64)[:n])
+    cases = [("random", rand, None), ("graded", reflected(graded), graded), ("clustered", reflected(clustered), clustered)]
+    for name, mat, known in cases:
         model = _onsite_model(mat)
         eig = np.array(model.eigenval([[0.1, 0.2, 0.3], [0.0, 0.0, 0.0]]))
-        ref = np.linalg.eigvalsh(mat)
-        assert np.abs(eig - ref[None]).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * n, name
+        ref = np.linalg.eigvalsh(mat) if known is None else known
+        assert np.abs(eig - ref[None]).max() <= 1e-13 * max(1.0, np.abs(ref).max()) * n, (name, np.abs(eig - ref[None]).max())
         assert np.array_equal(eig[0], eig[1])
 
 
