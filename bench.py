@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--eigensolver", default="auto", choices=["auto", "wave", "rocsolver"])
     ap.add_argument("--k-chunk", type=int, default=0)
     ap.add_argument("--construct-only", action="store_true", help="time H(k) construction alone (not the metric)")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="no GPU: every rank walks the control flow of a --gpus N run with tools/standin_lib.py in place of libtbk "
+                         "and a tiny model (CPU test of the exact launch command; the numbers mean nothing)")
     return ap.parse_args()
 
 
@@ -791,7 +794,14 @@ def main():
         nk_gpu = args.nk
     if args.nr:
         n_r = args.nr
-    arrays = build_model_arrays(args.config, args.nr)
+    arrays = build_model_arrays(args.config, args.nr) if not args.dry_ranks else None
+    if args.dry_ranks:
+        # the launch mechanics of an N-rank run on the CPU: 5 orbitals, 12 lattice vectors, 96 k-points per rank, a 7^3 mesh for
+        # the strong-scaling leg -- the stand-in evaluates slabs with the oracle, "eigenvalues per second" are meaningless
+        r_dry, hop_dry, pos_dry = synthetic.dense_model_arrays(5, 12, synthetic.MODEL_SEED + 77)
+        arrays = dict(kind="dense", n_orb=5, R=r_dry, hop=hop_dry, pos=pos_dry)
+        n_orb, nk_gpu = 5, (args.nk or 96)
+        os.environ.setdefault("TBK_BENCH_STRONG_MESH", "7")
     n_r = len(arrays["R"])
     dim = arrays["R"].shape[1]
 
@@ -821,8 +831,8 @@ def main():
     cpu_all_other = {}
     per_proc_all = {"cfg1": 64, "cfg2": 256, "cfg3": 24, "cfg4": 256, "cfg5": 2}  # ~5-10 s each
     run_others = (world == 1 and args.config == "cfg2" and not args.construct_only and not args.nk and not args.nr
-                  and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1")
-    if rank == 0 and world == 1 and args.cpu_sample != 0 and not args.construct_only:
+                  and not args.dry_ranks and os.environ.get("TBK_BENCH_SKIP_CONFIGS") != "1")
+    if rank == 0 and world == 1 and args.cpu_sample != 0 and not args.construct_only and not args.dry_ranks:
         cpu_all, cpu_all_rows = cpu_baseline_all_cores(arrays, k_slab, per_proc_all[args.config])
         if run_others and os.environ.get("TBK_BENCH_CPU_LIGHT") != "1":
             # all-core row of the sparse config too; it forks, so it runs here, before the GPU is touched
@@ -830,11 +840,18 @@ def main():
             cpu_all_other["cfg3"] = cpu_baseline_all_cores(arrays3, config_kpoints("cfg3", CONFIGS["cfg3"][3], 3), per_proc_all["cfg3"])
             del arrays3
 
-    lib = _lib.lib()
-    if _lib.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: libtbk has no CPU path")
-    device = local_rank % _lib.device_count()
     group = group_from_env() if world > 1 else None
+    if args.dry_ranks:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from standin_lib import StandInLib  # pylint: disable=import-outside-toplevel,import-error
+
+        lib = StandInLib(group, world, rank, arrays)
+        device = 0
+    else:
+        lib = _lib.lib()
+        if _lib.device_count() < 1:
+            raise SystemExit("bench.py needs a GPU: libtbk has no CPU path")
+        device = local_rank % _lib.device_count()
     model = stage(lib, device, arrays)
     solver = {"auto": _lib.TBK_EIG_AUTO, "wave": _lib.TBK_EIG_WAVE, "rocsolver": _lib.TBK_EIG_ROCSOLVER}[args.eigensolver]
     _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_EIGENSOLVER, solver))
@@ -983,7 +1000,7 @@ def main():
                     "allgather_ms": [round(float(p[1]), 3) for p in parts],
                     "note": "one step, not overlapped: eigenval on the rank's slab, then the RCCL all-gather alone"}
     host_api = None
-    if world == 1 and rank == 0 and not args.construct_only and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
+    if world == 1 and rank == 0 and not args.construct_only and not args.dry_ranks and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
         # SURVEY 8(d) "Evidence": wall-clock through the drop-in surface -- host k in, host eigenvalues out (H2D of k,
         # all kernels, the non-finite check, D2H), i.e. tbk_eigenval, what Model.eigenval_array calls; plus the
         # reference's return type (a Python list of row arrays, _tb_model.py:1148-1150)
@@ -1007,7 +1024,7 @@ def main():
         }
         _lib.check(lib.tbk_get_timing(model, None, None, 1))  # drop the stage events of these two extra calls
     construct = None
-    if world == 1 and rank == 0 and not args.construct_only and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
+    if world == 1 and rank == 0 and not args.construct_only and not args.dry_ranks and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
         # SURVEY 8(d) "Metric": k-points/s for H(k) construction alone, the result resident in HBM (tbk_hamilton_device, the
         # FULL matrix of Model.hamilton); and hard part 5: the batch hamilton() wall-clock through HOST buffers, PCIe-bound
         nk_c = min(nk_gpu, max(1, int(12e9 // (n_orb * n_orb * 16))))  # at most 12 GB of H
@@ -1078,7 +1095,7 @@ def main():
         eig_roofline = None
         if not args.construct_only and stage_ms.get("eig", 0.0) > 0.0:
             eig_roofline = eig_roofline_entry(n_orb, nk_gpu * args.steps, stage_ms["eig"], args.steps)
-            if world == 1 and os.environ.get("TBK_BENCH_SKIP_STANDALONE") != "1" and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
+            if world == 1 and not args.dry_ranks and os.environ.get("TBK_BENCH_SKIP_STANDALONE") != "1" and os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
                 eig_roofline["standalone"] = standalone_reduction(
                     lib, device, n_orb, 32768 if n_orb <= 64 else 8192 if n_orb <= 128 else 4096 if n_orb <= 256 else 2048)
 
@@ -1131,7 +1148,7 @@ def main():
             "scaling": "strong" if args.config == "cfg4" and not args.nk else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.dry_ranks else "synthetic; DRY RUN on the CPU (tools/standin_lib.py in place of libtbk, a 5-orbital model): launch mechanics only, the numbers mean nothing",
             "config": {
                 "workload": "%s: %s N_orb=%d N_R=%d, %d %s k-points per GPU, eigenval (H(k)+eig)"
                             % (args.config, arrays["kind"], n_orb, n_r, nk_gpu,

@@ -59,83 +59,13 @@ def test_hk_roofline_entries_price_the_documented_work():
 
 
 # ------------------------------------------------------------------------------------------------
-# bench.py's strong-scaling leg (cfg4 at N ranks) with N = 2 on the CPU: a stand-in for libtbk that keeps "device" buffers in
-# NumPy arrays, evaluates slabs with the oracle and does the all-gather through the process group -- what is checked is the
+# bench.py's strong-scaling leg (cfg4 at N ranks) with N = 2 / 8 on the CPU: tools/standin_lib.py stands in for libtbk ("device"
+# buffers in NumPy arrays, slabs evaluated by the oracle, the all-gather through the process group) -- what is checked is the
 # leg's own logic (slabs, result layout [rank][per][n], per-rank timings, parity rows of the first and the last slab, the
 # trace identity over the whole mesh), which no one-GPU box can run at N > 1.
 # ------------------------------------------------------------------------------------------------
-class _StandInLib:
-    def __init__(self, group, world, rank, arrays):
-        import ctypes
-
-        self.ctypes = ctypes
-        self.group, self.world, self.rank, self.arrays = group, world, rank, arrays
-        self.buffers = {}
-        self.next_id = 1
-
-    def _buf(self, pointer):
-        value = pointer.value if hasattr(pointer, "value") else pointer
-        return self.buffers[int(value)]
-
-    def tbk_device_malloc(self, device, nbytes, out):
-        handle = self.next_id
-        self.next_id += 1
-        self.buffers[handle] = np.zeros(int(nbytes) // 8 + 1)
-        out._obj.value = handle
-        return 0
-
-    def tbk_device_free(self, device, pointer):
-        self.buffers.pop(int(pointer.value), None)
-        return 0
-
-    def _host(self, pointer, count):
-        return np.ctypeslib.as_array(self.ctypes.cast(pointer, self.ctypes.POINTER(self.ctypes.c_double)), shape=(count,))
-
-    def tbk_memcpy_h2d(self, device, dst, src, nbytes):
-        self._buf(dst)[: nbytes // 8] = self._host(src, nbytes // 8)
-        return 0
-
-    def tbk_memcpy_d2h(self, device, dst, src, nbytes):
-        self._host(dst, nbytes // 8)[:] = self._buf(src)[: nbytes // 8]
-        return 0
-
-    def tbk_model_set_option(self, *args):
-        return 0
-
-    def tbk_synchronize(self, *args):
-        return 0
-
-    def tbk_comm_synchronize(self, *args):
-        return 0
-
-    def tbk_comm_ranks(self, comm, count, rank):
-        count._obj.value = self.world
-        return 0
-
-    def _eig(self, d_k, nk):
-        from oracle import tbk_oracle as oracle
-
-        k = self._buf(d_k)[: nk * 3].reshape(nk, 3)
-        return np.array(oracle.eigenval(self.arrays["R"], self.arrays["hop"], k)).reshape(nk, -1)
-
-    def tbk_eigenval_device_hint(self, model, d_k, h_k, nk, d_out):
-        eig = self._eig(d_k, nk)
-        self._buf(d_out)[: eig.size] = eig.reshape(-1)
-        return 0
-
-    fail_rank = -1  # this rank's solver "fails" inside the gather: like the library, it still walks every collective and
-    # its verdict reaches every rank through the status words (the LAST collective)
-
-    def tbk_eigenval_device_gather(self, comm, model, d_k, h_k, nk, per, host_status, d_all, d_status):
-        n = self.arrays["n_orb"]
-        slab = np.zeros((per, n))
-        if nk:
-            slab[:nk] = self._eig(d_k, nk)
-        pieces = self.group.all_gather_array(slab)
-        self._buf(d_all)[: self.world * per * n] = np.concatenate(pieces).reshape(-1)
-        mine = np.array([3.0 if self.rank == self.fail_rank else 0.0])
-        self._buf(d_status)[: self.world] = np.concatenate(self.group.all_gather_array(mine))
-        return 0
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from standin_lib import StandInLib as _StandInLib  # noqa: E402  pylint: disable=wrong-import-position
 
 
 def _strong_leg_worker(rank, world, out_dir, fail_rank=-1):
@@ -295,3 +225,35 @@ def test_summary_is_compact_and_carries_every_config():
     # a multi-rank line has no host_api / construct_only / other configs: still a valid summary
     bare = bench.make_summary({"value": 7.5e6, "ms_per_step": 105.0, "config": {"workload": "cfg2: ..."}, "configs": None})
     assert bare["cfg2"]["v"] == 7.5e6 and bare["host"] is None and len(json.dumps(bare)) < 700
+
+
+def test_the_scaling_drivers_command_runs_dry_on_eight_cpu_ranks():
+    """The exact command the SCALE driver runs on an 8-GPU node -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`` -- with ``--dry-ranks`` appended: eight rank
+    processes walk main()'s whole control flow on the CPU (rendezvous from the launcher's environment, the communicator, the
+    step loop with the overlapped gather, the per-rank split, the cfg4 strong-scaling leg, ONE JSON line from rank 0) with
+    tools/standin_lib.py in place of libtbk.  No scaling curve has ever been measured (no multi-GPU node in six rounds): this
+    keeps the path that will produce it runnable.  Independence / order of k-points: `_tb_model.py:1111-1123`, `:1148-1150`."""
+    import json
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-ranks"]
+    run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, check=False)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [line for line in run.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    record = json.loads(lines[0])
+    assert record["n_gpus"] == 8 and record["steps"] == 3 and record["warmup"] == 1 and record["scaling"] == "weak"
+    assert record["rccl_ranks"] == 8 and record["config"]["rccl_ranks"] == 8 and "DRY RUN" in record["data"]
+    assert record["strong_scaling"] == "ok"
+    assert len(record["per_rank"]["compute_ms"]) == 8 and len(record["per_rank"]["allgather_ms"]) == 8
+    leg = record["configs"]["cfg4"]
+    assert leg["scaling"] == "strong" and leg["n_gpus"] == 8 and leg["rccl_ranks"] == 8 and len(leg["per_rank"]["exposed_gather_ms"]) == 8
+    assert leg["max_abs_err_vs_oracle"] <= 1e-12 and record["max_abs_err_vs_oracle"] <= 1e-12
+    assert list(record)[-1] == "summary" and abs(record["summary"]["cfg4"]["v"] - leg["value"]) <= 1e-5 * leg["value"]
+    assert record["value"] > 0 and record["unit"] == "k-points/s" and record["value_host_buffers"] is None
