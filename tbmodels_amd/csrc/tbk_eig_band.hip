@@ -3363,13 +3363,18 @@ bool tbk_band_split(const tbk_model* m, int64_t nk) {
     // 6.05 -> 5.03 at 512, 13.98 -> 10.28 at 768, 24.35 -> 16.84 at 1024; 64 matrices: 2.23 -> 2.31 / 4.39 -> 4.43 / 6.80 -> 7.16 /
     // 22.5 -> 17.6 / 46.3 -> 35.1; 64 matrices of 512 orbitals in ONE launch of the eight-wave kernel: 8.09 ms -- so calls of up to 8
     // matrices up to 256 orbitals, 64 up to 512, 96 above.
+#ifdef TBK_EXPERIMENTS  // (TBK_BAND_SPLIT=2: round 4's chain, PHASE 1 / 2 of band_reduce_kernel -- dropped in round 5, experiments build only)
     static const bool old_chain = getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 2;
+#else
+    constexpr bool old_chain = false;
+#endif
     const int64_t limit = forced_limit > 0 ? forced_limit
                           : old_chain      ? (n <= 256 ? 8 : std::max(1, m->n_cu) / tbk_band_split_members(n, 8))
                                            : (n <= 256 ? 8 : n <= 512 ? 64 : 96);
     return std::max<int64_t>(m->call_nk, nk) <= limit;
 }
 
+#ifdef TBK_EXPERIMENTS
 template <int NT, int ROWS>
 static int launch_split(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t nk, d2* d_VW, d2* d_VN, d2* d_band, size_t lds) {
     constexpr int NW = NT / 64;
@@ -3398,6 +3403,7 @@ static int launch_split(tbk_model* m, hipStream_t s, double* d_H, int n, int64_t
     return TBK_OK;
 }
 
+#endif  // TBK_EXPERIMENTS
 // The first stage above 1024 orbitals: three launches per panel (serial phases / update sweep / product sweep), one more update
 // sweep for the last pending update, then the band's way out.
 static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t nk, double* d_D, double* d_E);
@@ -3422,6 +3428,7 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     // TBK_BAND_XL_SWEEPS=2 (measurements): the update sweep and the product sweep as two launches on ONE matrix buffer (the first
     // form of the chain: every tile crosses HBM four times per panel)
     static const bool two_sweeps = tbk_exp_env("TBK_BAND_XL_SWEEPS") && atoi(tbk_exp_env("TBK_BAND_XL_SWEEPS")) == 2;
+#ifdef TBK_EXPERIMENTS
     if (two_sweeps) {
         for (int p = 0; p <= p_end; ++p) {
             hipLaunchKernelGGL((band_xl_serial_kernel<NTS, false>), dim3((unsigned)nk), dim3(NTS), 0, s, d_H, n, d_VW, d_VN, d_XY, d_T, p,
@@ -3440,6 +3447,9 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
+#else
+    (void)two_sweeps;
+#endif
     // One sweep per panel between two matrix buffers (the caller's and ws_xl) that change roles; the finished rows go to the band
     // as the serial phases produce them, the rows behind the last panel come out of the buffer the last update leaves them in,
     // and the band is put back into the caller's buffer (the work copy tbk_tridiagonal_reduce hands out).
@@ -3450,7 +3460,8 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
     const size_t p_stride = xl_partial_doubles(n);
     TBK_CHECK(m->ws_xl.reserve((size_t)nk * n * n * 2 * sizeof(double) + (sweep4 ? (size_t)nk * p_stride * sizeof(double) : 0)));
     double* buf[2] = {d_H, m->ws_xl.as<double>()};
-    double* d_P = m->ws_xl.as<double>() + (size_t)nk * n * n * 2;
+    double* d_P = m->ws_xl.as<double>() + (size_t)nk * n * n * 2;  // (partial sums of the read-once sweep: experiments build)
+    (void)d_P;
     // up to 1024 orbitals (calls of a few matrices): the panel's rows in LDS (TBK_BAND_XL_YLDS=0: in global memory, as above 1024)
     static const bool y_lds_env = !(tbk_exp_env("TBK_BAND_XL_YLDS") && atoi(tbk_exp_env("TBK_BAND_XL_YLDS")) == 0);
     const bool y_lds = y_lds_env && n <= BAND_ONE_WG_MAXN;
@@ -3492,12 +3503,15 @@ static int launch_band_xl(tbk_model* m, hipStream_t s, double* d_H, int n, int64
                                    stride);
             if (p == p_end) break;
             const int i0 = PB * (p + 1) / TS, na = nbk - i0;
+#ifdef TBK_EXPERIMENTS
             if (sweep4) {
                 hipLaunchKernelGGL((band_xl_sweep4_kernel<NTP>), dim3((unsigned)((na + 3) / 4), (unsigned)nkg), dim3(NTP), 0, st, b[cur], b[cur ^ 1],
                                    n, vw, vn, xy, d_P + (size_t)k0 * p_stride, p_stride, i0, p > 0 ? 1 : 0);
                 hipLaunchKernelGGL(band_xl_xsum_kernel, dim3((unsigned)na, (unsigned)nkg), dim3(256), 0, st, xy, d_P + (size_t)k0 * p_stride,
                                    p_stride, n, i0);
-            } else {
+            } else
+#endif
+            {
                 hipLaunchKernelGGL((band_xl_sweep_kernel<NTP>), dim3((unsigned)na, (unsigned)nkg), dim3(NTP), 0, st, b[cur], b[cur ^ 1], n, vw, vn,
                                    xy, i0, (p > 0 ? 1 : 0) | walk_flag);
             }
@@ -3580,9 +3594,14 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     }
     d2* d_VW = static_cast<d2*>(d_vw);
     d2* d_VN = d_VW + (size_t)nk * nbk * 256;
+#ifdef TBK_EXPERIMENTS  // (TBK_BAND_SPLIT=2: round 4's chain, PHASE 1 / 2 of band_reduce_kernel -- dropped in round 5, experiments build only)
     static const bool old_chain = getenv("TBK_BAND_SPLIT") && atoi(getenv("TBK_BAND_SPLIT")) == 2;
+#else
+    constexpr bool old_chain = false;
+#endif
     if (d_de_fused == nullptr && tbk_band_split(m, nk) && !old_chain)
         return launch_band_xl(m, s, d_H, n, nk, static_cast<d2*>(d_vw), static_cast<d2*>(d_band));
+#ifdef TBK_EXPERIMENTS
     if (d_de_fused == nullptr && tbk_band_split(m, nk)) {
         // the launch chain: one row per thread where the rows allow it (the serial phases are thread-per-row)
         auto lds_for = [&](int waves, int rows) { return band_xv_bytes(npad, false, waves, rows) + (size_t)(waves * 16 * 17 + waves * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16; };
@@ -3590,6 +3609,7 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
         if (n <= 512) return launch_split<512, 1>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8, 1));
         return launch_split<512, 2>(m, s, d_H, n, nk, d_VW, d_VN, static_cast<d2*>(d_band), lds_for(8, 2));
     }
+#endif
     static std::atomic<bool> raised[6][TBK_MAX_DEVICES] = {};
 #define TBK_REDUCE(NTV, ROWSV, VNL, SLOT)                                                                                       \
     do {                                                                                                                        \
@@ -3601,10 +3621,15 @@ int tbk_launch_band_reduce(tbk_model* m, hipStream_t s, double* d_H, int64_t nk,
     // per CU instead of two, the per-wave overhead of the serial phases (reductions, scalar chains) paid half as often per
     // matrix; 38 KiB of LDS, second stage in its own launch
     static const bool narrow_env = tbk_exp_env("TBK_BAND_NARROW") && atoi(tbk_exp_env("TBK_BAND_NARROW")) != 0;
+#ifdef TBK_EXPERIMENTS
     if (narrow_env && !wide && n <= 256 && d_de_fused == nullptr) {
         lds = band_xv_bytes(npad, false, 2, 2) + (size_t)(2 * 16 * 17 + 2 * 64 + 64) * 8 + (16 + 64 + 64 + 8 + 2) * 16;
         TBK_REDUCE(128, 2, false, 5);
-    } else if (wide && vn_lds)
+    } else
+#else
+    (void)narrow_env;
+#endif
+    if (wide && vn_lds)
         TBK_REDUCE(512, 1, true, 3);
     else if (wide)
         TBK_REDUCE(512, 1, false, 4);
@@ -3665,10 +3690,15 @@ static int launch_chase(tbk_model* m, hipStream_t s, const void* d_band, int64_t
         const size_t stride = tbk_band_bytes_per_matrix(n) / sizeof(d2);
         if (nwg <= 4)
             hipLaunchKernelGGL(band_chase4g_kernel<4>, dim3((unsigned)nk), dim3(256), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
+#ifdef TBK_EXPERIMENTS
         else if (nwg <= 8)
             hipLaunchKernelGGL(band_chase4g_kernel<8>, dim3((unsigned)nk), dim3(512), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
         else
             hipLaunchKernelGGL(band_chase4g_kernel<12>, dim3((unsigned)nk), dim3(768), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
+#else
+        else
+            hipLaunchKernelGGL(band_chase4g_kernel<8>, dim3((unsigned)nk), dim3(512), ldsg, s, d_b, stride, n, np, 2, d_D, d_E);
+#endif
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
