@@ -690,7 +690,7 @@ def test_ql_pipeline_agrees_with_bisection_on_every_row(n_orb):
 @pytest.mark.parametrize("n, nk", [(513, 3), (600, 3), (777, 3), (1030, 3), (1300, 3), (300, 260), (385, 260), (449, 257), (512, 257), (600, 260), (768, 257)])
 def test_second_stage_in_the_lds_window_equals_the_one_in_global_memory(n, nk):
     """Above 512 orbitals the 16 working diagonals of the second stage do not fit the LDS: the ~490 columns the 32 sweeps in
-    flight touch live in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band.hip, band_chase4w_kernel;
+    flight touch live in a cyclic LDS window in front of the global buffer (csrc/tbk_eig_band_chase.hip, band_chase4w_kernel;
     tools/two_stage_model.py: stage2_window).  ``TBK_CHASE_WINDOW=0`` (read once per process, hence the child) works in global
     memory throughout (band_chase4g_kernel, the round-4 form).  257 - 768 orbitals: calls of more than 256 matrices take a window
     of 16 sweep slots and 272 columns in 78 KiB, so that two workgroups share a CU; with the switch off the plain LDS form up to
@@ -744,7 +744,7 @@ def test_the_read_once_sweep_above_1024_orbitals_stays_correct():
     """``TBK_BAND_XL_SWEEP4=1`` (a measurement switch of the EXPERIMENTS build of the library, `libtbk_experiments.so` -- the default
     library does not read it; read once per process, hence the child process): the panels' sweeps run four
     block rows per workgroup, every tile is read once and the transposed products are added up through partial sums
-    (csrc/tbk_eig_band.hip, band_xl_sweep4_kernel + band_xl_xsum_kernel; DESIGN_LOG.md R5.12: built, not faster, off by default).
+    (csrc/tbk_eig_band_xl.hip, band_xl_sweep4_kernel + band_xl_xsum_kernel; DESIGN_LOG.md R5.12: built, not faster, off by default).
     Same function as the one-row sweep: the spectra are those of the matrices (scipy's eigvalsh at _tb_model.py:1149), two runs
     give the same bits (the partial sums are added in a fixed order)."""
     import os
@@ -788,7 +788,7 @@ print("ok")
 
 
 def test_a_batch_above_1024_orbitals_in_groups_equals_its_matrices_one_at_a_time():
-    """Above 1024 orbitals a batch goes in groups of matrices on streams of their own (csrc/tbk_eig_band.hip, launch_band_xl:
+    """Above 1024 orbitals a batch goes in groups of matrices on streams of their own (csrc/tbk_eig_band_xl.hip, tbk_band_launch_xl:
     one group's serial phases and second stage under the other groups' sweeps).  Per matrix nothing may change: (d, e) and the
     band left in the work copy of a batch of 11 (two groups of 6 and 5) equal those of the same matrices reduced one per call,
     bit for bit (the independence of k-points at _tb_model.py:1111-1123)."""
@@ -917,7 +917,7 @@ def test_largest_sizes_of_the_own_path(n):
 @pytest.mark.parametrize("n", [66, 97, 130, 200, 300])
 def test_launch_chain_above_1024_orbitals_equals_the_model_at_small_sizes(n):
     """Above 1024 orbitals the first stage is a chain of launches with nothing per row in registers or LDS
-    (csrc/tbk_eig_band.hip, band_xl_*: serial phases / update sweep / product sweep per panel).  TBK_BAND_XL_FROM=64 (read
+    (csrc/tbk_eig_band_xl.hip, band_xl_*: serial phases / update sweep / product sweep per panel).  TBK_BAND_XL_FROM=64 (read
     once per process) sends EVERY two-stage size down that chain: the band it leaves must equal the NumPy model of the
     algorithm (tools/two_stage_model.py with the Gram-matrix panel QR) entry by entry, the tridiagonal behind the second
     stage must have the matrix' spectrum, a batch with scaled / diagonal members included, and the chain is deterministic."""

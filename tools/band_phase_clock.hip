@@ -8,6 +8,8 @@
 
 #define TBK_EXPERIMENTS 1  // (this driver flips the measurement switches: tbk_exp_env reads the environment)
 #include "../tbmodels_amd/csrc/tbk_eig_band.hip"
+#include "../tbmodels_amd/csrc/tbk_eig_band_chase.hip"
+#include "../tbmodels_amd/csrc/tbk_eig_band_xl.hip"
 
 void tbk_set_error(const char*, ...) {}
 int DevBuf::reserve(size_t) { return 0; }

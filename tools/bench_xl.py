@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Above 1024 orbitals: the own launch chain (csrc/tbk_eig_band.hip, band_xl_*) against rocsolver_zheevd_strided_batched,
+"""Above 1024 orbitals: the own launch chain (csrc/tbk_eig_band_xl.hip, band_xl_*) against rocsolver_zheevd_strided_batched,
 whole `eigenval` (H(k) of a dense N_R = 4 model + eigenvalues) of nk k-points, and the stage times of the own path.
 
     python tools/bench_xl.py [--own] [sizes ...]        (GPU box; default 1030 1536 2048; --own: without the rocSOLVER runs,
