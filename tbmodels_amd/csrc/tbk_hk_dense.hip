@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) hk_dense_kernel(const HkArgs a) {
 
 // Batches of at most 32 k-points (Z2Pack-style callers evaluate one k-point per call): the 128-row MFMA tile would
 // spend most of its work on padding (127/128 for one k-point), so this is a plain matrix-vector product on the vector
-// unit, bound by reading Bt ONCE (272 MB at N_orb = 64, N_R = 4096; 8.6 GB at N_orb = 512, N_R = 2048).
+// unit, bound by reading Bt ONCE (277 MB at N_orb = 64, N_R = 4096; 8.6 GB at N_orb = 512, N_R = 2048).
 //
 // Round 6: a streaming kernel built from independent WAVES.  A row of Bt is `2 ncol_pad` doubles = ncol_pad / 64 blocks of
 // 128 doubles; a wave owns one block (16 B per lane: one global_load_dwordx4 reads 1 KiB of the row -- 8-byte loads reach
