@@ -1151,7 +1151,8 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
             TBK_CHECK(rc_inline);
             if (!direct) TBK_HIP(hipMemcpyAsync(st + h_off, m->ws_out.ptr, h_bytes, hipMemcpyDeviceToHost, m->stream));
             TBK_CHECK(wait_main_stream(m));
-            std::memcpy(H_out, st + h_off, h_bytes);
+            static const bool no_copy = tbk_exp_env("TBK_ABLATE_NO_HOSTCOPY") != nullptr;  // (timing only: what the host copy costs)
+            if (!no_copy) std::memcpy(H_out, st + h_off, h_bytes);
             return TBK_OK;
         }
     }
