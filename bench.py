@@ -448,7 +448,8 @@ def single_k_latency(lib, model, k_slab, n_orb, calls=128, warm=8, arrays=None):
             "bound": "hbm", "kernel_us": round(hk_us, 2), "bytes": nbytes, "TB/s": round(rate, 3), "peak": 8.0,
             "frac": round(rate / 8.0, 4),
             "note": "HIP events around the H(k) stage of a one-k hamilton call (all its kernels and the gaps between them); "
-                    "bytes = one read of the staged operand + one write of the full H; kernel traces: profiles/*_single_k_*.csv",
+                    "bytes = one read of the staged operand + one write of the full H; kernel traces: profiles/*_single_k_*.csv; "
+                    "PMC (profiles/r06_single_k.txt): hk_gemv_kernel fetches 1.006 x / 1.003 x the staged bytes at cfg2 / cfg5",
         }
     _lib.check(lib.tbk_model_set_option(model, _lib.TBK_OPT_TIMING, 1))  # (the callers measure with stage timing on)
     _lib.check(lib.tbk_get_timing(model, None, None, 1))
