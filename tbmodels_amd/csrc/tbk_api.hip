@@ -441,12 +441,20 @@ static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
     // above 64 orbitals a chunk is a few thousand matrices: every kernel of the eigensolver ends on a partly filled
     // round of workgroups, and 2 - 3 times longer chunks were worth 3 - 4 % (cfg3 3846 -> 12500 matrices per chunk,
     // cfg5 1250 -> 5000)
-    int64_t budget = std::min<int64_t>((int64_t)(free_b / 4), int64_t(n > 64 ? 24 : 6) << 30);
+    // Round 6: 65 - 256 orbitals take chunks as long as 64 GiB allow (up to 131072 k-points).  At these sizes the reduction is
+    // ~90 % of a chunk and its neighbours in the pipeline (the next chunk's H(k), the previous chunk's bisection) run on the
+    // same FP64 pipes: overlapping them buys nothing, every chunk boundary costs the partly filled last rounds of its kernels
+    // -- whole eigenval, us per k-point, chunks of 16384 / 32768 / 65536 / 131072: 0.4095 / 0.4060 / 0.4041 / 0.4024 at 96
+    // orbitals, 2.291 / 2.264 / 2.247 / 2.228 at 160, 5.668 / 5.586 / 5.531 / 5.518 at 256; cfg3 170.8 -> 176.4 k k-points/s in ONE
+    // chunk.  Above 256 orbitals the second stage is a launch of its own that does fill gaps: cfg5 16.63 k in chunks of 4096,
+    // 16.51 k in one.
+    const bool mid = n > 64 && n <= 256;
+    int64_t budget = std::min<int64_t>((int64_t)(free_b / 4), int64_t(mid ? 64 : n > 64 ? 24 : 6) << 30);
     int64_t chunk = budget / per_k / TBK_BM * TBK_BM;
     // 32768 k-points per chunk at 64 orbitals and above; small matrices take proportionally more (up to 1 M at 8
     // orbitals): a chunk is ~6 launches and one QL latency chain whatever its size, and 20 M k-points of an
     // 8-orbital model spent 42 of 92 GPU-ms in 612 of those chains
-    int64_t cap = 32768;
+    int64_t cap = mid ? 131072 : 32768;
     if (n < 64) cap *= std::min<int64_t>(32, (64 / n) * (64 / n));
     chunk = std::max<int64_t>(TBK_BM, std::min<int64_t>(chunk, cap));
     if (m->k_chunk > 0) chunk = round_up(m->k_chunk, TBK_BM);
