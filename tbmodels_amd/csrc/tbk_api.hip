@@ -438,6 +438,10 @@ static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
     if (per_k < 64) per_k = 64;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
+    // (what this handle's grow-only chunk workspaces hold already is as good as free: counted out, the second call of a model
+    // chose a smaller chunk than the first -- cfg3: one chunk in the warm-up, two from then on)
+    free_b += m->ws_H.bytes + m->ws_H2.bytes + m->ws_phase.bytes + m->ws_band.bytes + m->ws_bandmat[0].bytes + m->ws_bandmat[1].bytes +
+              m->ws_E.bytes + m->ws_xl.bytes;
     // above 64 orbitals a chunk is a few thousand matrices: every kernel of the eigensolver ends on a partly filled
     // round of workgroups, and 2 - 3 times longer chunks were worth 3 - 4 % (cfg3 3846 -> 12500 matrices per chunk,
     // cfg5 1250 -> 5000)
