@@ -525,12 +525,10 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         stage_n = {stage_name: launches[i] for i, stage_name in enumerate(_lib.STAGE_NAMES)}
         eig = np.empty((nk, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig), d_e, eig.nbytes))
-        moment_err = None
-        if n_orb > 64:
-            # sum E^2 = ||H(k)||_F^2 on 4096 rows (512 at 512 orbitals: 4 MiB of H per row) -- the eigensolver held to H itself
-            moment_rows = 4096 if n_orb <= 256 else 512
-            moment_err = second_moment_error(lib, model, n_orb, k, eig, moment_rows)
-            _lib.check(lib.tbk_get_timing(model, None, None, 1))
+        # sum E^2 = ||H(k)||_F^2 on 4096 rows (512 at 512 orbitals: 4 MiB of H per row) -- the eigensolver held to H itself
+        moment_rows = 4096 if n_orb <= 256 else 512
+        moment_err = second_moment_error(lib, model, n_orb, k, eig, moment_rows)
+        _lib.check(lib.tbk_get_timing(model, None, None, 1))
         single = None
         if os.environ.get("TBK_BENCH_SKIP_HOSTAPI") != "1":
             # (a one-k call at 512 orbitals takes ~10 ms: fewer of them)
@@ -580,7 +578,7 @@ def run_other_config(lib, device, name, model=None, arrays=None, steps=2, warmup
         "max_second_moment_err": moment_err,
         "second_moment_note": None if moment_err is None else
                               "max |sum E^2 - ||H(k)||_F^2| / (2 sum |E|) over %d rows of the workload, H(k) from tbk_hamilton"
-                              % (4096 if n_orb <= 256 else 512),
+                              % min(nk, 4096 if n_orb <= 256 else 512),
         "model_build_and_staging_s": round(build_s, 2),
     }
     if not (parity <= 1e-10 and trace_err <= 1e-10 and (moment_err is None or moment_err <= 1e-10)):
@@ -1071,6 +1069,7 @@ def main():
     #      slab, so every k chunk of the pipeline is covered (host work independent of the GPU path)
     eig_head = np.empty((min(nk_gpu, 64), n_orb))
     trace_err = None
+    moment_err = None
     parity_all = None
     if not args.construct_only and rank == 0:
         d_e = d_e_pair[(step_no[0] - 1) & 1]  # the buffer of the last step
@@ -1078,6 +1077,9 @@ def main():
         eig_all = np.empty((nk_gpu, n_orb))
         _lib.check(lib.tbk_memcpy_d2h(device, _lib.ptr(eig_all), d_e, eig_all.nbytes))
         trace_err = trace_identity_error(arrays, k_slab, eig_all)
+        if not args.dry_ranks:
+            moment_err = second_moment_error(lib, model, n_orb, k_slab, eig_all, 4096 if n_orb <= 256 else 512)
+            _lib.check(lib.tbk_get_timing(model, None, None, 1))
         if cpu_all_rows is not None and len(cpu_all_rows):
             # every row the all-core CPU baseline computed (the first rows of this slab) against the GPU's eigenvalues
             parity_all = float(np.abs(cpu_all_rows - eig_all[:len(cpu_all_rows)]).max())
@@ -1174,6 +1176,7 @@ def main():
             "oracle_sample": "%d rows (the first %d k-points of the slab%s)"
                              % (oracle_rows, oracle_rows, ": the rows of cpu_baseline_all_cores" if parity_all is not None else ""),
             "max_trace_identity_err_4096_rows": trace_err,
+            "max_second_moment_err": moment_err,
             "construct_only": construct,
             "strong_scaling": None,
         }
@@ -1202,7 +1205,7 @@ def main():
     if group is not None:
         group.close()
     if rank == 0 and result:
-        for key in ("max_abs_err_vs_oracle", "max_trace_identity_err_4096_rows"):
+        for key in ("max_abs_err_vs_oracle", "max_trace_identity_err_4096_rows", "max_second_moment_err"):
             if result.get(key) is not None and not result[key] <= 1e-10:
                 raise SystemExit("parity failure: %s = %g" % (key, result[key]))
     if strong_failed:

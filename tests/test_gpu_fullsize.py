@@ -40,6 +40,9 @@ def test_config2_headline_shape_100k():
     assert np.all(np.diff(eig, axis=1) >= 0)
     traces = np.einsum("rii->r", hop)
     assert np.abs(eig.sum(axis=1) - _trace_from_hoppings(r_vec, traces, k)).max() < 1e-10
+    import bench
+
+    assert bench.second_moment_error(_lib.lib(), model._staged(), 64, k, eig, 4096) < 1e-10  # sum E^2 = ||H(k)||_F^2 on 4096 rows
     # periodicity, and independence of position in the batch (different chunk / tile for every k)
     perm = np.random.default_rng(3).permutation(len(k))
     shifted = k[perm] + np.array([2.0, -1.0, 5.0])
@@ -193,6 +196,10 @@ def test_config4_headline_model_on_the_100_cubed_mesh():
     rows = np.sort(np.random.default_rng(6).choice(n ** 3, 4096, replace=False))
     traces = np.einsum("rii->r", hop)
     assert np.abs(whole[rows].sum(axis=1) - _trace_from_hoppings(r_vec, traces, k[rows])).max() < 1e-10
+    import bench
+
+    # (the second moment with H(k) from the DIRECT evaluation -- random rows are no mesh -- against the folded eigenvalues)
+    assert bench.second_moment_error(_lib.lib(), model._staged(), 64, k, whole, 4096) < 1e-10
     # 192 rows against the oracle
     idx = np.sort(np.random.default_rng(7).choice(n ** 3, 192, replace=False))
     ref = np.array(oracle.eigenval(r_vec, hop, k[idx]))
