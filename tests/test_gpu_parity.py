@@ -203,6 +203,32 @@ def test_small_batches_vs_oracle(n_k):
     assert np.array_equal(again, np.conj(np.swapaxes(again, 1, 2)))  # exactly Hermitian
 
 
+@pytest.mark.parametrize("n_orb", [1, 2, 3, 7, 11, 12, 23, 33, 64, 65, 100, 181, 300])
+def test_matrix_vector_path_over_shapes(n_orb):
+    """The matrix-vector kernel of round 6 cuts its work into (blocks of 64 packed elements) x (slices of whole lattice vectors)
+    per WAVE, the slices ragged (K rows / slices is no whole number), one round of two workgroups per CU or many rounds, the
+    phase rows in a wave-private LDS strip or -- strip too short -- handed in (`csrc/tbk_hk_dense.hip`: gemv_plan,
+    tbk_hk_inline_phases).  Every combination of 13 orbital counts (1 .. 300: one block of 64 elements .. 706 blocks, with and
+    without padding), 8 lattice-vector counts (1 .. 1500: one slice of 16 rows .. hundreds) and 7 batch sizes (every
+    instantiation, full and ragged) against the oracle: H(k) in both conventions, and the eigenvalues
+    (`_tb_model.py:1109-1128`, `:1147-1150`)."""
+    rng = np.random.default_rng(600 + n_orb)
+    for n_r in (1, 2, 7, 8, 9, 100, 257, 1500):
+        if n_orb * n_orb * n_r > 3e7:  # (the oracle's time, not the kernel's limit)
+            continue
+        r_vec, hop, pos = syn.dense_model_arrays(n_orb, n_r, syn.MODEL_SEED + 7 * n_orb + n_r)
+        model = tbmodels_amd.Model.from_packed(r_vec, hop, pos=pos)
+        for n_k in (1, 2, 3, 5, 9, 17, 32):
+            k = rng.random((n_k, 3)) * 4.0 - 2.0
+            arg = k[0] if n_k == 1 else k
+            want = oracle.hamilton(r_vec, hop, k)
+            _close(np.asarray(model.hamilton(arg)).reshape(want.shape), want)
+            want1 = oracle.hamilton(r_vec, hop, k, 1, pos=pos)
+            _close(np.asarray(model.hamilton(arg, convention=1)).reshape(want1.shape), want1)
+            if n_k in (1, 5, 32):
+                _close(np.asarray(model.eigenval(arg)).reshape(n_k, n_orb), np.array(oracle.eigenval(r_vec, hop, k)))
+
+
 def _grid(shape, offset=(0.0, 0.0, 0.0), order="ij"):
     axes = [np.linspace(0, 1, n, endpoint=False) + o for n, o in zip(shape, offset)]
     mesh = np.meshgrid(*axes, indexing=order)
