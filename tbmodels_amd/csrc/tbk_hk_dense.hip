@@ -453,6 +453,81 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_
     }
 }
 
+// ONE k-point of a SMALL model (at most 4 blocks of 64 packed elements, i.e. up to 22 orbitals -- most tight-binding models a
+// Z2Pack-style caller brings): the whole H(k) in one launch.  A workgroup owns a block, its four waves take a quarter of the K rows
+// each (the loop of hk_gemv_kernel: 16-byte loads, the wave's phase rows in its LDS strip), meet once, and wave 0 adds the four
+// partial sums in wave order and stores the elements -- hk_gemv_kernel + hk_finish_kernel were two dependent launches of ~3 us each
+// around a ~2 us boundary for a call that takes 24 us end to end (silicon).
+template <int MODE, int CONV>
+__global__ void __launch_bounds__(256) hk_tiny_kernel(const HkArgs a, int strip_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double s_tiny[];  // [4][strip_doubles] phase rows, then [4][64] (re, im) partial sums
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.x;
+    const int64_t n_pairs = a.k2 >> 1;
+    const int64_t kk0 = 2 * (wave * n_pairs / 4);
+    const int n_rows = (int)(2 * ((wave + 1) * n_pairs / 4) - kk0);  // k2 is a multiple of 16: at least four rows per wave
+    const int64_t ld2 = a.ncol_pad;
+    const d2* rows = reinterpret_cast<const d2*>(a.Bt) + kk0 * ld2 + cb * 64;
+    double* strip = s_tiny + wave * strip_doubles;
+    d2* part = reinterpret_cast<d2*>(s_tiny + 4 * strip_doubles);  // [4][64]
+    d2 buf0[GEMV_U], buf1[GEMV_U];
+    auto fetch = [&](d2 (&buf)[GEMV_U], int base) {
+#pragma unroll
+        for (int u = 0; u < GEMV_U; ++u) buf[u] = rows[(int64_t)min(base + u, n_rows - 1) * ld2 + lane];
+    };
+    fetch(buf0, 0);
+    fetch(buf1, GEMV_U);
+    for (int rr = lane; rr < ((n_rows + 15) >> 4) * 8; rr += 64) {
+        const int64_t r = (kk0 >> 1) + rr;
+        double sn = 0.0, cs = 0.0;
+        if (r < a.n_r && 2 * rr < n_rows) {
+            double dot = 0.0;
+            for (int d = 0; d < a.dim; ++d) dot = fma(hk_kcomp(a, 0, d), (double)a.R[r * a.dim + d], dot);
+            sincospi(2.0 * dot, &sn, &cs);
+        }
+        strip[2 * rr] = cs;
+        strip[2 * rr + 1] = sn;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave's own strip: its LDS operations execute in order)
+    double acc0 = 0.0, acc1 = 0.0;
+    auto consume = [&](const d2 (&buf)[GEMV_U], int row) {
+#pragma unroll
+        for (int u = 0; u < GEMV_U; ++u) {
+            const double aq = strip[row + u];  // (zero past the slice's end)
+            acc0 = fma(aq, buf[u][0], acc0);
+            acc1 = fma(aq, buf[u][1], acc1);
+        }
+    };
+    for (int row = 0; row < n_rows; row += 2 * GEMV_U) {
+        consume(buf0, row);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(buf0, row + 2 * GEMV_U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(buf1, row + GEMV_U);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(buf1, row + 3 * GEMV_U);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // (re, re') / (im, im') of elements e0, e0 + 1 in lanes l and l ^ 8 -> (re, im) pairs, as in hk_gemv_kernel
+    const bool hi = (lane & 8) != 0;
+    const int el = (lane >> 4) * 16 + (lane & 7) * 2 + (hi ? 1 : 0);
+    const double got = __shfl_xor(hi ? acc0 : acc1, 8, 64);
+    part[wave * 64 + el] = hi ? (d2){got, acc1} : (d2){acc0, got};
+    __syncthreads();
+    if (wave != 0) return;
+    const int e = cb * 64 + lane;
+    const int32_t ij = a.colmap[e];
+    if (ij < 0) return;
+    d2 sum = part[lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        sum[0] += part[w * 64 + lane][0];
+        sum[1] += part[w * 64 + lane][1];
+    }
+    store_element<MODE, CONV>(a, 0, ij >> 16, ij & 0xffff, sum[0], sum[1]);
+}
+
 // split-K finish: one thread per (k-point, packed element) adds the partial tiles in split order and stores the
 // element like the epilogue above.
 template <int MODE, int CONV>
@@ -785,6 +860,21 @@ int tbk_launch_hk_dense(tbk_model* m, const double* d_A, int64_t nk, int64_t nk_
         }
         TBK_ARG(d_A != nullptr || (tbk_hk_inline_phases(m, nk) && (d_k != nullptr || a.k_inline)), "phase rows missing");
         TBK_ARG(convention != 1 || mode == HK_TRI || d_pos != nullptr || (a.k_inline && a.pos_raw != nullptr), "convention 1 needs the orbital phases");
+        if (nk == 1 && d_A == nullptr && a.ncol_pad <= 256 && m->k2 <= 4096) {  // (<= 36 KiB of LDS)
+            // one k-point of a small model: the whole H(k) in ONE launch (hk_tiny_kernel)
+            const int strip = (int)(((m->k2 / 2 + 3) / 4 * 2 + 15) / 16 * 16);  // rows of the longest quarter, whole trips of the loop
+            const size_t lds_tiny = ((size_t)4 * strip + 4 * 64 * 2) * sizeof(double);
+            const dim3 grid_tiny((unsigned)(a.ncol_pad / 64));
+            StageTimer t(m, TBK_T_HK);
+            if (mode == HK_TRI)
+                hipLaunchKernelGGL((hk_tiny_kernel<HK_TRI, 2>), grid_tiny, dim3(256), lds_tiny, m->stream, a, strip);
+            else if (convention == 1)
+                hipLaunchKernelGGL((hk_tiny_kernel<HK_FULL, 1>), grid_tiny, dim3(256), lds_tiny, m->stream, a, strip);
+            else
+                hipLaunchKernelGGL((hk_tiny_kernel<HK_FULL, 2>), grid_tiny, dim3(256), lds_tiny, m->stream, a, strip);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
         TBK_CHECK(m->ws_part.reserve(per_split * slices));
         a.P = m->ws_part.as<double>();
         a.splits = slices;
