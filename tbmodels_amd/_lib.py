@@ -138,11 +138,12 @@ def check(status):
 
 
 def ptr(array):
-    """``void*`` of a C-contiguous numpy array (or None)."""
+    """Address of a C-contiguous numpy array as an ``int`` (or None): what a ``void*`` parameter of the ctypes signatures takes.
+    (``array.ctypes.data_as(c_void_p)`` builds two ctypes objects per call: 2.1 us against 0.9 -- three pointers per one-k call.)"""
     if array is None:
         return None
-    assert array.flags["C_CONTIGUOUS"]
-    return array.ctypes.data_as(ctypes.c_void_p)
+    assert array.flags.c_contiguous
+    return array.__array_interface__["data"][0]
 
 
 def device_count():

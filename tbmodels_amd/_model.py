@@ -515,6 +515,7 @@ class Model:
         state["_handles"] = []
         state["_staged_fingerprint"] = None
         state.pop("_call_lock", None)
+        state.pop("_handle_array_cache", None)  # (a ctypes array of device handles: neither picklable nor valid elsewhere)
         return state
 
     def __setstate__(self, state):
@@ -667,7 +668,11 @@ class Model:
 
     def _handle_array(self):
         handles = self._staged_all()
-        return (ctypes.c_void_p * len(handles))(*[h.value for h in handles]), len(handles)
+        cached = getattr(self, "_handle_array_cache", None)
+        if cached is None or cached[0] is not handles:  # (the list object changes whenever the model is re-staged)
+            cached = (handles, (ctypes.c_void_p * len(handles))(*[h.value for h in handles]))
+            self._handle_array_cache = cached
+        return cached[1], len(handles)
 
     def set_option(self, option, value):
         """Forward a ``TBK_OPT_*`` option to the staged model (see ``include/tbk.h``)."""

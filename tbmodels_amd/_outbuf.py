@@ -15,6 +15,7 @@ keep their mapping for themselves; it is unmapped with them.
 The reference returns arrays that own their data (``out.flags.owndata``); these do not -- nothing else differs.
 """
 
+import math
 import mmap
 import threading
 import weakref
@@ -48,7 +49,7 @@ def _trim():
 def empty(shape, dtype):
     """Like ``np.empty(shape, dtype)`` (C order); large arrays come from the recycled mappings."""
     dtype = np.dtype(dtype)
-    count = int(np.prod(shape, dtype=np.int64))
+    count = math.prod(shape)  # (np.prod of a three-element tuple: 2.9 us of a 25 us one-k call)
     nbytes = count * dtype.itemsize
     if nbytes < MIN_BYTES:
         return np.empty(shape, dtype)
