@@ -433,6 +433,8 @@ extern "C" int tbk_model_info(const tbk_model* m, int* device, int* dim, int* n_
 // the chunked pipeline
 // ------------------------------------------------------------------------------------------------
 static int64_t choose_chunk(tbk_model* m, int64_t nk, bool with_eig) {
+    // (a call of up to one k tile is one chunk whatever the memory: no hipMemGetInfo -- a driver query -- on the one-k path)
+    if (nk <= TBK_BM) return TBK_BM;
     const int64_t n = m->n_orb;
     int64_t per_k = m->k2 * 8 + (with_eig ? n * n * 16 + (int64_t)tbk_eig_scratch_per_k(m) : 0);
     if (per_k < 64) per_k = 64;
