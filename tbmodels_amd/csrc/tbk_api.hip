@@ -1157,7 +1157,8 @@ extern "C" int tbk_hamilton(tbk_model* m, const double* k, int64_t nk, int conve
             // across PCIe: 1.69 -> 1.81 ms), so a bigger H still takes the copy; downloading it in two or four pieces, each
             // copied on to the caller's array while the next crosses PCIe, was measured and is within the noise of the
             // 1.3 - 1.4 ms kernel in front of it (1586 / 1661 / 1704 and 1568 / 1613 / 1563 us for 1 / 2 / 4 pieces).
-            const bool direct = h_bytes <= (size_t(1) << 20);
+            static const size_t direct_max = tbk_exp_env("TBK_ZERO_COPY_MAX") ? (size_t)atoll(tbk_exp_env("TBK_ZERO_COPY_MAX")) : (size_t(1) << 20);
+            const bool direct = h_bytes <= direct_max;
             double* d_out = direct ? reinterpret_cast<double*>(st + h_off) : m->ws_out.as<double>();
             const int rc_inline = tbk_hamilton_device(m, m->ws_k.as<double>(), nk, convention, d_pos, d_out);
             m->h_k_inline = nullptr;
