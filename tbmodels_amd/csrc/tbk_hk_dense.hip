@@ -362,6 +362,9 @@ constexpr int GEMV_U = 8;  // rows per batch of loads; two batches in flight
 template <int NKV, bool INLINE_PHASES>
 __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_doubles) {
     extern __shared__ __attribute__((aligned(16))) double s_rows[];  // [4 waves][strip_doubles]: phase rows [row][NKV] of the wave's slice
+    // (32 k-points: 64 accumulators -- batches of four loads, or the kernel needs copies through accumulation registers and
+    // runs one wave per SIMD: H(k) stage of 32 k-points at the headline shape 158 us)
+    constexpr int U = NKV >= 32 ? 4 : GEMV_U;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nblk = a.ncol_pad >> 6;
@@ -378,27 +381,27 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_
     const d2* rows = reinterpret_cast<const d2*>(a.Bt) + kk0 * ld2 + cb * 64;
     double* strip = s_rows + wave * strip_doubles;
 
-    d2 buf0[GEMV_U], buf1[GEMV_U];
+    d2 buf0[U], buf1[U];
     double acc[NKV][2];
 #pragma unroll
     for (int q = 0; q < NKV; ++q) acc[q][0] = acc[q][1] = 0.0;
 
-    // a batch of GEMV_U rows; rows past the slice's end re-read its last row (a cache hit) and are skipped by consume().  No
+    // a batch of U rows; rows past the slice's end re-read its last row (a cache hit) and are skipped by consume().  No
     // branch around a batch: behind a merge of control flow the compiler's wait counts assume the SHORTER queue, and the
     // first use of one batch would wait for the whole of the next
-    auto fetch = [&](d2 (&buf)[GEMV_U], int base) {
+    auto fetch = [&](d2 (&buf)[U], int base) {
 #pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int r = min(base + u, n_rows - 1);
             buf[u] = __builtin_nontemporal_load(rows + (int64_t)r * ld2 + lane);
         }
     };
-    auto consume = [&](const d2 (&buf)[GEMV_U], int row) {
+    auto consume = [&](const d2 (&buf)[U], int row) {
         // uniform: phase row `row`, k-points 0 .. NKV-1
         const double* arow = INLINE_PHASES ? strip + row * NKV : a.A + (kk0 + row) * a.nk_pad + kbase;
         const int64_t lda = INLINE_PHASES ? NKV : a.nk_pad;
 #pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (!INLINE_PHASES && row + u >= n_rows) break;  // (the strip holds zeros past the slice's end; finished rows end with A)
 #pragma unroll
             for (int q = 0; q < NKV; ++q) {
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_
         }
     };
     fetch(buf0, 0);
-    fetch(buf1, GEMV_U);
+    fetch(buf1, U);
     if (INLINE_PHASES) {
         // n_rows / 2 lattice vectors x NKV k-points, cos and sin of each; zeros up to the next multiple of 16 rows
         for (int idx = lane; idx < ((n_rows + 15) >> 4) * 8 * NKV; idx += 64) {
@@ -426,16 +429,16 @@ __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave writes and reads the strip: its LDS operations execute in order
     }
-    for (int row = 0; row < n_rows; row += 2 * GEMV_U) {
+    for (int row = 0; row < n_rows; row += 2 * U) {
         // (scheduling fences: left alone, the compiler sinks both batches of loads below both batches of FMAs, and the queue
         // runs empty once per trip)
         consume(buf0, row);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(buf0, row + 2 * GEMV_U);
+        fetch(buf0, row + 2 * U);
         __builtin_amdgcn_sched_barrier(0);
-        consume(buf1, row + GEMV_U);
+        consume(buf1, row + U);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(buf1, row + 3 * GEMV_U);
+        fetch(buf1, row + 3 * U);
         __builtin_amdgcn_sched_barrier(0);
     }
     // lanes l and l ^ 8 hold (re, re') and (im, im') of elements e0, e0 + 1: after the exchange lane l writes element e0,
