@@ -362,8 +362,8 @@ constexpr int GEMV_U = 8;  // rows per batch of loads; two batches in flight
 template <int NKV, bool INLINE_PHASES>
 __global__ void __launch_bounds__(256) hk_gemv_kernel(const HkArgs a, int strip_doubles) {
     extern __shared__ __attribute__((aligned(16))) double s_rows[];  // [4 waves][strip_doubles]: phase rows [row][NKV] of the wave's slice
-    // (32 k-points: 64 accumulators -- batches of four loads, or the kernel needs copies through accumulation registers and
-    // runs one wave per SIMD: H(k) stage of 32 k-points at the headline shape 158 us)
+    // (32 k-points: 64 accumulators -- with batches of four loads the kernel needs 168 registers instead of 242 plus copies through
+    // accumulation registers; the H(k) stage of 32 k-points at the headline shape is 158 us either way, DESIGN_LOG.md R6.11)
     constexpr int U = NKV >= 32 ? 4 : GEMV_U;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
